@@ -1,0 +1,249 @@
+"""Functional torch-CPU restatement of the reference's Vector-Neuron layers and the
+VN-PointNet / VN-FoldingNet networks.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Tensors use the reference layout ``[B, C, 3, N, ...]`` (models/vn_layers.py:19).
+Parameters are passed as plain tensors / a dict keyed by the reference's
+``state_dict`` names, so the same weights drive the reference (when generating the
+golden fixtures), this oracle and the HIP path.
+
+Parity status: PINNED — every function here is checked against the imported
+reference by ``tests/golden/make_golden.py`` (run in the build container) and against
+the committed fixtures by ``tests/test_oracle_golden.py``.
+"""
+from __future__ import annotations
+
+import torch
+
+EPS = 1e-6          # models/vn_layers.py:10
+BN_EPS = 1e-5       # torch.nn.BatchNorm default (models/vn_layers.py:111-114)
+BN_MOMENTUM = 0.1
+LN_EPS = 1e-5       # torch.nn.LayerNorm default (models/vn_layers.py:135)
+
+
+# --------------------------------------------------------------------------- layers
+def vn_linear(x, w):
+    """models/vn_layers.py:12-22: y[b,o,t,...] = sum_c w[o,c] x[b,c,t,...]."""
+    return torch.einsum("oc,bc...->bo...", w, x)
+
+
+def _leaky_project(p, d, negative_slope):
+    """Shared tail of models/vn_layers.py:38-42 and :70-73."""
+    dot = (p * d).sum(2, keepdim=True)
+    dsq = (d * d).sum(2, keepdim=True)
+    neg = (dot < 0).to(p.dtype)
+    return p - (1.0 - negative_slope) * neg * (dot / (dsq + EPS)) * d
+
+
+def vn_leaky_relu(x, w_dir, negative_slope=0.2):
+    """models/vn_layers.py:25-43 (share_nonlinearity handled by w_dir having 1 row)."""
+    d = vn_linear(x, w_dir)
+    return _leaky_project(x, d, negative_slope)
+
+
+def vn_batchnorm(x, gamma, beta, running_mean=None, running_var=None, training=True):
+    """models/vn_layers.py:107-127.  Returns (y, new_running_mean, new_running_var).
+
+    Norm over the 3-axis plus EPS, BatchNorm over every axis except channels,
+    x / norm * norm_bn.  Running stats follow torch: momentum 0.1, unbiased variance.
+    """
+    norm = torch.sqrt((x * x).sum(2)) + EPS                      # [B, C, N, ...]
+    red = [i for i in range(norm.dim()) if i != 1]
+    shape = [1, -1] + [1] * (norm.dim() - 2)
+    if training:
+        mean = norm.mean(red)
+        var = norm.var(red, unbiased=False)
+        count = norm.numel() // norm.shape[1]
+        if running_mean is not None:
+            new_rm = (1 - BN_MOMENTUM) * running_mean + BN_MOMENTUM * mean.detach()
+            new_rv = (1 - BN_MOMENTUM) * running_var + BN_MOMENTUM * var.detach() * count / max(count - 1, 1)
+        else:
+            new_rm = new_rv = None
+    else:
+        mean, var = running_mean, running_var
+        new_rm, new_rv = running_mean, running_var
+    norm_bn = (norm - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS) * gamma.view(shape) + beta.view(shape)
+    y = x / norm.unsqueeze(2) * norm_bn.unsqueeze(2)
+    return y, new_rm, new_rv
+
+
+def vn_linear_leaky_relu(x, w_feat, w_dir, gamma, beta, running_mean=None, running_var=None,
+                         training=True, negative_slope=0.2):
+    """models/vn_layers.py:46-74: direction comes from the layer INPUT (:69)."""
+    p = vn_linear(x, w_feat)
+    p, rm, rv = vn_batchnorm(p, gamma, beta, running_mean, running_var, training)
+    d = vn_linear(x, w_dir)
+    return _leaky_project(p, d, negative_slope), rm, rv
+
+
+def vn_linear_and_leaky_relu(x, w_lin, w_dir, negative_slope=0.2):
+    """models/vn_layers.py:77-104 with use_batchnorm='none': direction from the linear OUTPUT."""
+    y = vn_linear(x, w_lin)
+    return vn_leaky_relu(y, w_dir, negative_slope)
+
+
+def vn_max_pool(x, w_dir, return_index=False):
+    """models/vn_layers.py:153-167: argmax over the last axis of <x, W_d x>."""
+    d = vn_linear(x, w_dir)
+    dot = (x * d).sum(2, keepdim=True)                            # [B,C,1,N]
+    idx = dot.argmax(dim=-1, keepdim=True)                        # first maximum
+    shape = list(idx.shape)
+    shape[2] = 3
+    out = torch.gather(x, -1, idx.expand(shape)).squeeze(-1)
+    if return_index:
+        return out, idx.squeeze(-1).squeeze(2), dot.squeeze(2)
+    return out
+
+
+def mean_pool(x, dim=-1, keepdim=False):
+    """models/vn_layers.py:170-171."""
+    return x.mean(dim=dim, keepdim=keepdim)
+
+
+def vn_layer_norm(x, gamma, beta):
+    """models/vn_layers.py:129-150: LayerNorm over the channel axis of the vector norms."""
+    norm = torch.sqrt((x * x).sum(2)) + EPS                      # [B, C, N]
+    nt = norm.transpose(2, 1)                                     # [B, N, C]
+    mu = nt.mean(-1, keepdim=True)
+    var = nt.var(-1, unbiased=False, keepdim=True)
+    nl = (nt - mu) / torch.sqrt(var + LN_EPS) * gamma + beta      # [B, N, C]
+    nl = nl.transpose(2, 1)                                       # [B, C, N]
+    return x / norm.unsqueeze(2) * nl.unsqueeze(2)
+
+
+# ------------------------------------------------------------------------- networks
+def _bn(sd, prefix):
+    return (sd[prefix + ".batchnorm.bn.weight"], sd[prefix + ".batchnorm.bn.bias"],
+            sd.get(prefix + ".batchnorm.bn.running_mean"), sd.get(prefix + ".batchnorm.bn.running_var"))
+
+
+def _lin_leaky(sd, prefix, x, training, new_stats):
+    g, b, rm, rv = _bn(sd, prefix)
+    y, nrm, nrv = vn_linear_leaky_relu(x, sd[prefix + ".map_to_feat.weight"], sd[prefix + ".map_to_dir.weight"],
+                                       g, b, rm, rv, training)
+    if new_stats is not None and nrm is not None:
+        new_stats[prefix + ".batchnorm.bn.running_mean"] = nrm
+        new_stats[prefix + ".batchnorm.bn.running_var"] = nrv
+    return y
+
+
+def vn_pointnet_forward(sd, xyz, training=True, prefix="encoder", new_stats=None):
+    """models/pcn.py:165-184 (VN_PointNet.forward), num_coarse != 224 branch.
+
+    Returns (coarse [B,Mc,3], feature_global [B,C,3,1])."""
+    B, N, _ = xyz.shape
+    p = prefix
+    x = xyz.transpose(2, 1).unsqueeze(1)                          # [B,1,3,N]
+    f = _lin_leaky(sd, f"{p}.first_conv.0", x, training, new_stats)
+    f = vn_linear(f, sd[f"{p}.first_conv.1.map_to_feat.weight"])
+    g = vn_max_pool(f, sd[f"{p}.maxpool1.map_to_dir.weight"]).unsqueeze(-1)
+    f = torch.cat([g.expand(-1, -1, -1, N), f], dim=1)
+    f = _lin_leaky(sd, f"{p}.second_conv.0", f, training, new_stats)
+    f = vn_linear(f, sd[f"{p}.second_conv.1.map_to_feat.weight"])
+    g = vn_max_pool(f, sd[f"{p}.maxpool2.map_to_dir.weight"]).unsqueeze(-1)   # [B,C,3,1]
+    h = vn_linear_and_leaky_relu(g, sd[f"{p}.mlp.0.linear.map_to_feat.weight"],
+                                 sd[f"{p}.mlp.0.leaky_relu.map_to_dir.weight"])
+    h = vn_linear_and_leaky_relu(h, sd[f"{p}.mlp.1.linear.map_to_feat.weight"],
+                                 sd[f"{p}.mlp.1.leaky_relu.map_to_dir.weight"])
+    h = vn_linear(h, sd[f"{p}.mlp.2.map_to_feat.weight"])          # [B,Mc,3,1]
+    mc = h.shape[1]
+    coarse = h.reshape(-1, mc, 3)
+    return coarse.contiguous(), g
+
+
+def folding_seed(grid_size=4, lo=-0.05, hi=0.05):
+    """models/pcn.py:359-362: [1,1,3,grid^2], z = 0."""
+    lin = torch.linspace(lo, hi, steps=grid_size, dtype=torch.float)
+    a = lin.view(1, grid_size).expand(grid_size, grid_size).reshape(1, -1)
+    b = lin.view(grid_size, 1).expand(grid_size, grid_size).reshape(1, -1)
+    c = torch.zeros_like(a)
+    return torch.cat([a, b, c], dim=0).reshape(1, 1, 3, -1)
+
+
+def vn_foldingnet_forward(sd, coarse, feature_global, rot_R=None, training=True, grid_size=4,
+                          prefix="decoder", new_stats=None):
+    """models/pcn.py:365-389 (VN_FoldingNet.forward).  ``rot_R`` is a [B,3,3] rotation in the
+    pytorch3d row-vector convention (points @ R), or None."""
+    p = prefix
+    B, mc, _ = coarse.shape
+    S = grid_size * grid_size
+    md = mc * S
+    seed = folding_seed(grid_size).to(coarse)
+    if rot_R is not None:
+        s = seed.squeeze(1).transpose(1, 2)                      # [1,S,3]
+        s = torch.matmul(s.expand(B, -1, -1), rot_R)              # [B,S,3]
+        seed = s.transpose(1, 2).unsqueeze(1)                     # [B,1,3,S]
+    point_feat = coarse.unsqueeze(2).expand(-1, -1, S, -1).reshape(-1, md, 3).transpose(2, 1).unsqueeze(1)
+    seed = seed.unsqueeze(3).expand(B, -1, -1, mc, -1).reshape(B, -1, 3, md)
+    fg = feature_global.expand(-1, -1, -1, md)
+    feat = torch.cat([fg, seed, point_feat], dim=1)
+    f = _lin_leaky(sd, f"{p}.final_conv.0", feat, training, new_stats)
+    f = _lin_leaky(sd, f"{p}.final_conv.1", f, training, new_stats)
+    f = vn_linear(f, sd[f"{p}.final_conv.2.map_to_feat.weight"])
+    fine = f + point_feat
+    return fine.squeeze(1).transpose(1, 2).contiguous()
+
+
+def pcnnet_forward(sd, xyz, rot_R=None, training=True, new_stats=None):
+    """models/model.py:52-64 for enc_type='vn_pointnet', dec_type='vn_foldingnet'."""
+    coarse, g = vn_pointnet_forward(sd, xyz, training, new_stats=new_stats)
+    fine = vn_foldingnet_forward(sd, coarse, g, rot_R, training, new_stats=new_stats)
+    return coarse, fine, g
+
+
+# --------------------------------------------------------------------------- losses
+def chamfer_torch(a, b):
+    """Direct-form squared NN distances (same formula as chamfer3D.cu:33-36) in torch, per sample,
+    differentiable.  Returns dist1[B,n], dist2[B,m], idx1, idx2 (int32; first minimum wins)."""
+    d1, d2, i1, i2 = [], [], [], []
+    for x, y in zip(a, b):
+        diff = x[:, None, :] - y[None, :, :]
+        P = (diff * diff).sum(-1)
+        v1, j1 = P.min(1)
+        v2, j2 = P.min(0)
+        d1.append(v1), d2.append(v2), i1.append(j1.int()), i2.append(j2.int())
+    return torch.stack(d1), torch.stack(d2), torch.stack(i1), torch.stack(i2)
+
+
+def cd_loss_l1(dist1, dist2):
+    """metrics/loss.py:28-31."""
+    return (torch.sqrt(dist1).mean() + torch.sqrt(dist2).mean()) / 2.0
+
+
+def cd_loss_l2(dist1, dist2):
+    """metrics/loss.py:42-43."""
+    return dist1.mean() + dist2.mean()
+
+
+def l1_cd_metric(dist1, dist2):
+    """metrics/metric.py:19-23 (sum over the batch)."""
+    return (torch.sqrt(dist1).mean(1) + torch.sqrt(dist2).mean(1)).sum() / 2
+
+
+def l2_cd_metric(dist1, dist2):
+    """metrics/metric.py:12-16."""
+    return (dist1.mean(1) + dist2.mean(1)).sum()
+
+
+# ----------------------------------------------------------------- deterministic fill
+def closed_form_fill(state_dict):
+    """Fill a state_dict in place with a closed-form rule keyed by (position, flat index), so the
+    reference, the oracle and the HIP modules can be given identical weights without storing them.
+    Linear weights: amplitude sqrt(3/fan_in) (variance ~ 1.5/fan_in); BN gamma 1+0.1 sin, beta 0.1 sin."""
+    import math
+    for k, (name, t) in enumerate(state_dict.items()):
+        if not t.dtype.is_floating_point:
+            continue
+        i = torch.arange(t.numel(), dtype=torch.float64)
+        s = torch.sin(0.37 * i + 1.0 * k + 0.11 * (i % 7))
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            continue
+        if name.endswith("bn.weight") or name.endswith("norm.weight") or name.endswith("layer_norm.weight"):
+            v = 1.0 + 0.1 * s
+        elif name.endswith(".bias"):
+            v = 0.1 * s
+        elif t.dim() >= 2:
+            v = math.sqrt(3.0 / t.shape[1]) * s
+        else:
+            v = 0.5 * s
+        t.copy_(v.to(t.dtype).view_as(t))
+    return state_dict

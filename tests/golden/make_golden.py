@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference
+(/root/reference) on CPU in the build container, and cross-check the oracle against it.
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; never run on the GPU box)
+
+The reference cannot travel, so only inputs / outputs (data) are written here.  Third-party
+CUDA-only imports of the reference (pointnet2_ops, knn_cuda, timm) get empty stand-ins in
+sys.modules before the import, exactly as SURVEY.md §8c describes; nothing of the reference
+is executed through them on the vn_pointnet / vn_foldingnet path.
+"""
+import os
+import sys
+import types
+import importlib.util
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+
+def _standins():
+    m = types.ModuleType("pointnet2_ops")
+    m.pointnet2_utils = types.ModuleType("pointnet2_ops.pointnet2_utils")
+    sys.modules["pointnet2_ops"] = m
+    sys.modules["pointnet2_ops.pointnet2_utils"] = m.pointnet2_utils
+    k = types.ModuleType("knn_cuda")
+    k.KNN = lambda *a, **kw: None
+    sys.modules["knn_cuda"] = k
+    t, tm, tl = types.ModuleType("timm"), types.ModuleType("timm.models"), types.ModuleType("timm.models.layers")
+    tl.DropPath = torch.nn.Identity
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    sys.modules["timm"], sys.modules["timm.models"], sys.modules["timm.models.layers"] = t, tm, tl
+    torch.Tensor.cuda = lambda self, *a, **k: self          # folding_seed(...).cuda(), pcn.py:362
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Rot:
+    """Minimal pytorch3d.transforms.Rotate look-alike: row-vector convention p @ R."""
+    def __init__(self, R):
+        self.R = R
+
+    def transform_points(self, p):
+        return torch.matmul(p.expand(self.R.shape[0], -1, -1) if p.shape[0] == 1 else p, self.R)
+
+
+def random_rotations(n, gen):
+    q = torch.randn(n, 4, generator=gen)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).view(n, 3, 3)
+    return R
+
+
+def npz(name, **arrs):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()}
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays")
+
+
+def check(a, b, what, tol=2e-5):
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1e-6)
+    assert err <= tol * max(scale, 1.0), f"oracle != reference for {what}: {err} (scale {scale})"
+    return err
+
+
+def main():
+    _standins()
+    from oracle import vn_oracle as O
+    from oracle import chamfer_oracle as CO
+    vl = _load(os.path.join(REF, "models/vn_layers.py"), "ref_vn_layers")
+    chp = _load(os.path.join(REF, "extensions/ChamferDistancePytorch/chamfer_python.py"), "ref_chamfer_python")
+    from models.model import PCNNet
+    from models.pcn import VN_FoldingNet
+    from types import SimpleNamespace
+
+    gen = torch.Generator().manual_seed(20240917)
+    R = lambda *s: torch.randn(*s, generator=gen)
+
+    # ------------------------------------------------------------------ 1. layers
+    out = {}
+    B, Ci, Co, N, K = 2, 6, 8, 16, 4
+    for tag, shape in (("d4", (B, Ci, 3, N)), ("d5", (B, Ci, 3, N, K))):
+        dim = len(shape)
+        x = R(*shape)
+        # VNLinear
+        m = vl.VNLinear(Ci, Co)
+        O.closed_form_fill(m.state_dict())
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        g = R(*y.shape)
+        y.backward(g)
+        out.update({f"lin_{tag}_x": x, f"lin_{tag}_w": m.map_to_feat.weight, f"lin_{tag}_y": y, f"lin_{tag}_g": g,
+                    f"lin_{tag}_gx": xr.grad, f"lin_{tag}_gw": m.map_to_feat.weight.grad})
+        check(O.vn_linear(x, m.map_to_feat.weight.detach()), y, f"vn_linear {tag}")
+        # VNLeakyReLU
+        m = vl.VNLeakyReLU(Ci)
+        O.closed_form_fill(m.state_dict())
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        g = R(*y.shape)
+        y.backward(g)
+        out.update({f"leaky_{tag}_w": m.map_to_dir.weight, f"leaky_{tag}_y": y, f"leaky_{tag}_g": g,
+                    f"leaky_{tag}_gx": xr.grad, f"leaky_{tag}_gw": m.map_to_dir.weight.grad})
+        check(O.vn_leaky_relu(x, m.map_to_dir.weight.detach()), y, f"vn_leaky {tag}")
+        # VNBatchNorm train + eval
+        m = vl.VNBatchNorm(Ci, dim=dim)
+        O.closed_form_fill(m.state_dict())
+        m.train()
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        g = R(*y.shape)
+        y.backward(g)
+        out.update({f"bn_{tag}_gamma": m.bn.weight, f"bn_{tag}_beta": m.bn.bias, f"bn_{tag}_y": y, f"bn_{tag}_g": g,
+                    f"bn_{tag}_gx": xr.grad, f"bn_{tag}_ggamma": m.bn.weight.grad, f"bn_{tag}_gbeta": m.bn.bias.grad,
+                    f"bn_{tag}_rm": m.bn.running_mean.clone(), f"bn_{tag}_rv": m.bn.running_var.clone()})
+        yo, rm, rv = O.vn_batchnorm(x, m.bn.weight.detach(), m.bn.bias.detach(), torch.zeros(Ci), torch.ones(Ci), True)
+        check(yo, y, f"vn_bn train {tag}"), check(rm, m.bn.running_mean, "bn rm"), check(rv, m.bn.running_var, "bn rv")
+        m.eval()
+        ye = m(x)
+        out[f"bn_{tag}_y_eval"] = ye
+        check(O.vn_batchnorm(x, m.bn.weight.detach(), m.bn.bias.detach(), m.bn.running_mean, m.bn.running_var, False)[0],
+              ye, f"vn_bn eval {tag}")
+        # VNLinearLeakyReLU train (+ eval)
+        m = vl.VNLinearLeakyReLU(Ci, Co, dim=dim)
+        O.closed_form_fill(m.state_dict())
+        m.train()
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        g = R(*y.shape)
+        y.backward(g)
+        out.update({f"ll_{tag}_wf": m.map_to_feat.weight, f"ll_{tag}_wd": m.map_to_dir.weight,
+                    f"ll_{tag}_gamma": m.batchnorm.bn.weight, f"ll_{tag}_beta": m.batchnorm.bn.bias,
+                    f"ll_{tag}_y": y, f"ll_{tag}_g": g, f"ll_{tag}_gx": xr.grad,
+                    f"ll_{tag}_gwf": m.map_to_feat.weight.grad, f"ll_{tag}_gwd": m.map_to_dir.weight.grad,
+                    f"ll_{tag}_ggamma": m.batchnorm.bn.weight.grad, f"ll_{tag}_gbeta": m.batchnorm.bn.bias.grad,
+                    f"ll_{tag}_rm": m.batchnorm.bn.running_mean.clone(), f"ll_{tag}_rv": m.batchnorm.bn.running_var.clone()})
+        yo, _, _ = O.vn_linear_leaky_relu(x, m.map_to_feat.weight.detach(), m.map_to_dir.weight.detach(),
+                                          m.batchnorm.bn.weight.detach(), m.batchnorm.bn.bias.detach(),
+                                          torch.zeros(Co), torch.ones(Co), True)
+        check(yo, y, f"vn_linear_leaky {tag}")
+        m.eval()
+        ye = m(x)
+        out[f"ll_{tag}_y_eval"] = ye
+        # VNLinearAndLeakyReLU (no BN)
+        m = vl.VNLinearAndLeakyReLU(Ci, Co, dim=dim, use_batchnorm="none")
+        O.closed_form_fill(m.state_dict())
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        g = R(*y.shape)
+        y.backward(g)
+        out.update({f"lal_{tag}_wl": m.linear.map_to_feat.weight, f"lal_{tag}_wd": m.leaky_relu.map_to_dir.weight,
+                    f"lal_{tag}_y": y, f"lal_{tag}_g": g, f"lal_{tag}_gx": xr.grad,
+                    f"lal_{tag}_gwl": m.linear.map_to_feat.weight.grad, f"lal_{tag}_gwd": m.leaky_relu.map_to_dir.weight.grad})
+        check(O.vn_linear_and_leaky_relu(x, m.linear.map_to_feat.weight.detach(), m.leaky_relu.map_to_dir.weight.detach()),
+              y, f"vn_linear_and_leaky {tag}")
+        # VNMaxPool
+        m = vl.VNMaxPool(Ci)
+        O.closed_form_fill(m.state_dict())
+        xr = x.clone().requires_grad_(True)
+        y = m(xr)
+        g = R(*y.shape)
+        y.backward(g)
+        out.update({f"pool_{tag}_w": m.map_to_dir.weight, f"pool_{tag}_y": y, f"pool_{tag}_g": g, f"pool_{tag}_gx": xr.grad})
+        assert m.map_to_dir.weight.grad is None          # argmax detaches the direction weights
+        check(O.vn_max_pool(x, m.map_to_dir.weight.detach()), y, f"vn_max_pool {tag}")
+        if dim == 4:
+            m = vl.VNLayerNorm(Ci)
+            O.closed_form_fill(m.state_dict())
+            xr = x.clone().requires_grad_(True)
+            y = m(xr)
+            g = R(*y.shape)
+            y.backward(g)
+            out.update({"ln_gamma": m.layer_norm.weight, "ln_beta": m.layer_norm.bias, "ln_y": y, "ln_g": g,
+                        "ln_gx": xr.grad, "ln_ggamma": m.layer_norm.weight.grad, "ln_gbeta": m.layer_norm.bias.grad})
+            check(O.vn_layer_norm(x, m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), y, "vn_layer_norm")
+        out[f"x_{tag}"] = x
+    npz("layers.npz", **out)
+
+    # ------------------------------------------------------- 2. small VN_FoldingNet
+    cfg = SimpleNamespace(num_coarse=4, latent_dim=8, only_coarse=False, enc_pretrained="none", device="cpu")
+    dec = VN_FoldingNet(cfg)
+    dec.num_dense = 64
+    O.closed_form_fill(dec.state_dict())
+    dec.train()
+    coarse = 0.3 * R(2, 4, 3)
+    fg = R(2, 8, 3, 1)
+    Rm = random_rotations(2, gen)
+    out = {"coarse": coarse, "fg": fg, "R": Rm}
+    sd0 = {"decoder." + k: v.clone() for k, v in dec.state_dict().items()}     # closed-form: not stored
+    for tag, rot in (("norot", None), ("rot", Rot(Rm))):
+        dec.load_state_dict({k[len("decoder."):]: v for k, v in sd0.items()})
+        dec.zero_grad()
+        cr, fr = coarse.clone().requires_grad_(True), fg.clone().requires_grad_(True)
+        fine = dec(cr, fr, rot)
+        g = R(*fine.shape)
+        fine.backward(g)
+        out.update({f"{tag}_fine": fine, f"{tag}_g": g, f"{tag}_gcoarse": cr.grad, f"{tag}_gfg": fr.grad})
+        for k, p in dec.named_parameters():
+            if p.numel() <= 4096:
+                out[f"{tag}_grad.decoder.{k}"] = p.grad.clone()
+            else:
+                out[f"{tag}_gradnorm.decoder.{k}"] = p.grad.double().norm()
+                out[f"{tag}_gradhead.decoder.{k}"] = p.grad.flatten()[:256].clone()
+        for k, v in dec.state_dict().items():
+            if "running" in k:
+                out[f"{tag}_after.decoder.{k}"] = v.clone()
+        fo = O.vn_foldingnet_forward(sd0, coarse, fg, None if rot is None else Rm, True)
+        check(fo, fine, f"vn_foldingnet {tag}")
+    npz("foldingnet_small.npz", **out)
+
+    # ------------------------------------------------- 3. config 1 end-to-end (B=2)
+    # Train-mode BatchNorm over a batch of 2 plus the arg-max pools make this network chaotic for most
+    # weight draws: the reference's own fp32 and fp64 runs then disagree by O(0.1) in `fine`.  Parity can
+    # only be pinned where the reference itself is reproducible, so scan seeds of torch's DEFAULT init
+    # (the reference's init; our modules draw the same stream) for a well-conditioned instance, and store
+    # the fp64 run as the yardstick.  Weights are not stored: seed + per-tensor checksums pin them.
+    cfg = SimpleNamespace(num_coarse=64, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cpu")
+
+    def cd64(x, y):
+        P = ((x[:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)
+        return (P.min(2)[0].sqrt().mean() + P.min(1)[0].sqrt().mean()) / 2
+
+    def build(seed, dtype=torch.float32, sd=None):
+        torch.manual_seed(seed)
+        n_ = PCNNet(cfg, "vn_pointnet", "vn_foldingnet")
+        n_.decoder.num_dense = 64 * 16                    # 16384 is hard-coded at pcn.py:332
+        if sd is not None:
+            n_ = n_.to(dtype)
+            n_.decoder.folding_seed = n_.decoder.folding_seed.to(dtype)
+            n_.load_state_dict({k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()})
+        n_.train()
+        return n_
+
+    p = torch.rand(2, 256, 3, generator=gen) - 0.5
+    c = torch.rand(2, 1024, 3, generator=gen) - 0.5
+    chosen = None
+    for seed in range(32):
+        net = build(seed)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        coarse, fine = net(p)
+        net64 = build(seed, torch.float64, sd0)
+        c64, f64 = net64(p.double())
+        dfine = (fine.double() - f64).abs().max().item()
+        print(f"cfg1 seed {seed}: reference fp32 vs fp64 max |fine| diff {dfine:.2e}")
+        if dfine < 1e-4:
+            chosen = seed
+            break
+    assert chosen is not None
+    d1c, d2c, i1c, i2c = chp.distChamfer(coarse, c)
+    d1f, d2f, i1f, i2f = chp.distChamfer(fine, c)
+    loss1 = (torch.sqrt(d1c).mean() + torch.sqrt(d2c).mean()) / 2          # metrics/loss.py:28-31
+    loss2 = (torch.sqrt(d1f).mean() + torch.sqrt(d2f).mean()) / 2
+    (loss1 + loss2).backward()
+    l1_64, l2_64 = cd64(c64, c.double()), cd64(f64, c.double())
+    (l1_64 + l2_64).backward()
+    out = {"seed": chosen, "p": p, "c": c, "coarse": coarse, "fine": fine, "loss1": loss1, "loss2": loss2,
+           "coarse64": c64, "fine64": f64, "loss1_64": l1_64, "loss2_64": l2_64,
+           "d1c": d1c, "d2c": d2c, "i1c": i1c, "i2c": i2c, "d1f": d1f, "d2f": d2f, "i1f": i1f, "i2f": i2f}
+    names, norms, norms64, heads, heads64, wsum, wabs = [], [], [], [], [], [], []
+    for (k, prm), (_, prm64) in zip(net.named_parameters(), net64.named_parameters()):
+        names.append(k)
+        wsum.append(sd0[k].double().sum().item())
+        wabs.append(sd0[k].double().abs().sum().item())
+        if prm.grad is None:
+            norms.append(-1.0), norms64.append(-1.0)
+            heads.append(np.zeros(16, np.float32)), heads64.append(np.zeros(16))
+        else:
+            norms.append(prm.grad.double().norm().item()), norms64.append(prm64.grad.norm().item())
+            hh = torch.zeros(16); hh[:min(16, prm.numel())] = prm.grad.flatten()[:16]
+            h64 = torch.zeros(16, dtype=torch.float64); h64[:min(16, prm.numel())] = prm64.grad.flatten()[:16]
+            heads.append(hh.numpy()), heads64.append(h64.numpy())
+    out.update({"grad_names": np.array(names), "grad_norms": np.array(norms), "grad_norms64": np.array(norms64),
+                "grad_heads": np.stack(heads), "grad_heads64": np.stack(heads64),
+                "weight_sum": np.array(wsum), "weight_abssum": np.array(wabs)})
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            out["after." + k] = v.clone()
+    print("cfg1: loss1 32/64", loss1.item(), l1_64.item(), "loss2 32/64", loss2.item(), l2_64.item())
+    # oracle cross-check (teacher-forced at the arg-max pools, see SURVEY.md §7 'Hard parts')
+    net.load_state_dict(sd0)
+    with torch.no_grad():
+        c_ref, g_ref = net.encoder(p)
+    out["feature_global"] = g_ref
+    net.load_state_dict(sd0)
+    co, go = O.vn_pointnet_forward(sd0, p, True)
+    flipped = ((go - g_ref).abs().amax(dim=(2, 3)) > 1e-4).sum().item()
+    print(f"cfg1: oracle vs reference feature_global: {flipped} of {go.shape[0] * go.shape[1]} channels picked another point")
+    assert flipped <= 0.005 * go.shape[0] * go.shape[1]
+    h = O.vn_linear_and_leaky_relu(g_ref, sd0["encoder.mlp.0.linear.map_to_feat.weight"], sd0["encoder.mlp.0.leaky_relu.map_to_dir.weight"])
+    h = O.vn_linear_and_leaky_relu(h, sd0["encoder.mlp.1.linear.map_to_feat.weight"], sd0["encoder.mlp.1.leaky_relu.map_to_dir.weight"])
+    h = O.vn_linear(h, sd0["encoder.mlp.2.map_to_feat.weight"]).reshape(-1, 64, 3)
+    check(h, coarse, "cfg1 coarse (teacher-forced mlp)", 2e-5)
+    fo = O.vn_foldingnet_forward(sd0, coarse.detach(), g_ref, None, True)
+    check(fo, fine, "cfg1 fine (teacher-forced)", 2e-4)
+    # eval-mode forward with the updated running stats
+    net.load_state_dict(sd0)
+    net.train()
+    with torch.no_grad():
+        net(p)
+    net.eval()
+    with torch.no_grad():
+        ce, fe = net(p)
+    out["coarse_eval"], out["fine_eval"] = ce, fe
+    # rotated input + rot passed to the decoder (equivariance fixture)
+    Rm = random_rotations(2, gen)
+    net.load_state_dict(sd0)
+    net.train()
+    with torch.no_grad():
+        cr_, fr_ = net(torch.matmul(p, Rm), Rot(Rm))
+    out["R"], out["coarse_rot"], out["fine_rot"] = Rm, cr_, fr_
+    print("cfg1: equivariance of the reference itself: max |fine_rot - fine@R|",
+          (fr_ - torch.matmul(fine.detach(), Rm)).abs().max().item())
+    npz("cfg1_e2e.npz", **out)
+
+    # -------------------------------------------------------------- 4. chamfer goldens
+    a = torch.rand(4, 100, 3, generator=gen)               # unit_test.py:16-17 shapes
+    b = torch.rand(4, 200, 3, generator=gen)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    d1, d2, i1, i2 = chp.distChamfer(ar, br)
+    g1, g2 = R(*d1.shape), R(*d2.shape)
+    ((d1 * g1).sum() + (d2 * g2).sum()).backward()
+    out = {"a": a, "b": b, "d1": d1, "d2": d2, "i1": i1, "i2": i2, "g1": g1, "g2": g2, "ga": ar.grad, "gb": br.grad}
+    od1, od2, oi1, oi2 = CO.chamfer_forward(a.numpy(), b.numpy())
+    assert np.abs(od1 - d1.detach().numpy()).max() < 1e-6 and (oi1 == i1.numpy()).all() and (oi2 == i2.numpy()).all()
+    oga, ogb = CO.chamfer_backward(a.numpy(), b.numpy(), g1.numpy(), g2.numpy(), oi1, oi2)
+    assert np.abs(oga - ar.grad.numpy()).max() < 1e-5 and np.abs(ogb - br.grad.numpy()).max() < 1e-5
+    a2 = torch.rand(1, 1024, 3, generator=gen) - 0.5
+    b2 = torch.rand(1, 16384, 3, generator=gen) - 0.5
+    e1, e2, j1, j2 = chp.distChamfer(a2, b2)
+    out.update({"a2": a2, "b2": b2, "e1": e1, "e2": e2, "j1": j1, "j2": j2})
+    od1, od2, oi1, oi2 = CO.chamfer_forward(a2.numpy(), b2.numpy())
+    print("chamfer 1024x16384: max |d| diff", np.abs(od1 - e1.numpy()).max(), np.abs(od2 - e2.numpy()).max(),
+          "idx mismatches", int((oi1 != j1.numpy()).sum()), int((oi2 != j2.numpy()).sum()))
+    npz("chamfer.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    main()
