@@ -1,0 +1,126 @@
+/* libvnpcc — C-ABI of the MI355X (gfx950) kernels behind the VN-PCN hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's Python would bind in place of its two pybind11
+ * CUDA extensions and of the eager ATen chains inside models/vn_layers.py.  All functions
+ *   - take raw DEVICE pointers, explicit sizes / leading dimensions and the caller's hipStream_t,
+ *   - allocate nothing (scratch is passed in), are re-entrant, launch on the given stream without synchronising,
+ *   - return 0 on success, VNP_EINVAL (-1) for bad arguments, or the positive hipError_t of a failed launch
+ *     (stricter than the reference, which printf()s and swallows launch errors: chamfer3D.cu:145-151).
+ *
+ * "rows layout": a VN feature map with P points and C channels is a row-major fp32 matrix [P*3, ld] with
+ * row = point*3 + t (t = x,y,z) and channels contiguous.  The reference's [B, C, 3, N] tensor
+ * (models/vn_layers.py:19) maps to rows[(b*N+n)*3+t][c].  vnp_ref_to_rows / vnp_rows_to_ref convert.
+ */
+#ifndef VNPCC_H
+#define VNPCC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define VNP_OK 0
+#define VNP_EINVAL (-1)
+
+/* ---- Chamfer distance ------------------------------------------------------------------------------------
+ * replaces chamfer_3D.forward / chamfer_3D.backward
+ *   (/root/reference/extensions/chamfer_distance/chamfer_cuda.cpp:17-33, chamfer3D.cu:136-195).
+ * xyz1 [B,n,3], xyz2 [B,m,3] contiguous fp32; dist1 [B,n], dist2 [B,m] fp32; idx1, idx2 int32.
+ * ws: scratch of 8*B*max(n,m) bytes.  Outputs need not be pre-zeroed (the reference requires zeroed outputs). */
+int vnp_chamfer_fwd(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
+                    float* dist1, int* idx1, float* dist2, int* idx2, void* ws);
+int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
+                    const float* grad_dist1, const int* idx1, const float* grad_dist2, const int* idx2,
+                    float* grad_xyz1, float* grad_xyz2);
+
+/* ---- fp32 MFMA GEMM -----------------------------------------------------------------------------------------
+ * replaces the x.transpose(1,-1) -> nn.Linear -> transpose chains of models/vn_layers.py:21,36,65,69,162 and their
+ * autograd.  C[M,N] (+)= op(A) op(B) (+ A2 B2) (+ bias).
+ *   op_a = 0: A is [M,K] row-major; 1: A is [K,M] row-major.   op_b = 0: B is [N,K] row-major; 1: B is [K,N].
+ *   (A2,B2,K2): optional second product with the same op flags accumulated in the same tile (K2 = 0: none).
+ *   bias: optional [groups*3, ldbias]; row r gets bias[(r / rows_per_group)*3 + r%3] (per-sample VN bias).
+ *   accumulate != 0: C += result.   nsplit > 1: split-K through ws (nsplit*M*N floats), bias not allowed. */
+int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
+             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+             const float* A2, int lda2, const float* B2, int ldb2, int K2,
+             const float* bias, int ldbias, int rows_per_group,
+             int accumulate, int nsplit, float* ws);
+
+/* ---- VN BatchNorm / leaky projection ------------------------------------------------------------------------
+ * VNBatchNorm (models/vn_layers.py:107-127), VNLeakyReLU (:25-43), VNLinearLeakyReLU tail (:66-73).
+ * Chunked reductions use chunks of vnp_chunk_points() points: nchunk = ceil(P / vnp_chunk_points()). */
+int vnp_chunk_points(void);
+/* partial [nchunk][C][2] = per-chunk (mean, M2 = sum (n - mean)^2) of n = |p| + 1e-6 (Welford; merged by Chan) */
+int vnp_vn_norm_stats(hipStream_t st, const float* p, int ldp, long long P, int C, float* partial);
+/* mean/rstd [C] from the partials; running stats (nullable) updated like torch BatchNorm (momentum, unbiased var) */
+int vnp_vn_bn_finalize(hipStream_t st, const float* partial, int nchunk, int C, long long count,
+                       float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps);
+int vnp_rstd_from_var(hipStream_t st, const float* var, float* rstd, int C, float eps);
+/* out = leaky(bn(p), d); d NULL: BatchNorm only; mean NULL: no BatchNorm */
+int vnp_vn_bn_leaky_fwd(hipStream_t st, const float* p, int ldp, const float* d, int ldd, float* out, int ldo,
+                        long long P, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        float negative_slope);
+/* backward phase 1: gq = dL/dbn(p), gd = dL/dd, partial [nchunk][C][2] = (sum g_nhat, sum g_nhat*xhat).
+ * go NULL: rank-1 upstream gradient go[r][c] = go_row[r]*go_col[c]. */
+int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, const float* go_row, const float* go_col,
+                         const float* p, int ldp, const float* d, int ldd,
+                         float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         float negative_slope, float* partial);
+/* backward phase 2: g (dL/dbn(p)) -> dL/dp in place; S [C][2] reduced partial sums (NULL: eval-mode BatchNorm) */
+int vnp_vn_bn_bwd2(hipStream_t st, float* g, int ldg, const float* p, int ldp, long long P, int C,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta,
+                   const float* S, long long count);
+/* out[b][j] = sum_{i<n} in[b*batch_stride + i*stride + j], j < W (double accumulation) */
+int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long long batch_stride, int n, long long stride, int W,
+                    float* out, long long out_stride);
+
+/* ---- pooling ----------------------------------------------------------------------------------------------
+ * VNMaxPool (models/vn_layers.py:153-167) over groups of gs consecutive points; idx [G][C] = local arg-max (first max).
+ * ws_val / ws_idx: G*ceil(gs/vnp_chunk_points())*C elements. */
+int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int ldd, long long G, int gs, int C,
+                    int* idx, float* out, int ldo, float* ws_val, int* ws_idx);
+int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
+                    float* gx, int ldgx);
+/* mean_pool (models/vn_layers.py:170-171) over groups of gs consecutive points */
+int vnp_vn_mean_pool_fwd(hipStream_t st, const float* x, int ldx, long long G, int gs, int C, float* out, int ldo);
+int vnp_vn_mean_pool_bwd(hipStream_t st, const float* gout, int ldgo, long long G, int gs, int C, float* gx, int ldgx);
+
+/* ---- FoldingNet expansion (models/pcn.py:375-387, broadcast input de-duplicated) ---------------------------
+ * out[((b*Mc+mc)*S+s)*3+t][j] = bias[b*3+t][j] + wseed[j]*seed[(b)][s][t] + wcoarse[j]*coarse[b][mc][t], j < W */
+int vnp_fold_fwd(hipStream_t st, const float* bias, int ldb, const float* wseed, const float* wcoarse,
+                 const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int W,
+                 float* out, int ldo);
+/* part [B*Mc][5][W]: rows 0-2 sum_s g (per t), row 3 sum g*seed, row 4 sum g*coarse */
+int vnp_fold_bwd(hipStream_t st, const float* g, int ldg, const float* seed, int seed_batched, const float* coarse,
+                 int B, int Mc, int S, int W, float* part);
+
+/* ---- small reductions -------------------------------------------------------------------------------------- */
+/* out[r] = sum_c X[r][c]*w[c] (+ add[((r/3)/add_group)*3 + r%3]) : final VNLinear(C->1) + point_feat (pcn.py:387) */
+int vnp_rowdot(hipStream_t st, const float* X, int ldx, const float* w, long long R, int C,
+               const float* add, int add_group, float* out);
+/* out[pc*3+t] (+)= sum_{s<S} in[(pc*S+s)*3+t] */
+int vnp_group_sum3(hipStream_t st, const float* in, long long Pc, int S, float* out, int accumulate);
+/* partial [nb][ceil(R/chunk)][C] = chunked column sums of X (optionally weighted per row by w[b*R + r]) */
+int vnp_colsum(hipStream_t st, const float* X, long long batch_stride, long long row_stride, int nb, long long R, int C,
+               const float* w, float* partial);
+
+/* out[r][c] = u[r]*w[c] */
+int vnp_outer(hipStream_t st, const float* u, const float* w, long long R, int C, float* out, int ldo);
+
+/* ---- layout conversion at the module boundary ---------------------------------------------------------------- */
+int vnp_rows_to_ref(hipStream_t st, const float* rows, int ld, int B, int C, int N, float* ref);
+int vnp_ref_to_rows(hipStream_t st, const float* ref, int B, int C, int N, float* rows, int ld);
+
+/* ---- optimizer: fused Adam over flat buffers (train.py:70, torch.optim.Adam semantics) ----------------------- */
+int vnp_adam_step(hipStream_t st, float* p, const float* g, float* m, float* v, long long n,
+                  float lr, float beta1, float beta2, float eps, int step, float weight_decay);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNPCC_H */

@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def lib_built():
+    """Build (or reuse) libvnpcc.so once per session."""
+    from vn_pointcloudcompletion_amd import _lib
+    _lib.build()
+    return _lib.lib()
+
+
+def t(a, device="cuda"):
+    return torch.as_tensor(np.asarray(a)).to(device)
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(a).double()
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(b).double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()

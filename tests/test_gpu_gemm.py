@@ -1,0 +1,78 @@
+"""fp32-MFMA GEMM (vnp_gemm) against a float64 torch reference.  Tolerance: an fp32 fmaf chain of length K has
+error <= ~K * 6e-8 * sum|a||b|; we assert 2e-5 relative to max|C| for K <= 4096."""
+import pytest
+import torch
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _lib(lib_built):
+    pass
+
+
+def _mk(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(192, 128, 32), (96, 64, 8), (1000, 300, 130), (7, 5, 3), (3, 128, 1), (600, 257, 1024),
+                                   (96, 2048, 2048)])
+def test_nt(M, N, K):
+    from vn_pointcloudcompletion_amd import ops
+    A, B = _mk(M, K, seed=1), _mk(N, K, seed=2)
+    C = ops.gemm(A, B)
+    ref = A.double() @ B.double().t()
+    assert relerr(C, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(500, 130, 70), (192, 128, 64), (5, 3, 2), (2000, 512, 256)])
+def test_nn_and_tn(M, N, K):
+    from vn_pointcloudcompletion_amd import ops
+    A, B = _mk(M, K, seed=3), _mk(K, N, seed=4)
+    C = ops.gemm(A, B, op_b=1)
+    assert relerr(C, A.double() @ B.double()) < 2e-5
+    At = _mk(K, M, seed=5)
+    C2 = ops.gemm(At, B, op_a=1, op_b=1)
+    assert relerr(C2, At.double().t() @ B.double()) < 2e-5
+    C3 = ops.gemm(At, B, op_a=1, op_b=1, nsplit=1)
+    assert relerr(C3, At.double().t() @ B.double()) < 2e-5
+
+
+def test_splitk_large_k():
+    from vn_pointcloudcompletion_amd import ops
+    A, B = _mk(50000, 96, seed=6), _mk(50000, 40, seed=7)
+    C = ops.gemm(A, B, op_a=1, op_b=1)
+    assert relerr(C, A.double().t() @ B.double()) < 2e-5
+
+
+def test_dual_bias_strided_accumulate():
+    from vn_pointcloudcompletion_amd import ops
+    M, N, K1, K2 = 2 * 10 * 3, 70, 40, 24          # 2 samples x 10 points
+    A1, A2 = _mk(M, K1, seed=8), _mk(M, K2, seed=9)
+    W1, W2 = _mk(K1, N, seed=10), _mk(K2, N, seed=11)
+    C = ops.gemm(A1, W1, op_b=1, A2=A2, B2=W2)
+    ref = A1.double() @ W1.double() + A2.double() @ W2.double()
+    assert relerr(C, ref) < 2e-5
+    # per-sample VN bias and a strided (column-slice) weight / output
+    Wfull = _mk(N, K1 + 16, seed=12)
+    bias = _mk(2 * 3, N, seed=13)
+    out = torch.zeros(M, 2 * N, device="cuda")
+    ops.gemm(A1, Wfull[:, 16:], out=out[:, N:], bias=bias, rows_per_group=30)
+    r = torch.arange(M, device="cuda")
+    ref = A1.double() @ Wfull[:, 16:].double().t() + bias.double()[(r // 30) * 3 + r % 3]
+    assert relerr(out[:, N:], ref) < 2e-5
+    assert out[:, :N].abs().max().item() == 0.0
+    prev = out[:, N:].clone()
+    ops.gemm(A1, Wfull[:, 16:], out=out[:, N:], accumulate=True, nsplit=1)
+    assert relerr(out[:, N:], prev.double() + A1.double() @ Wfull[:, 16:].double().t()) < 2e-5
+
+
+def test_bad_arguments_raise():
+    from vn_pointcloudcompletion_amd import ops, _lib
+    with pytest.raises(_lib.VnpError):
+        ops.gemm(_mk(4, 5), _mk(4, 6))
+    with pytest.raises(_lib.VnpError):
+        ops.gemm(torch.zeros(4, 5), torch.zeros(4, 5))          # CPU tensors: no fallback

@@ -1,0 +1,143 @@
+"""VN layer modules on the HIP path vs the golden fixtures generated from the reference
+(tests/golden/layers.npz, make_golden.py section 1).  Inputs / weights / cotangents are the reference's;
+tolerance 2e-5 relative to the tensor's max (fp32, K <= 8; the reference-vs-oracle gap is of the same order)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr, t
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-5
+
+
+@pytest.fixture(scope="module")
+def G(lib_built):
+    return load_golden("layers.npz")
+
+
+def _run(mod, x, g):
+    mod = mod.cuda()
+    mod.train()
+    xr = t(x).requires_grad_(True)
+    y = mod(xr)
+    y.backward(t(g))
+    return y, xr.grad
+
+
+@pytest.mark.parametrize("tag", ["d4", "d5"])
+def test_vnlinear(G, tag):
+    from vn_pointcloudcompletion_amd.vn_layers import VNLinear
+    w = G[f"lin_{tag}_w"]
+    m = VNLinear(w.shape[1], w.shape[0])
+    m.map_to_feat.weight.data.copy_(torch.as_tensor(w))
+    y, gx = _run(m, G[f"lin_{tag}_x"], G[f"lin_{tag}_g"])
+    assert relerr(y, G[f"lin_{tag}_y"]) < TOL
+    assert relerr(gx, G[f"lin_{tag}_gx"]) < TOL
+    assert relerr(m.map_to_feat.weight.grad, G[f"lin_{tag}_gw"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["d4", "d5"])
+def test_vnleakyrelu(G, tag):
+    from vn_pointcloudcompletion_amd.vn_layers import VNLeakyReLU
+    w = G[f"leaky_{tag}_w"]
+    m = VNLeakyReLU(w.shape[1])
+    m.map_to_dir.weight.data.copy_(torch.as_tensor(w))
+    y, gx = _run(m, G[f"x_{tag}"], G[f"leaky_{tag}_g"])
+    assert relerr(y, G[f"leaky_{tag}_y"]) < TOL
+    assert relerr(gx, G[f"leaky_{tag}_gx"]) < TOL
+    assert relerr(m.map_to_dir.weight.grad, G[f"leaky_{tag}_gw"]) < TOL
+
+
+@pytest.mark.parametrize("tag,dim", [("d4", 4), ("d5", 5)])
+def test_vnbatchnorm(G, tag, dim):
+    from vn_pointcloudcompletion_amd.vn_layers import VNBatchNorm
+    C = G[f"bn_{tag}_gamma"].shape[0]
+    m = VNBatchNorm(C, dim=dim)
+    m.bn.weight.data.copy_(torch.as_tensor(G[f"bn_{tag}_gamma"]))
+    m.bn.bias.data.copy_(torch.as_tensor(G[f"bn_{tag}_beta"]))
+    y, gx = _run(m, G[f"x_{tag}"], G[f"bn_{tag}_g"])
+    assert relerr(y, G[f"bn_{tag}_y"]) < TOL
+    assert relerr(gx, G[f"bn_{tag}_gx"]) < 1e-4
+    assert relerr(m.bn.weight.grad, G[f"bn_{tag}_ggamma"]) < TOL
+    assert relerr(m.bn.bias.grad, G[f"bn_{tag}_gbeta"]) < TOL
+    assert relerr(m.bn.running_mean, G[f"bn_{tag}_rm"]) < TOL
+    assert relerr(m.bn.running_var, G[f"bn_{tag}_rv"]) < TOL
+    assert int(m.bn.num_batches_tracked) == 1
+    m.eval()
+    with torch.no_grad():
+        ye = m(t(G[f"x_{tag}"]))
+    assert relerr(ye, G[f"bn_{tag}_y_eval"]) < TOL
+
+
+@pytest.mark.parametrize("tag,dim", [("d4", 4), ("d5", 5)])
+def test_vnlinearleakyrelu(G, tag, dim):
+    from vn_pointcloudcompletion_amd.vn_layers import VNLinearLeakyReLU
+    wf = G[f"ll_{tag}_wf"]
+    m = VNLinearLeakyReLU(wf.shape[1], wf.shape[0], dim=dim)
+    m.map_to_feat.weight.data.copy_(torch.as_tensor(wf))
+    m.map_to_dir.weight.data.copy_(torch.as_tensor(G[f"ll_{tag}_wd"]))
+    m.batchnorm.bn.weight.data.copy_(torch.as_tensor(G[f"ll_{tag}_gamma"]))
+    m.batchnorm.bn.bias.data.copy_(torch.as_tensor(G[f"ll_{tag}_beta"]))
+    y, gx = _run(m, G[f"x_{tag}"], G[f"ll_{tag}_g"])
+    assert relerr(y, G[f"ll_{tag}_y"]) < TOL
+    assert relerr(gx, G[f"ll_{tag}_gx"]) < 1e-4
+    assert relerr(m.map_to_feat.weight.grad, G[f"ll_{tag}_gwf"]) < 1e-4
+    assert relerr(m.map_to_dir.weight.grad, G[f"ll_{tag}_gwd"]) < 1e-4
+    assert relerr(m.batchnorm.bn.weight.grad, G[f"ll_{tag}_ggamma"]) < 1e-4
+    assert relerr(m.batchnorm.bn.bias.grad, G[f"ll_{tag}_gbeta"]) < 1e-4
+    assert relerr(m.batchnorm.bn.running_mean, G[f"ll_{tag}_rm"]) < TOL
+    assert relerr(m.batchnorm.bn.running_var, G[f"ll_{tag}_rv"]) < TOL
+    m.eval()
+    with torch.no_grad():
+        ye = m(t(G[f"x_{tag}"]))
+    assert relerr(ye, G[f"ll_{tag}_y_eval"]) < TOL
+
+
+@pytest.mark.parametrize("tag,dim", [("d4", 4), ("d5", 5)])
+def test_vnlinearandleakyrelu(G, tag, dim):
+    from vn_pointcloudcompletion_amd.vn_layers import VNLinearAndLeakyReLU
+    wl = G[f"lal_{tag}_wl"]
+    m = VNLinearAndLeakyReLU(wl.shape[1], wl.shape[0], dim=dim, use_batchnorm="none")
+    m.linear.map_to_feat.weight.data.copy_(torch.as_tensor(wl))
+    m.leaky_relu.map_to_dir.weight.data.copy_(torch.as_tensor(G[f"lal_{tag}_wd"]))
+    y, gx = _run(m, G[f"x_{tag}"], G[f"lal_{tag}_g"])
+    assert relerr(y, G[f"lal_{tag}_y"]) < TOL
+    assert relerr(gx, G[f"lal_{tag}_gx"]) < TOL
+    assert relerr(m.linear.map_to_feat.weight.grad, G[f"lal_{tag}_gwl"]) < TOL
+    assert relerr(m.leaky_relu.map_to_dir.weight.grad, G[f"lal_{tag}_gwd"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["d4", "d5"])
+def test_vnmaxpool(G, tag):
+    from vn_pointcloudcompletion_amd.vn_layers import VNMaxPool
+    w = G[f"pool_{tag}_w"]
+    m = VNMaxPool(w.shape[0])
+    m.map_to_dir.weight.data.copy_(torch.as_tensor(w))
+    y, gx = _run(m, G[f"x_{tag}"], G[f"pool_{tag}_g"])
+    assert tuple(y.shape) == G[f"pool_{tag}_y"].shape
+    assert relerr(y, G[f"pool_{tag}_y"]) < TOL             # margins at this size are >> fp32 noise: same arg-max
+    assert relerr(gx, G[f"pool_{tag}_gx"]) < TOL
+    assert m.map_to_dir.weight.grad is None                 # arg-max detaches the direction weights
+
+
+def test_layout_round_trip(lib_built):
+    from vn_pointcloudcompletion_amd.vn_layers import from_rows, to_rows
+    x = torch.randn(3, 5, 3, 7, 2, device="cuda")
+    rows, meta = to_rows(x)
+    assert rows.shape == (3 * 7 * 2 * 3, 5)
+    # rows[(b*N+n)*3+t][c] == x[b][c][t][n]
+    xf = x.reshape(3, 5, 3, 14)
+    assert torch.equal(rows.reshape(3, 14, 3, 5), xf.permute(0, 3, 2, 1))
+    assert torch.equal(from_rows(rows, meta), x)
+
+
+def test_mean_pool(lib_built):
+    from vn_pointcloudcompletion_amd.vn_layers import mean_pool
+    x = torch.randn(2, 6, 3, 9, 4, device="cuda", requires_grad=True)
+    y = mean_pool(x)
+    ref = x.detach().mean(-1)
+    assert relerr(y, ref) < 1e-6
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert relerr(x.grad, (g / 4).unsqueeze(-1).expand_as(x)) < 1e-6

@@ -1,0 +1,135 @@
+"""Loader for libvnpcc.so (the C-ABI of include/vnpcc.h) and thin ctypes helpers.
+
+The library is built in-tree by ``build()`` (``hipcc --offload-arch=gfx950``) and loaded with ctypes.
+There is NO fallback: if the library is missing or a kernel launch fails the product raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import glob
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libvnpcc.so")
+_LIB = None
+
+
+class VnpError(RuntimeError):
+    """A libvnpcc entry point returned non-zero (bad argument or HIP launch error)."""
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into csrc/libvnpcc.so (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for s in srcs:
+        o = os.path.join(CSRC, "build", os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if (not force and os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(s)
+                and all(os.path.getmtime(o) >= os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{out.decode()}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+
+# name -> argtypes (after the leading hipStream_t); mirrors include/vnpcc.h
+_SIGNATURES = {
+    "vnp_chamfer_fwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vnp_chamfer_bwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vnp_gemm": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "vnp_vn_norm_stats": [_vp, _i, _ll, _i, _vp],
+    "vnp_vn_bn_finalize": [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _f, _f],
+    "vnp_rstd_from_var": [_vp, _vp, _i, _f],
+    "vnp_vn_bn_leaky_fwd": [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f],
+    "vnp_vn_bn_leaky_bwd1": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp],
+    "vnp_vn_bn_bwd2": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll],
+    "vnp_reduce_rows": [_vp, _i, _ll, _i, _ll, _i, _vp, _ll],
+    "vnp_vn_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "vnp_vn_pool_bwd": [_vp, _i, _vp, _ll, _i, _i, _vp, _i],
+    "vnp_vn_mean_pool_fwd": [_vp, _i, _ll, _i, _i, _vp, _i],
+    "vnp_vn_mean_pool_bwd": [_vp, _i, _ll, _i, _i, _vp, _i],
+    "vnp_fold_fwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i],
+    "vnp_fold_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "vnp_rowdot": [_vp, _i, _vp, _ll, _i, _vp, _i, _vp],
+    "vnp_group_sum3": [_vp, _ll, _i, _vp, _i],
+    "vnp_colsum": [_vp, _ll, _ll, _i, _ll, _i, _vp, _vp],
+    "vnp_outer": [_vp, _vp, _ll, _i, _vp, _i],
+    "vnp_rows_to_ref": [_vp, _i, _i, _i, _i, _vp],
+    "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
+    "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
+}
+_NO_STREAM = {"vnp_chunk_points": []}
+
+
+def exported_symbols():
+    """Every symbol include/vnpcc.h declares (used by the CPU-side ABI test)."""
+    return sorted(list(_SIGNATURES) + list(_NO_STREAM))
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise VnpError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU / PyTorch fallback for the HIP kernels)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = [_vp] + args
+            fn.restype = _i
+        for name, args in _NO_STREAM.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = _i
+        _LIB = L
+    return _LIB
+
+
+def chunk_points() -> int:
+    return lib().vnp_chunk_points()
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name, *args):
+    """Invoke a stream-taking entry point on torch's current HIP stream; raise on a non-zero status."""
+    st = torch.cuda.current_stream().cuda_stream
+    rc = getattr(lib(), name)(st, *args)
+    if rc != 0:
+        raise VnpError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise VnpError("libvnpcc kernels need tensors on a HIP device (no CPU fallback); got a CPU tensor")

@@ -1,0 +1,705 @@
+// Vector-Neuron pointwise / reduction kernels on the rows layout (vnp_common.h):
+//   norm statistics + BatchNorm-over-norms + leaky projection (models/vn_layers.py:25-43, 46-74, 107-127),
+//   arg-max pooling (models/vn_layers.py:153-167), the FoldingNet rank-2 expansion (models/pcn.py:375-385)
+//   and the small column / row reductions their backward passes need.
+// All of them are HBM-bound: one thread owns one (point, channel) pair, a wave reads 64 consecutive
+// channels of a row (256 contiguous bytes) for each of the 3 Cartesian components.
+#include "vnp_common.h"
+
+#define VNP_CHUNK 256          // points per block in the chunked reductions (also exported via vnp_chunk_points)
+
+extern "C" int vnp_chunk_points() { return VNP_CHUNK; }
+
+// ------------------------------------------------------------------------------------------------
+// block = 256 threads = 64 channels x 4 point lanes; grid = (ceil(C/64), nchunk)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float vnp_sq3(float a, float b, float c) { return a * a + b * b + c * c; }
+
+// partial[chunk][c] = (mean, M2) of n = |p| + EPS over the chunk's points (vn_layers.py:121).
+// Welford per thread + Chan's pairwise merge: the batch variance of the norms can be 1e4-1e5 times smaller than
+// mean^2 (FoldingNet layer 0: every point of a sample shares the dominant global term), where sum / sum-of-squares
+// in fp32 loses the variance to cancellation.
+__device__ __forceinline__ void vnp_chan_merge(double& na, double& ma, double& Ma, double nb, double mb, double Mb)
+{
+    if (nb <= 0.0) return;
+    const double n = na + nb, delta = mb - ma;
+    ma += delta * nb / n;
+    Ma += Mb + delta * delta * na * nb / n;
+    na = n;
+}
+
+__global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __restrict__ p, int ld, long long P, int C,
+                                                            float2* __restrict__ partial)
+{
+    __shared__ float2 red[4][64];
+    __shared__ int cnt[4];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
+    const long long p1 = min(P, p0 + VNP_CHUNK);
+    float mean = 0.f, m2 = 0.f;
+    int k = 0;
+    if (c < C) {
+        for (long long pt = p0 + py; pt < p1; pt += 4) {
+            const float* r = p + (size_t)pt * 3 * ld + c;
+            const float n = sqrtf(vnp_sq3(r[0], r[ld], r[2 * ld])) + VNP_EPS;
+            ++k;
+            const float delta = n - mean;
+            mean += delta / (float)k;
+            m2 += delta * (n - mean);
+        }
+    }
+    red[py][cx] = make_float2(mean, m2);
+    if (cx == 0) cnt[py] = (int)((p1 - p0 - py + 3) / 4 > 0 ? (p1 - p0 - py + 3) / 4 : 0);
+    __syncthreads();
+    if (py == 0 && c < C) {
+        double na = cnt[0], ma = red[0][cx].x, Ma = red[0][cx].y;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) vnp_chan_merge(na, ma, Ma, (double)cnt[j], (double)red[j][cx].x, (double)red[j][cx].y);
+        partial[(size_t)blockIdx.y * C + c] = make_float2((float)ma, (float)Ma);
+    }
+}
+
+// mean / rstd per channel from the chunk partials (Chan merge in double), running-stat update as torch does
+// (momentum, unbiased variance for running_var).
+__global__ void vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int C, long long count,
+                                       float* __restrict__ mean, float* __restrict__ rstd,
+                                       float* running_mean, float* running_var, float momentum, float eps)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double na = 0.0, ma = 0.0, Ma = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const float2 v = partial[(size_t)k * C + c];
+        const long long left = count - (long long)k * VNP_CHUNK;
+        const double nb = (double)(left < VNP_CHUNK ? left : VNP_CHUNK);
+        if (na == 0.0) { na = nb; ma = v.x; Ma = v.y; }
+        else vnp_chan_merge(na, ma, Ma, nb, (double)v.x, (double)v.y);
+    }
+    const double m = ma;
+    double var = Ma / (double)count;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+__global__ void vnp_rstd_from_var_kernel(const float* __restrict__ var, float* __restrict__ rstd, int C, float eps)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) rstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+
+// out = leaky(bn(p), d).  d == nullptr: BatchNorm only.  mean == nullptr: no BatchNorm (plain VNLeakyReLU).
+__global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ d, int ldd,
+                                                              float* __restrict__ out, int ldo, long long P, int C,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float ns)
+{
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    if (c >= C) return;
+    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
+    const long long p1 = min(P, p0 + VNP_CHUNK);
+    float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
+    if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
+    for (long long pt = p0 + py; pt < p1; pt += 4) {
+        const float* r = p + (size_t)pt * 3 * ldp + c;
+        float q0 = r[0], q1 = r[ldp], q2 = r[2 * ldp];
+        if (mean) {
+            const float n = sqrtf(vnp_sq3(q0, q1, q2)) + VNP_EPS;
+            const float s = ((n - mu) * rs * ga + be) / n;
+            q0 *= s; q1 *= s; q2 *= s;
+        }
+        if (d) {
+            const float* rd = d + (size_t)pt * 3 * ldd + c;
+            const float d0 = rd[0], d1 = rd[ldd], d2 = rd[2 * ldd];
+            const float dot = q0 * d0 + q1 * d1 + q2 * d2;
+            if (dot < 0.f) {
+                const float a = (1.f - ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                q0 -= a * d0; q1 -= a * d1; q2 -= a * d2;
+            }
+        }
+        float* o = out + (size_t)pt * 3 * ldo + c;
+        o[0] = q0; o[ldo] = q1; o[2 * ldo] = q2;
+    }
+}
+
+// Backward, phase 1.  Upstream gradient go is either a matrix [P*3, ldgo] or (go == nullptr) the rank-1 form
+// go[r][c] = go_row[r] * go_col[c] (gradient of the final VNLinear(C->1), models/pcn.py:346).
+// Writes gq = dL/dq (q = bn(p)) and gd = dL/dd, and the per-chunk partial sums S1 = sum g_nhat, S2 = sum g_nhat*xhat
+// (= dL/dbeta, dL/dgamma).  Without BatchNorm (mean == nullptr) gq is already dL/dp.
+__global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __restrict__ go, int ldgo,
+                                                               const float* __restrict__ go_row, const float* __restrict__ go_col,
+                                                               const float* __restrict__ p, int ldp, const float* __restrict__ d, int ldd,
+                                                               float* __restrict__ gq, int ldgq, float* __restrict__ gd, int ldgd,
+                                                               long long P, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float ns,
+                                                               float2* __restrict__ partial)
+{
+    __shared__ float2 red[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
+    const long long p1 = min(P, p0 + VNP_CHUNK);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, gc = 0.f;
+        if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
+        if (!go) gc = go_col[c];
+        for (long long pt = p0 + py; pt < p1; pt += 4) {
+            const float* r = p + (size_t)pt * 3 * ldp + c;
+            const float x0 = r[0], x1 = r[ldp], x2 = r[2 * ldp];
+            float g0, g1, g2;
+            if (go) {
+                const float* rg = go + (size_t)pt * 3 * ldgo + c;
+                g0 = rg[0]; g1 = rg[ldgo]; g2 = rg[2 * ldgo];
+            } else {
+                g0 = go_row[pt * 3] * gc; g1 = go_row[pt * 3 + 1] * gc; g2 = go_row[pt * 3 + 2] * gc;
+            }
+            float n = 1.f, s = 1.f, xh = 0.f;
+            if (mean) {
+                n = sqrtf(vnp_sq3(x0, x1, x2)) + VNP_EPS;
+                xh = (n - mu) * rs;
+                s = (xh * ga + be) / n;
+            }
+            const float q0 = x0 * s, q1 = x1 * s, q2 = x2 * s;
+            if (d) {
+                const float* rd = d + (size_t)pt * 3 * ldd + c;
+                const float d0 = rd[0], d1 = rd[ldd], d2 = rd[2 * ldd];
+                const float dot = q0 * d0 + q1 * d1 + q2 * d2;
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+                if (dot < 0.f) {
+                    const float cc = 1.f - ns;
+                    const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                    const float a = dot * inv;
+                    const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
+                    const float k1 = cc * gdd * inv;
+                    // dL/dd = -c [ a*go + gdd*(q*inv - 2 a inv d) ]
+                    e0 = -cc * (a * g0 + gdd * (q0 * inv - 2.f * a * inv * d0));
+                    e1 = -cc * (a * g1 + gdd * (q1 * inv - 2.f * a * inv * d1));
+                    e2 = -cc * (a * g2 + gdd * (q2 * inv - 2.f * a * inv * d2));
+                    g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;
+                }
+                float* wd = gd + (size_t)pt * 3 * ldgd + c;
+                wd[0] = e0; wd[ldgd] = e1; wd[2 * ldgd] = e2;
+            }
+            float* wq = gq + (size_t)pt * 3 * ldgq + c;
+            wq[0] = g0; wq[ldgq] = g1; wq[2 * ldgq] = g2;
+            if (mean) {
+                const float gnh = (g0 * x0 + g1 * x1 + g2 * x2) / n;     // dL/dnhat = (gq . p) / n
+                s1 += gnh; s2 += gnh * xh;
+            }
+        }
+    }
+    if (partial) {
+        red[py][cx] = make_float2(s1, s2);
+        __syncthreads();
+        if (py == 0 && c < C) {
+            float2 a = red[0][cx], b = red[1][cx], e = red[2][cx], f = red[3][cx];
+            partial[(size_t)blockIdx.y * C + c] = make_float2((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y));
+        }
+    }
+}
+
+// Backward, phase 2 (BatchNorm only): g (in: dL/dq, out: dL/dp).
+//   train: g_n = gamma*rstd*(g_nhat - S1/count - xhat*S2/count) - g_s*nhat/n^2     eval (S == nullptr): without the batch terms
+//   g_p = s*g_q + g_n * p/|p|
+__global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g, int ldg, const float* __restrict__ p, int ldp,
+                                                         long long P, int C,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ S, float inv_count)
+{
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    if (c >= C) return;
+    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
+    const long long p1 = min(P, p0 + VNP_CHUNK);
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const float m1 = S ? S[2 * c] * inv_count : 0.f, m2 = S ? S[2 * c + 1] * inv_count : 0.f;
+    for (long long pt = p0 + py; pt < p1; pt += 4) {
+        const float* r = p + (size_t)pt * 3 * ldp + c;
+        const float x0 = r[0], x1 = r[ldp], x2 = r[2 * ldp];
+        float* rg = g + (size_t)pt * 3 * ldg + c;
+        const float g0 = rg[0], g1 = rg[ldg], g2 = rg[2 * ldg];
+        const float pn = sqrtf(vnp_sq3(x0, x1, x2));
+        const float n = pn + VNP_EPS;
+        const float xh = (n - mu) * rs;
+        const float nh = xh * ga + be;
+        const float s = nh / n;
+        const float gs = g0 * x0 + g1 * x1 + g2 * x2;
+        const float gnh = gs / n;
+        const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
+        const float k = pn > 0.f ? gn / pn : 0.f;
+        rg[0] = s * g0 + k * x0; rg[ldg] = s * g1 + k * x1; rg[2 * ldg] = s * g2 + k * x2;
+    }
+}
+
+// out[b][j] = sum_{i<n} in[b*batch_stride + i*stride + j]   (double accumulation; small finalisation reductions)
+__global__ void vnp_reduce_rows_kernel(const float* __restrict__ in, long long batch_stride, int n, long long stride, int W,
+                                       float* __restrict__ out, long long out_stride)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= W) return;
+    const float* src = in + (size_t)blockIdx.y * batch_stride + j;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += src[(size_t)i * stride];
+    out[(size_t)blockIdx.y * out_stride + j] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+// VNMaxPool (vn_layers.py:153-167): per group of gs consecutive points and channel c, argmax_n <x, d>, first max wins.
+// Stage 1: grid (ceil(C/64), nchunk, G): best (value, local index) of each chunk of the group.
+__global__ void __launch_bounds__(256) vnp_pool_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ d, int ldd,
+                                                              int gs, int C, int nchunk, float* __restrict__ pval, int* __restrict__ pidx)
+{
+    __shared__ float rv[4][64];
+    __shared__ int ri[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long g = blockIdx.z;
+    const int n0 = blockIdx.y * VNP_CHUNK, n1 = min(gs, n0 + VNP_CHUNK);
+    float best = -INFINITY; int bi = 0x7fffffff;
+    if (c < C) {
+        for (int n = n0 + py; n < n1; n += 4) {
+            const size_t row = ((size_t)g * gs + n) * 3;
+            const float* rx = x + row * ldx + c;
+            const float* rd = d + row * ldd + c;
+            const float dot = rx[0] * rd[0] + rx[ldx] * rd[ldd] + rx[2 * ldx] * rd[2 * ldd];
+            if (dot > best || bi == 0x7fffffff) { best = dot; bi = n; }
+        }
+    }
+    rv[py][cx] = best; ri[py][cx] = bi;
+    __syncthreads();
+    if (py == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float v = rv[k][cx]; const int i = ri[k][cx];
+            if (i != 0x7fffffff && (bi == 0x7fffffff || v > best || (v == best && i < bi))) { best = v; bi = i; }
+        }
+        pval[((size_t)g * nchunk + blockIdx.y) * C + c] = best;
+        pidx[((size_t)g * nchunk + blockIdx.y) * C + c] = bi;
+    }
+}
+
+// Stage 2: grid (ceil(C/256), G): reduce the chunk partials (ascending chunk order keeps the first maximum),
+// write idx and gather the selected vectors.
+__global__ void vnp_pool_final_kernel(const float* __restrict__ x, int ldx, int gs, int C, int nchunk,
+                                      const float* __restrict__ pval, const int* __restrict__ pidx,
+                                      int* __restrict__ idx, float* __restrict__ out, int ldo)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y;
+    float best = pval[(size_t)g * nchunk * C + c];
+    int bi = pidx[(size_t)g * nchunk * C + c];
+    for (int k = 1; k < nchunk; ++k) {
+        const float v = pval[((size_t)g * nchunk + k) * C + c];
+        if (v > best) { best = v; bi = pidx[((size_t)g * nchunk + k) * C + c]; }
+    }
+    idx[(size_t)g * C + c] = bi;
+    const size_t row = ((size_t)g * gs + bi) * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) out[((size_t)g * 3 + t) * ldo + c] = x[(row + t) * ldx + c];
+}
+
+// gx (zero-filled beforehand) [(g*gs + idx[g][c])*3 + t][c] = gout[g*3+t][c]
+__global__ void vnp_pool_bwd_kernel(const float* __restrict__ gout, int ldgo, const int* __restrict__ idx, int gs, int C,
+                                    float* __restrict__ gx, int ldgx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y;
+    const size_t row = ((size_t)g * gs + idx[(size_t)g * C + c]) * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) gx[(row + t) * ldgx + c] = gout[((size_t)g * 3 + t) * ldgo + c];
+}
+
+// mean over groups of gs consecutive points (vn_layers.py:170-171 on the neighbour axis); grid (ceil(C/256), G*3)
+__global__ void vnp_mean_pool_fwd_kernel(const float* __restrict__ x, int ldx, int gs, int C, float* __restrict__ out, int ldo)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y / 3; const int t = blockIdx.y % 3;
+    float s = 0.f;
+    for (int n = 0; n < gs; ++n) s += x[(((size_t)g * gs + n) * 3 + t) * ldx + c];
+    out[(size_t)blockIdx.y * ldo + c] = s / (float)gs;
+}
+
+__global__ void vnp_mean_pool_bwd_kernel(const float* __restrict__ gout, int ldgo, int gs, int C, float* __restrict__ gx, int ldgx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y / 3; const int t = blockIdx.y % 3;
+    const float v = gout[(size_t)blockIdx.y * ldgo + c] / (float)gs;
+    for (int n = 0; n < gs; ++n) gx[(((size_t)g * gs + n) * 3 + t) * ldgx + c] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ folding
+// Layer 1 of VN_FoldingNet with the broadcast input de-duplicated (models/pcn.py:375-387): of the latent+2 input
+// channels, `latent` are the per-sample global feature, so W[:, :latent] g is a per-sample bias; what is left per
+// point is the rank-2 term  w_seed * seed[s] + w_coarse * coarse[b, mc].
+//   out[((b*Mc + mc)*S + s)*3 + t][j] = bias[b*3+t][j] + wseed[j]*seed[(b)][s][t] + wcoarse[j]*coarse[b][mc][t]
+// grid (ceil(W/256), B*Mc): one block per coarse point, threads over the W (= 2*C: feat | dir) columns.
+__global__ void __launch_bounds__(256) vnp_fold_fwd_kernel(const float* __restrict__ bias, int ldb, const float* __restrict__ wseed,
+                                                          const float* __restrict__ wcoarse, const float* __restrict__ seed, int seed_batched,
+                                                          const float* __restrict__ coarse, int Mc, int S, int W,
+                                                          float* __restrict__ out, int ldo)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= W) return;
+    const long long pc = blockIdx.y;             // b*Mc + mc
+    const int b = (int)(pc / Mc);
+    const float ws = wseed[j], wc = wcoarse[j];
+    float base[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) base[t] = bias[((size_t)b * 3 + t) * ldb + j] + wc * coarse[pc * 3 + t];
+    const float* sd = seed + (seed_batched ? (size_t)b * S * 3 : 0);
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            out[(((size_t)pc * S + s) * 3 + t) * ldo + j] = base[t] + ws * sd[s * 3 + t];
+    }
+}
+
+// Backward of the expansion: per coarse point partial sums over its S folded points, for column j:
+//   part[pc][0..2][j] = sum_s g[(pc,s,t)][j]                (-> bias gradient after summing over mc)
+//   part[pc][3][j]    = sum_{s,t} g * seed[s][t]            (-> wseed gradient)
+//   part[pc][4][j]    = sum_{s,t} g * coarse[pc][t]         (-> wcoarse gradient)
+// The caller reduces `part` over mc (per sample) / over everything with vnp_reduce_rows.
+__global__ void __launch_bounds__(256) vnp_fold_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ seed, int seed_batched,
+                                                          const float* __restrict__ coarse, int Mc, int S, int W, float* __restrict__ part)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= W) return;
+    const long long pc = blockIdx.y;
+    const int b = (int)(pc / Mc);
+    const float* sd = seed + (seed_batched ? (size_t)b * S * 3 : 0);
+    float a[3] = {0.f, 0.f, 0.f}, as = 0.f;
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float v = g[(((size_t)pc * S + s) * 3 + t) * ldg + j];
+            a[t] += v; as += v * sd[s * 3 + t];
+        }
+    }
+    float* o = part + (size_t)pc * 5 * W + j;
+    o[0] = a[0]; o[W] = a[1]; o[2 * W] = a[2]; o[3 * W] = as;
+    o[4 * W] = a[0] * coarse[pc * 3] + a[1] * coarse[pc * 3 + 1] + a[2] * coarse[pc * 3 + 2];
+}
+
+// ------------------------------------------------------------------------------------------------ row / column reductions
+// out[r] = sum_c X[r][c] * w[c] (+ add[((r/3)/add_group)*3 + r%3]); one wave per row, 4 rows per block.
+__global__ void __launch_bounds__(256) vnp_rowdot_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ w, long long R, int C,
+                                                        const float* __restrict__ add, int add_group, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* row = X + (size_t)r * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += row[c] * w[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        if (add) s += add[((r / 3) / add_group) * 3 + r % 3];
+        out[r] = s;
+    }
+}
+
+// out[pc*3+t] (+)= sum_{s<S} in[((pc*S+s)*3+t)]
+__global__ void vnp_group_sum3_kernel(const float* __restrict__ in, long long Pc, int S, float* __restrict__ out, int accumulate)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Pc * 3) return;
+    const long long pc = i / 3; const int t = (int)(i % 3);
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += in[((size_t)pc * S + k) * 3 + t];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// partial[b][chunk][c] = sum over the chunk's rows r of X[b*batch_stride + r*row_stride + c] * (w ? w[b*R + r] : 1)
+// grid (ceil(C/64), nchunk, nb); chunk = VNP_CHUNK rows.
+__global__ void __launch_bounds__(256) vnp_colsum_kernel(const float* __restrict__ X, long long batch_stride, long long row_stride,
+                                                        long long R, int C, const float* __restrict__ w, int nchunk, float* __restrict__ partial)
+{
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long r0 = (long long)blockIdx.y * VNP_CHUNK, r1 = min(R, r0 + VNP_CHUNK);
+    const float* base = X + (size_t)blockIdx.z * batch_stride;
+    float s = 0.f;
+    if (c < C)
+        for (long long r = r0 + py; r < r1; r += 4)
+            s += base[(size_t)r * row_stride + c] * (w ? w[(size_t)blockIdx.z * R + r] : 1.f);
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && c < C)
+        partial[((size_t)blockIdx.z * nchunk + blockIdx.y) * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
+// out[i] = a[i] + b[i]  /  a[i] += b[i] style helpers are left to the GEMM's accumulate flag; this one converts layouts:
+// rows layout [P*3, C] (ld) <-> reference layout [B, C, 3, N]: out_ref[((b*C + c)*3 + t)*N + n] = rows[((b*N+n)*3+t)*ld + c]
+__global__ void vnp_rows_to_ref_kernel(const float* __restrict__ rows, int ld, int B, int C, int N, float* __restrict__ ref)
+{
+    const long long total = (long long)B * C * 3 * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N); long long k = i / N;
+        const int t = (int)(k % 3); k /= 3;
+        const int c = (int)(k % C); const int b = (int)(k / C);
+        ref[i] = rows[(((size_t)b * N + n) * 3 + t) * ld + c];
+    }
+}
+
+__global__ void vnp_ref_to_rows_kernel(const float* __restrict__ ref, int B, int C, int N, float* __restrict__ rows, int ld)
+{
+    const long long total = (long long)B * N * 3 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long long k = i / C;
+        const int t = (int)(k % 3); k /= 3;
+        const int n = (int)(k % N); const int b = (int)(k / N);
+        rows[(((size_t)b * N + n) * 3 + t) * ld + c] = ref[(((size_t)b * C + c) * 3 + t) * N + n];
+    }
+}
+
+
+// out[r][c] = u[r] * w[c]   (gradient of the final VNLinear(C->1) w.r.t. its input)
+__global__ void vnp_outer_kernel(const float* __restrict__ u, const float* __restrict__ w, long long R, int C, float* __restrict__ out, int ldo)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= C) return;
+    const float wc = w[c];
+    const long long r0 = (long long)blockIdx.y * 64;
+    for (long long r = r0 + (threadIdx.x >> 6); r < min(R, r0 + 64); r += 4) out[(size_t)r * ldo + c] = u[r] * wc;
+}
+
+extern "C" int vnp_outer(hipStream_t st, const float* u, const float* w, long long R, int C, float* out, int ldo)
+{
+    if (!u || !w || !out || R <= 0 || C <= 0) return VNP_EINVAL;
+    if ((R + 63) / 64 > 65535LL * 64) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_outer_kernel, dim3(vnp_cdiv(C, 64), vnp_cdiv(R, 64)), dim3(256), 0, st, u, w, R, C, out, ldo);
+    return vnp_last_error();
+}
+
+// ================================================================================================ C-ABI
+static inline dim3 vnp_grid_pc(long long P, int C) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, VNP_CHUNK)); }
+
+extern "C" int vnp_vn_norm_stats(hipStream_t st, const float* p, int ldp, long long P, int C, float* partial)
+{
+    if (!p || !partial || P <= 0 || C <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_norm_stats_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, p, ldp, P, C, (float2*)partial);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_bn_finalize(hipStream_t st, const float* partial, int nchunk, int C, long long count,
+                                  float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps)
+{
+    if (!partial || !mean || !rstd || C <= 0 || count <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(64), 0, st, (const float2*)partial, nchunk, C, count,
+                       mean, rstd, running_mean, running_var, momentum, eps);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_rstd_from_var(hipStream_t st, const float* var, float* rstd, int C, float eps)
+{
+    if (!var || !rstd || C <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_rstd_from_var_kernel, dim3(vnp_cdiv(C, 256)), dim3(256), 0, st, var, rstd, C, eps);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_bn_leaky_fwd(hipStream_t st, const float* p, int ldp, const float* d, int ldd, float* out, int ldo,
+                                   long long P, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   float negative_slope)
+{
+    if (!p || !out || P <= 0 || C <= 0) return VNP_EINVAL;
+    if (mean && (!rstd || !gamma || !beta)) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_bn_leaky_fwd_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, p, ldp, d, ldd, out, ldo, P, C,
+                       mean, rstd, gamma, beta, negative_slope);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, const float* go_row, const float* go_col,
+                                    const float* p, int ldp, const float* d, int ldd,
+                                    float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                    float negative_slope, float* partial)
+{
+    if (!p || !gq || P <= 0 || C <= 0) return VNP_EINVAL;
+    if (!go && (!go_row || !go_col)) return VNP_EINVAL;
+    if (d && !gd) return VNP_EINVAL;
+    if (mean && (!rstd || !gamma || !beta || !partial)) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
+                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_bn_bwd2(hipStream_t st, float* g, int ldg, const float* p, int ldp, long long P, int C,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              const float* S, long long count)
+{
+    if (!g || !p || !mean || !rstd || !gamma || !beta || P <= 0 || C <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_bn_bwd2_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, g, ldg, p, ldp, P, C, mean, rstd, gamma, beta,
+                       S, count > 0 ? 1.0f / (float)count : 0.f);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long long batch_stride, int n, long long stride, int W,
+                               float* out, long long out_stride)
+{
+    if (!in || !out || nb <= 0 || n <= 0 || W <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(W, 64), nb), dim3(64), 0, st, in, batch_stride, n, stride, W, out, out_stride);
+    return vnp_last_error();
+}
+
+// ws_val / ws_idx: G * ceil(gs / vnp_chunk_points()) * C elements each
+extern "C" int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int ldd, long long G, int gs, int C,
+                               int* idx, float* out, int ldo, float* ws_val, int* ws_idx)
+{
+    if (!x || !d || !idx || !out || !ws_val || !ws_idx || G <= 0 || gs <= 0 || C <= 0 || G > 2147483647LL) return VNP_EINVAL;
+    const int nchunk = vnp_cdiv(gs, VNP_CHUNK);
+    if (nchunk > 65535) return VNP_EINVAL;
+    // gridDim.z is limited to 65535: loop over slices of groups
+    for (long long g0 = 0; g0 < G; g0 += 65535) {
+        const int ng = (int)((G - g0) < 65535 ? (G - g0) : 65535);
+        hipLaunchKernelGGL(vnp_pool_partial_kernel, dim3(vnp_cdiv(C, 64), nchunk, ng), dim3(256), 0, st,
+                           x + (size_t)g0 * gs * 3 * ldx, ldx, d + (size_t)g0 * gs * 3 * ldd, ldd, gs, C, nchunk,
+                           ws_val + (size_t)g0 * nchunk * C, ws_idx + (size_t)g0 * nchunk * C);
+        hipLaunchKernelGGL(vnp_pool_final_kernel, dim3(vnp_cdiv(C, 256), ng), dim3(256), 0, st,
+                           x + (size_t)g0 * gs * 3 * ldx, ldx, gs, C, nchunk,
+                           (const float*)(ws_val + (size_t)g0 * nchunk * C), (const int*)(ws_idx + (size_t)g0 * nchunk * C),
+                           idx + (size_t)g0 * C, out + (size_t)g0 * 3 * ldo, ldo);
+    }
+    return vnp_last_error();
+}
+
+// gx [G*gs*3, ldgx] is zero-filled here, then the selected rows receive gout.
+extern "C" int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
+                               float* gx, int ldgx)
+{
+    if (!gout || !idx || !gx || G <= 0 || gs <= 0 || C <= 0) return VNP_EINVAL;
+    if (ldgx != C) {
+        // strided destination: clear row by row
+        hipError_t e = hipMemset2DAsync(gx, (size_t)ldgx * 4, 0, (size_t)C * 4, (size_t)G * gs * 3, st);
+        if (e != hipSuccess) return (int)e;
+    } else {
+        hipError_t e = hipMemsetAsync(gx, 0, (size_t)G * gs * 3 * C * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    for (long long g0 = 0; g0 < G; g0 += 65535) {
+        const int ng = (int)((G - g0) < 65535 ? (G - g0) : 65535);
+        hipLaunchKernelGGL(vnp_pool_bwd_kernel, dim3(vnp_cdiv(C, 256), ng), dim3(256), 0, st,
+                           gout + (size_t)g0 * 3 * ldgo, ldgo, idx + (size_t)g0 * C, gs, C, gx + (size_t)g0 * gs * 3 * ldgx, ldgx);
+    }
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_mean_pool_fwd(hipStream_t st, const float* x, int ldx, long long G, int gs, int C, float* out, int ldo)
+{
+    if (!x || !out || G <= 0 || gs <= 0 || C <= 0) return VNP_EINVAL;
+    for (long long g0 = 0; g0 < G; g0 += 21845) {
+        const int ng = (int)((G - g0) < 21845 ? (G - g0) : 21845);
+        hipLaunchKernelGGL(vnp_mean_pool_fwd_kernel, dim3(vnp_cdiv(C, 256), ng * 3), dim3(256), 0, st,
+                           x + (size_t)g0 * gs * 3 * ldx, ldx, gs, C, out + (size_t)g0 * 3 * ldo, ldo);
+    }
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_mean_pool_bwd(hipStream_t st, const float* gout, int ldgo, long long G, int gs, int C, float* gx, int ldgx)
+{
+    if (!gout || !gx || G <= 0 || gs <= 0 || C <= 0) return VNP_EINVAL;
+    for (long long g0 = 0; g0 < G; g0 += 21845) {
+        const int ng = (int)((G - g0) < 21845 ? (G - g0) : 21845);
+        hipLaunchKernelGGL(vnp_mean_pool_bwd_kernel, dim3(vnp_cdiv(C, 256), ng * 3), dim3(256), 0, st,
+                           gout + (size_t)g0 * 3 * ldgo, ldgo, gs, C, gx + (size_t)g0 * gs * 3 * ldgx, ldgx);
+    }
+    return vnp_last_error();
+}
+
+extern "C" int vnp_fold_fwd(hipStream_t st, const float* bias, int ldb, const float* wseed, const float* wcoarse,
+                            const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int W,
+                            float* out, int ldo)
+{
+    if (!bias || !wseed || !wcoarse || !seed || !coarse || !out || B <= 0 || Mc <= 0 || S <= 0 || W <= 0) return VNP_EINVAL;
+    if ((long long)B * Mc > 2147483647LL / 4) return VNP_EINVAL;
+    const long long npc = (long long)B * Mc;
+    for (long long g0 = 0; g0 < npc;) {
+        // whole samples per launch (gridDim.y <= 65535) so that b = pc / Mc stays valid with the offset pointers
+        const long long nb = (npc - g0) / Mc;
+        const long long take = nb * Mc < 65535 ? nb * Mc : (65535 / Mc) * (long long)Mc;
+        if (take <= 0) return VNP_EINVAL;
+        const int b0 = (int)(g0 / Mc);
+        hipLaunchKernelGGL(vnp_fold_fwd_kernel, dim3(vnp_cdiv(W, 256), (int)take), dim3(256), 0, st,
+                           bias + (size_t)b0 * 3 * ldb, ldb, wseed, wcoarse, seed + (seed_batched ? (size_t)b0 * S * 3 : 0), seed_batched,
+                           coarse + (size_t)g0 * 3, Mc, S, W, out + (size_t)g0 * S * 3 * ldo, ldo);
+        g0 += take;
+    }
+    return vnp_last_error();
+}
+
+// part: [B*Mc][5][W]
+extern "C" int vnp_fold_bwd(hipStream_t st, const float* g, int ldg, const float* seed, int seed_batched, const float* coarse,
+                            int B, int Mc, int S, int W, float* part)
+{
+    if (!g || !seed || !coarse || !part || B <= 0 || Mc <= 0 || S <= 0 || W <= 0) return VNP_EINVAL;
+    const long long npc = (long long)B * Mc;
+    for (long long g0 = 0; g0 < npc;) {
+        const long long nb = (npc - g0) / Mc;
+        const long long take = nb * Mc < 65535 ? nb * Mc : (65535 / Mc) * (long long)Mc;
+        if (take <= 0) return VNP_EINVAL;
+        const int b0 = (int)(g0 / Mc);
+        hipLaunchKernelGGL(vnp_fold_bwd_kernel, dim3(vnp_cdiv(W, 256), (int)take), dim3(256), 0, st,
+                           g + (size_t)g0 * S * 3 * ldg, ldg, seed + (seed_batched ? (size_t)b0 * S * 3 : 0), seed_batched,
+                           coarse + (size_t)g0 * 3, Mc, S, W, part + (size_t)g0 * 5 * W);
+        g0 += take;
+    }
+    return vnp_last_error();
+}
+
+extern "C" int vnp_rowdot(hipStream_t st, const float* X, int ldx, const float* w, long long R, int C,
+                          const float* add, int add_group, float* out)
+{
+    if (!X || !w || !out || R <= 0 || C <= 0) return VNP_EINVAL;
+    if (add && add_group <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_rowdot_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, X, ldx, w, R, C, add, add_group > 0 ? add_group : 1, out);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_group_sum3(hipStream_t st, const float* in, long long Pc, int S, float* out, int accumulate)
+{
+    if (!in || !out || Pc <= 0 || S <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_group_sum3_kernel, dim3(vnp_cdiv(Pc * 3, 256)), dim3(256), 0, st, in, Pc, S, out, accumulate);
+    return vnp_last_error();
+}
+
+// partial: [nb][ceil(R / vnp_chunk_points())][C]
+extern "C" int vnp_colsum(hipStream_t st, const float* X, long long batch_stride, long long row_stride, int nb, long long R, int C,
+                          const float* w, float* partial)
+{
+    if (!X || !partial || nb <= 0 || R <= 0 || C <= 0 || nb > 65535) return VNP_EINVAL;
+    const int nchunk = vnp_cdiv(R, VNP_CHUNK);
+    if (nchunk > 65535) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_colsum_kernel, dim3(vnp_cdiv(C, 64), nchunk, nb), dim3(256), 0, st, X, batch_stride, row_stride, R, C, w, nchunk, partial);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_rows_to_ref(hipStream_t st, const float* rows, int ld, int B, int C, int N, float* ref)
+{
+    if (!rows || !ref || B <= 0 || C <= 0 || N <= 0) return VNP_EINVAL;
+    const long long total = (long long)B * C * 3 * N;
+    hipLaunchKernelGGL(vnp_rows_to_ref_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, rows, ld, B, C, N, ref);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_ref_to_rows(hipStream_t st, const float* ref, int B, int C, int N, float* rows, int ld)
+{
+    if (!rows || !ref || B <= 0 || C <= 0 || N <= 0) return VNP_EINVAL;
+    const long long total = (long long)B * C * 3 * N;
+    hipLaunchKernelGGL(vnp_ref_to_rows_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, ref, B, C, N, rows, ld);
+    return vnp_last_error();
+}

@@ -1,0 +1,26 @@
+// Shared helpers for the gfx950 HIP kernels behind the C-ABI in include/vnpcc.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VNP_OK 0
+#define VNP_EINVAL (-1)
+
+#define VNP_EPS 1e-6f          // models/vn_layers.py:10
+#define VNP_WAVE 64
+
+static inline int vnp_last_error() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VNP_OK : (int)e;
+}
+
+static inline int vnp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+typedef float vnp_f4 __attribute__((ext_vector_type(4)));
+typedef float vnp_f16 __attribute__((ext_vector_type(16)));
+
+// Activation layout used by every VN kernel ("rows layout"):
+//   a VN feature map with P points and C channels is a row-major float matrix [P*3, ld],
+//   row = point*3 + t (t = Cartesian component), channels contiguous.
+// The reference's [B, C, 3, N] tensors (models/vn_layers.py:19) map to it by
+//   rows[(b*N + n)*3 + t][c] = x[b][c][t][n].

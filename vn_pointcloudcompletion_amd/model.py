@@ -1,0 +1,67 @@
+"""Model factory with the reference's plugin surface (/root/reference/models/model.py:9-64):
+``PCNNet(config, enc_type, dec_type)``, attributes ``.encoder`` / ``.decoder`` / ``.num_coarse`` / ``.only_coarse``,
+``forward(input[B,N,3], rot=None) -> (coarse[B,Mc,3], fine[B,Md,3] | None)``."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .pcn import VN_FoldingNet, VN_PointNet
+
+ENCODERS = ("dgcnn_fps", "vn_dgcnn_fps", "vn_pointnet", "vn_pointr")
+DECODERS = ("vn_foldingnet", "foldingnet", "attention_vn_foldingnet")
+
+
+def _make_encoder(config, enc_type):
+    if enc_type == "vn_pointnet":
+        return VN_PointNet(config)
+    if enc_type == "vn_dgcnn_fps":
+        from .dgcnn import VN_DGCNN_fps
+        return VN_DGCNN_fps(config, only_coarse=config.only_coarse)
+    if enc_type == "vn_pointr":
+        from .vn_pointr import VN_PCTransformer
+        return VN_PCTransformer(in_chans=3, embed_dim=384, depth=[6, 8], drop_rate=0., num_query=224, knn_layer=1,
+                                dgcnn="vn_dgcnn", trans="vn_trans", memory_profile=False, only_coarse=True)
+    if enc_type == "dgcnn_fps":
+        raise NotImplementedError("enc_type 'dgcnn_fps' (non-equivariant baseline) is outside the VN hot path "
+                                  "(SURVEY.md §8f rank 4)")
+    raise Exception(f"encoder type {enc_type} not supported yet")          # models/model.py:20-21,26
+
+
+def _make_decoder(config, dec_type, enc_type):
+    if dec_type == "vn_foldingnet":
+        return VN_FoldingNet(config)
+    if dec_type == "attention_vn_foldingnet":
+        from .attention_decoder import Attention_VN_FoldingNet
+        return Attention_VN_FoldingNet(config)
+    if dec_type == "foldingnet":
+        raise NotImplementedError("dec_type 'foldingnet' (non-equivariant baseline) is outside the VN hot path "
+                                  "(SURVEY.md §8f rank 4)")
+    raise Exception(f"encoder type {enc_type} not supported yet")          # sic, models/model.py:48
+
+
+class PCNNet(nn.Module):
+    def __init__(self, config, enc_type="dgcnn_fps", dec_type="foldingnet"):
+        super().__init__()
+        self.num_coarse = config.num_coarse
+        self.only_coarse = config.only_coarse
+        self.encoder = _make_encoder(config, enc_type).to(config.device)
+        if config.enc_pretrained != "none":
+            sd = torch.load(config.enc_pretrained, map_location=config.device)
+            self.encoder.load_state_dict(sd, strict=False)
+            for param in self.encoder.parameters():
+                param.requires_grad = False
+        if not config.only_coarse:
+            self.decoder = _make_decoder(config, dec_type, enc_type).to(config.device)
+
+    def forward(self, input, rot=None):
+        coarse, feature_global = self.encoder(input)
+        if self.num_coarse == 448:
+            if self.only_coarse:
+                return coarse[1], None
+            fine = self.decoder(coarse[0], feature_global, rot)
+            return coarse[1], fine
+        if self.only_coarse:
+            return coarse, None
+        fine = self.decoder(coarse, feature_global, rot)
+        return coarse, fine

@@ -1,0 +1,472 @@
+"""Tensor-level wrappers and autograd Functions over libvnpcc (include/vnpcc.h).
+
+Everything here works on the *rows layout*: a VN feature map with P points and C channels is a
+2-D fp32 tensor ``[P*3, C]`` (row = point*3 + t, channels contiguous, ``stride(1) == 1``).
+torch supplies device memory, the current HIP stream and the autograd graph; all arithmetic
+is done by the HIP kernels.  No function in this file has a CPU / PyTorch fallback.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import call, ptr
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """Return t as a 2-D fp32 device tensor with unit inner stride (copying only if needed)."""
+    _lib.require_gpu(t)
+    if t.dtype != torch.float32:
+        raise _lib.VnpError(f"fp32 expected, got {t.dtype}")
+    if t.dim() != 2:
+        raise _lib.VnpError(f"2-D rows tensor expected, got shape {tuple(t.shape)}")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def _nchunk(P: int) -> int:
+    c = _lib.chunk_points()
+    return (P + c - 1) // c
+
+
+def gemm(A, B, *, op_a=0, op_b=0, out=None, A2=None, B2=None, bias=None, rows_per_group=0,
+         accumulate=False, nsplit=None):
+    """C = op(A) op(B) (+ op(A2) op(B2)) (+ per-sample bias).  See vnp_gemm in include/vnpcc.h."""
+    A, B = _rows(A), _rows(B)
+    M, K = (A.shape[0], A.shape[1]) if op_a == 0 else (A.shape[1], A.shape[0])
+    N, Kb = (B.shape[0], B.shape[1]) if op_b == 0 else (B.shape[1], B.shape[0])
+    if K != Kb:
+        raise _lib.VnpError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    K2 = 0
+    if A2 is not None:
+        A2, B2 = _rows(A2), _rows(B2)
+        K2 = A2.shape[1] if op_a == 0 else A2.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    elif out.shape != (M, N) or out.stride(1) != 1:
+        raise _lib.VnpError("gemm: bad output tensor")
+    if bias is not None:
+        bias = _rows(bias)
+    if nsplit is None:
+        nsplit = 1
+        if bias is None:
+            bm = 192 if op_a == 0 else 128
+            tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
+            nk = (K + 31) // 32 + ((K2 + 31) // 32 if K2 else 0)
+            if tiles < 256 and nk >= 8:
+                nsplit = max(1, min(nk // 4, 1024 // tiles))
+    ws = None
+    if nsplit > 1:
+        ws = torch.empty((nsplit, M, N), device=A.device, dtype=torch.float32)
+    call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
+         ptr(A2), _ld(A2) if A2 is not None else 0, ptr(B2), _ld(B2) if B2 is not None else 0, K2,
+         ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))
+    return out
+
+
+def _per_sample_colsum(g, rows_per_group):
+    """g [R, W] contiguous -> [R/rows_per_group*3, W]: sum over the points of each sample, per (t, column)."""
+    R, W = g.shape
+    assert g.is_contiguous()
+    nb = R // rows_per_group
+    npts = rows_per_group // 3
+    nch = _nchunk(npts)
+    part = torch.empty((nb, nch, 3 * W), device=g.device, dtype=torch.float32)
+    call("vnp_colsum", ptr(g), rows_per_group * W, 3 * W, nb, npts, 3 * W, None, ptr(part))
+    out = torch.empty((nb * 3, W), device=g.device, dtype=torch.float32)
+    call("vnp_reduce_rows", ptr(part), nb, nch * 3 * W, nch, 3 * W, 3 * W, ptr(out), 3 * W)
+    return out
+
+
+def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training, ns, use_bn=True):
+    """p, d: [R, C] views (d may be None).  Returns out, mean, rstd."""
+    R = p.shape[0]
+    P = R // 3
+    dev = p.device
+    mean = rstd = None
+    if use_bn:
+        if training:
+            nch = _nchunk(P)
+            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                 BN_MOMENTUM, BN_EPS)
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+    out = torch.empty((R, C), device=dev, dtype=torch.float32)
+    call("vnp_vn_bn_leaky_fwd", ptr(p), _ld(p), ptr(d), _ld(d) if d is not None else 0, ptr(out), C, P, C,
+         ptr(mean), ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None, ns)
+    return out, mean, rstd
+
+
+def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_bn=True, go_row=None, go_col=None):
+    """Returns (gpd [R, 2C or C] with dL/dp in [:, :C] and dL/dd in [:, C:], ggamma, gbeta)."""
+    R = p.shape[0]
+    P = R // 3
+    dev = p.device
+    has_d = d is not None
+    gpd = torch.empty((R, 2 * C if has_d else C), device=dev, dtype=torch.float32)
+    ldg = gpd.shape[1]
+    gq = gpd
+    gd = gpd[:, C:] if has_d else None
+    nch = _nchunk(P)
+    part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32) if use_bn else None
+    if go is not None:
+        go = _rows(go)
+    call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
+         ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0, ptr(gq), ldg, ptr(gd), ldg, P, C,
+         ptr(mean) if use_bn else None, ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None,
+         ns, ptr(part))
+    ggamma = gbeta = None
+    if use_bn:
+        S = torch.empty((C, 2), device=dev, dtype=torch.float32)
+        call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
+        call("vnp_vn_bn_bwd2", ptr(gq), ldg, ptr(p), _ld(p), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+             ptr(S) if training else None, P)
+        gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
+    return gpd, ggamma, gbeta
+
+
+def _wgrad(gy, x):
+    """dW [Cout, Cin] = gy[R, Cout]^T x[R, Cin]  (TN GEMM, split over the R rows)."""
+    return gemm(gy, x, op_a=1, op_b=1)
+
+
+# ------------------------------------------------------------------------------- autograd Functions
+class ToRowsFn(Function):
+    """reference layout [B, C, 3, N] -> rows [(B*N)*3, C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_gpu(x)
+        x = x.contiguous()
+        B, C, _, N = x.shape
+        ctx.dims = (B, C, N)
+        rows = torch.empty((B * N * 3, C), device=x.device, dtype=torch.float32)
+        call("vnp_ref_to_rows", ptr(x), B, C, N, ptr(rows), C)
+        return rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, C, N = ctx.dims
+        g = _rows(g)
+        out = torch.empty((B, C, 3, N), device=g.device, dtype=torch.float32)
+        call("vnp_rows_to_ref", ptr(g), _ld(g), B, C, N, ptr(out))
+        return out
+
+
+class FromRowsFn(Function):
+    """rows [(B*N)*3, C] -> reference layout [B, C, 3, N]."""
+
+    @staticmethod
+    def forward(ctx, rows, B, N):
+        rows = _rows(rows)
+        C = rows.shape[1]
+        ctx.dims = (B, C, N)
+        out = torch.empty((B, C, 3, N), device=rows.device, dtype=torch.float32)
+        call("vnp_rows_to_ref", ptr(rows), _ld(rows), B, C, N, ptr(out))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        B, C, N = ctx.dims
+        g = g.contiguous()
+        rows = torch.empty((B * N * 3, C), device=g.device, dtype=torch.float32)
+        call("vnp_ref_to_rows", ptr(g), B, C, N, ptr(rows), C)
+        return rows, None, None
+
+
+class VNLinearFn(Function):
+    """y = x W^T (+ per-sample bias)  —  VNLinear, models/vn_layers.py:12-22."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias=None, rows_per_group=0):
+        x = _rows(x)
+        y = gemm(x, W, bias=bias, rows_per_group=rows_per_group)
+        ctx.save_for_backward(x, W)
+        ctx.rpg = rows_per_group
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        gy = _rows(gy)
+        gx = gemm(gy, W, op_b=1) if ctx.needs_input_grad[0] else None
+        gW = _wgrad(gy, x) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _per_sample_colsum(gy.contiguous(), ctx.rpg)
+        return gx, gW, gb, None
+
+
+class VNLinearLeakyFn(Function):
+    """VNLinearLeakyReLU (models/vn_layers.py:46-74): p = W_f x -> BatchNorm over |p| -> leaky projection on d = W_d x.
+
+    ``bias`` [B*3, 2C] (feat | dir halves) carries the de-duplicated broadcast input channels."""
+
+    @staticmethod
+    def forward(ctx, x, Wf, Wd, gamma, beta, running_mean, running_var, bias, rows_per_group, training, ns):
+        x = _rows(x)
+        R = x.shape[0]
+        C = Wf.shape[0]
+        pd = torch.empty((R, 2 * C), device=x.device, dtype=torch.float32)
+        bf = bd = None
+        if bias is not None:
+            bias = _rows(bias)
+            bf, bd = bias[:, :C], bias[:, C:]
+        gemm(x, Wf, out=pd[:, :C], bias=bf, rows_per_group=rows_per_group, nsplit=1)
+        gemm(x, Wd, out=pd[:, C:], bias=bd, rows_per_group=rows_per_group, nsplit=1)
+        out, mean, rstd = _bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, running_mean, running_var, training, ns)
+        ctx.save_for_backward(x, Wf, Wd, gamma, beta, pd, mean, rstd)
+        ctx.cfg = (C, rows_per_group, training, ns, bias is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, Wf, Wd, gamma, beta, pd, mean, rstd = ctx.saved_tensors
+        C, rpg, training, ns, has_bias = ctx.cfg
+        gpd, ggamma, gbeta = _bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, ns)
+        gp, gd = gpd[:, :C], gpd[:, C:]
+        gx = gemm(gp, Wf, op_b=1, A2=gd, B2=Wd) if ctx.needs_input_grad[0] else None
+        gWf = _wgrad(gp, x) if ctx.needs_input_grad[1] else None
+        gWd = _wgrad(gd, x) if ctx.needs_input_grad[2] else None
+        gb = _per_sample_colsum(gpd, rpg) if (has_bias and ctx.needs_input_grad[7]) else None
+        return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None
+
+
+class VNBnLeakyFn(Function):
+    """BatchNorm-over-norms (+ optional leaky projection) on an existing [R, 2C] (p | d) or [R, C] (p) tensor.
+    VNBatchNorm (models/vn_layers.py:107-127) and the tail of VNLinearLeakyReLU (:66-73)."""
+
+    @staticmethod
+    def forward(ctx, pd, has_d, gamma, beta, running_mean, running_var, training, ns):
+        pd = _rows(pd)
+        C = pd.shape[1] // 2 if has_d else pd.shape[1]
+        p = pd[:, :C]
+        d = pd[:, C:] if has_d else None
+        out, mean, rstd = _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training, ns)
+        ctx.save_for_backward(pd, gamma, beta, mean, rstd)
+        ctx.cfg = (C, has_d, training, ns)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        pd, gamma, beta, mean, rstd = ctx.saved_tensors
+        C, has_d, training, ns = ctx.cfg
+        gpd, ggamma, gbeta = _bn_leaky_backward(go, pd[:, :C], pd[:, C:] if has_d else None, C, gamma, beta, mean, rstd,
+                                                training, ns)
+        return gpd, None, ggamma, gbeta, None, None, None, None
+
+
+class VNLeakyFn(Function):
+    """Leaky projection without BatchNorm: out = leaky(x, d) (models/vn_layers.py:37-42); returns grads for x and d."""
+
+    @staticmethod
+    def forward(ctx, x, d, ns):
+        x, d = _rows(x), _rows(d)
+        C = x.shape[1]
+        out, _, _ = _bn_leaky_forward(x, d, C, None, None, None, None, False, ns, use_bn=False)
+        ctx.save_for_backward(x, d)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, d = ctx.saved_tensors
+        C = x.shape[1]
+        gpd, _, _ = _bn_leaky_backward(go, x, d, C, None, None, None, None, False, ctx.ns, use_bn=False)
+        return gpd[:, :C], gpd[:, C:], None
+
+
+class VNMaxPoolFn(Function):
+    """VNMaxPool (models/vn_layers.py:153-167) over G groups of gs consecutive points.  W_d receives no gradient
+    (the arg-max detaches it in the reference as well)."""
+
+    @staticmethod
+    def forward(ctx, x, Wd, G, gs):
+        x = _rows(x)
+        C = x.shape[1]
+        d = gemm(x, Wd, nsplit=1)
+        nch = _nchunk(gs)
+        ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
+        ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
+        idx = torch.empty((G, C), device=x.device, dtype=torch.int32)
+        out = torch.empty((G * 3, C), device=x.device, dtype=torch.float32)
+        call("vnp_vn_pool_fwd", ptr(x), _ld(x), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        ctx.save_for_backward(idx)
+        ctx.cfg = (G, gs, C)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, _gidx):
+        (idx,) = ctx.saved_tensors
+        G, gs, C = ctx.cfg
+        gout = _rows(gout)
+        gx = torch.empty((G * gs * 3, C), device=gout.device, dtype=torch.float32)
+        call("vnp_vn_pool_bwd", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(gx), C)
+        return gx, None, None, None
+
+
+class VNMeanPoolFn(Function):
+    """mean_pool (models/vn_layers.py:170-171) over groups of gs consecutive points."""
+
+    @staticmethod
+    def forward(ctx, x, G, gs):
+        x = _rows(x)
+        C = x.shape[1]
+        out = torch.empty((G * 3, C), device=x.device, dtype=torch.float32)
+        call("vnp_vn_mean_pool_fwd", ptr(x), _ld(x), G, gs, C, ptr(out), C)
+        ctx.cfg = (G, gs, C)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        G, gs, C = ctx.cfg
+        gout = _rows(gout)
+        gx = torch.empty((G * gs * 3, C), device=gout.device, dtype=torch.float32)
+        call("vnp_vn_mean_pool_bwd", ptr(gout), _ld(gout), G, gs, C, ptr(gx), C)
+        return gx, None, None
+
+
+class FoldFn(Function):
+    """Rank-2 expansion of the first FoldingNet layer (models/pcn.py:375-387 with the broadcast channels de-duplicated):
+    pd[((b*Mc+mc)*S+s)*3+t, j] = bias[b*3+t, j] + wseed[j]*seed[(b), s, t] + wcoarse[j]*coarse[b, mc, t]."""
+
+    @staticmethod
+    def forward(ctx, bias, wseed, wcoarse, seed, coarse):
+        bias = _rows(bias)
+        B, Mc, _ = coarse.shape
+        coarse = coarse.contiguous()
+        seed = seed.contiguous()
+        S = seed.shape[-2]
+        if seed.dim() != 3 or seed.shape[0] not in (1, B) or seed.shape[2] != 3:
+            raise _lib.VnpError(f"fold: seed must be [1 or B, S, 3], got {tuple(seed.shape)}")
+        batched = 1 if seed.shape[0] == B else 0
+        W = bias.shape[1]
+        wseed, wcoarse = wseed.contiguous(), wcoarse.contiguous()
+        out = torch.empty((B * Mc * S * 3, W), device=bias.device, dtype=torch.float32)
+        call("vnp_fold_fwd", ptr(bias), _ld(bias), ptr(wseed), ptr(wcoarse), ptr(seed), batched, ptr(coarse), B, Mc, S, W,
+             ptr(out), W)
+        ctx.save_for_backward(wcoarse, seed, coarse)
+        ctx.cfg = (B, Mc, S, W, batched)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        wcoarse, seed, coarse = ctx.saved_tensors
+        B, Mc, S, W, batched = ctx.cfg
+        g = _rows(g)
+        dev = g.device
+        part = torch.empty((B * Mc, 5, W), device=dev, dtype=torch.float32)
+        call("vnp_fold_bwd", ptr(g), _ld(g), ptr(seed), batched, ptr(coarse), B, Mc, S, W, ptr(part))
+        gbias = torch.empty((B * 3, W), device=dev, dtype=torch.float32)
+        call("vnp_reduce_rows", ptr(part), B, Mc * 5 * W, Mc, 5 * W, 3 * W, ptr(gbias), 3 * W)
+        gws = torch.empty(W, device=dev, dtype=torch.float32)
+        gwc = torch.empty(W, device=dev, dtype=torch.float32)
+        call("vnp_reduce_rows", part.data_ptr() + 3 * W * 4, 1, 0, B * Mc, 5 * W, W, ptr(gws), W)
+        call("vnp_reduce_rows", part.data_ptr() + 4 * W * 4, 1, 0, B * Mc, 5 * W, W, ptr(gwc), W)
+        gcoarse = None
+        if ctx.needs_input_grad[4]:
+            R = B * Mc * S * 3
+            tmp = torch.empty(R, device=dev, dtype=torch.float32)
+            call("vnp_rowdot", ptr(g), _ld(g), ptr(wcoarse), R, W, None, 1, ptr(tmp))
+            gcoarse = torch.empty((B, Mc, 3), device=dev, dtype=torch.float32)
+            call("vnp_group_sum3", ptr(tmp), B * Mc, S, ptr(gcoarse), 0)
+        return gbias, gws, gwc, None, gcoarse
+
+
+class LinOutFn(Function):
+    """Final VNLinear(C -> 1) plus the residual point_feat (models/pcn.py:346,387):
+    fine[(b*Md+m)*3+t] = sum_c x[.., c] w[c] + coarse[b, m // S, t]."""
+
+    @staticmethod
+    def forward(ctx, x, w, coarse, S):
+        x = _rows(x)
+        R, C = x.shape
+        w = w.reshape(-1).contiguous()
+        coarse = coarse.contiguous()
+        out = torch.empty(R, device=x.device, dtype=torch.float32)
+        call("vnp_rowdot", ptr(x), _ld(x), ptr(w), R, C, ptr(coarse), S, ptr(out))
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (S, tuple(coarse.shape))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        S, cshape = ctx.cfg
+        R, C = x.shape
+        g = g.contiguous()
+        dev = g.device
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((R, C), device=dev, dtype=torch.float32)
+            call("vnp_outer", ptr(g), ptr(w), R, C, ptr(gx), C)
+        nch = _nchunk(R)
+        part = torch.empty((nch, C), device=dev, dtype=torch.float32)
+        call("vnp_colsum", ptr(x), 0, _ld(x), 1, R, C, ptr(g), ptr(part))
+        gw = torch.empty((1, C), device=dev, dtype=torch.float32)
+        call("vnp_reduce_rows", ptr(part), 1, 0, nch, C, C, ptr(gw), C)
+        gcoarse = torch.empty(cshape, device=dev, dtype=torch.float32)
+        call("vnp_group_sum3", ptr(g), R // 3 // S, S, ptr(gcoarse), 0)
+        return gx, gw, gcoarse, None
+
+
+class ChamferFn(Function):
+    """chamfer_3DFunction (extensions/chamfer_distance/chamfer_distance.py:29-71) on libvnpcc."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        _lib.require_gpu(xyz1, xyz2)
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        dev = xyz1.device
+        dist1 = torch.empty((B, n), device=dev, dtype=torch.float32)
+        dist2 = torch.empty((B, m), device=dev, dtype=torch.float32)
+        idx1 = torch.empty((B, n), device=dev, dtype=torch.int32)
+        idx2 = torch.empty((B, m), device=dev, dtype=torch.int32)
+        ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
+        call("vnp_chamfer_fwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, dist2, idx1, idx2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g1, g2, _gi1, _gi2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        gx1 = torch.empty_like(xyz1)
+        gx2 = torch.empty_like(xyz2)
+        call("vnp_chamfer_bwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(g1), ptr(idx1), ptr(g2), ptr(idx2), ptr(gx1), ptr(gx2))
+        return gx1, gx2

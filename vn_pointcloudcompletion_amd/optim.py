@@ -1,0 +1,124 @@
+"""Flat parameter / gradient buffers and the fused Adam step.
+
+The reference trains with ``torch.optim.Adam(model.parameters(), lr, betas=(0.9, 0.999))`` (train.py:70).  Here every
+trainable parameter, its gradient and both Adam moments are views into four flat fp32 buffers, so that
+  * the optimizer step is ONE HBM-bound kernel (``vnp_adam_step``) instead of ~25 small launches, and
+  * the data-parallel gradient exchange is ONE RCCL all-reduce over the flat gradient buffer (distributed.py).
+``FusedAdam`` is a ``torch.optim.Optimizer``: ``state_dict()`` / ``load_state_dict()`` keep torch-Adam's format
+(``state[i] = {step, exp_avg, exp_avg_sq}``), so the reference's ``optim_{last,best}.pth`` files round-trip
+(train.py:255-277), and ``StepLR`` works unchanged (train.py:93).
+Parameters that never receive a gradient (``maxpool*.map_to_dir``) keep a zero gradient slice and are
+therefore never moved, exactly as torch's Adam skips ``grad is None`` parameters.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_ALIGN = 4  # elements: keeps every slice 16-byte aligned for the float4 kernels
+
+
+class FlatBuffers:
+    """Re-homes ``params`` (and their ``.grad``) into one flat parameter buffer and one flat gradient buffer."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError("all parameters must be fp32 on one device")
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = off
+        self.flat_param = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                self.flat_param[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def view(self, flat, i):
+        p, o = self.params[i], self.offsets[i]
+        return flat[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for i, p in enumerate(self.params):          # re-attach views a caller may have dropped (set_to_none=True)
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + self.offsets[i] * 4:
+                p.grad = self.view(self.flat_grad, i)
+
+    def check_views(self):
+        """Gradients produced by autograd must have been accumulated IN PLACE into the flat buffer."""
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                p.grad = self.view(self.flat_grad, i)
+            elif p.grad.data_ptr() != self.flat_grad.data_ptr() + self.offsets[i] * 4:
+                self.view(self.flat_grad, i).copy_(p.grad)
+                p.grad = self.view(self.flat_grad, i)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._flat = []
+        for group in self.param_groups:
+            fb = FlatBuffers(group["params"])
+            fb.exp_avg = torch.zeros_like(fb.flat_param)
+            fb.exp_avg_sq = torch.zeros_like(fb.flat_param)
+            fb.step = 0
+            self._flat.append(fb)
+
+    @property
+    def flat_buffers(self):
+        return self._flat
+
+    def zero_grad(self, set_to_none: bool = True):
+        for fb in self._flat:
+            fb.zero_grad()
+
+    def _publish_state(self, fb):
+        for i, p in enumerate(fb.params):
+            self.state[p] = {"step": torch.tensor(float(fb.step)), "exp_avg": fb.view(fb.exp_avg, i),
+                             "exp_avg_sq": fb.view(fb.exp_avg_sq, i)}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group, fb in zip(self.param_groups, self._flat):
+            fb.check_views()
+            fb.step += 1
+            b1, b2 = group["betas"]
+            _lib.call("vnp_adam_step", fb.flat_param.data_ptr(), fb.flat_grad.data_ptr(), fb.exp_avg.data_ptr(),
+                      fb.exp_avg_sq.data_ptr(), fb.numel, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                      fb.step, float(group["weight_decay"]))
+        return loss
+
+    def state_dict(self):
+        for fb in self._flat:
+            self._publish_state(fb)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for fb in self._flat:
+                steps = []
+                for i, p in enumerate(fb.params):
+                    st = self.state.get(p)
+                    if st:                                   # torch's Adam has no state for grad-is-None parameters
+                        fb.view(fb.exp_avg, i).copy_(st["exp_avg"])
+                        fb.view(fb.exp_avg_sq, i).copy_(st["exp_avg_sq"])
+                        steps.append(int(float(st["step"])))
+                fb.step = max(steps) if steps else 0
+                self._publish_state(fb)

@@ -1,0 +1,135 @@
+"""VN-PointNet encoder and VN-FoldingNet decoder with the reference's class names, constructor signatures and
+``state_dict`` keys (/root/reference/models/pcn.py:110-184, 319-389), chained on the rows layout so that the whole
+forward/backward runs in libvnpcc kernels.
+
+Two algebraic de-duplications remove the reference's broadcast tensors:
+  * encoder ``second_conv[0]`` acts on cat([global.expand(N), feature]) (pcn.py:172): the global half becomes a
+    per-sample bias  W[:, :512] g  and only the 512 per-point channels go through the big GEMM;
+  * decoder ``final_conv[0]`` acts on cat([global.expand(Md), seed, point_feat]) (pcn.py:385, 12.9 GB at B=32):
+    W[:, :latent] g is a per-sample bias and the two remaining channels a rank-2 per-point term (ops.FoldFn).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .vn_layers import VNLinear, VNLinearAndLeakyReLU, VNLinearLeakyReLU, VNMaxPool
+
+
+def global_to_rows(feature_global):
+    """reference [B, C, 3, 1] -> rows [B*3, C]."""
+    B, C = feature_global.shape[0], feature_global.shape[1]
+    return feature_global.reshape(B, C, 3).permute(0, 2, 1).reshape(B * 3, C).contiguous()
+
+
+def rows_to_global(rows, B):
+    """rows [B*3, C] -> reference [B, C, 3, 1]."""
+    C = rows.shape[1]
+    return rows.reshape(B, 3, C).permute(0, 2, 1).unsqueeze(-1)
+
+
+def fps(pc, num):
+    """models/pcn.py:6-9 — furthest point sampling of a cloud (used only when num_coarse == 448)."""
+    from .sampling import furthest_point_sample, gather_points
+    idx = furthest_point_sample(pc, num)
+    return gather_points(pc, idx)
+
+
+class VN_PointNet(nn.Module):
+    """models/pcn.py:110-184."""
+
+    def __init__(self, config, num_dense=16384, latent_dim=1024):
+        super().__init__()
+        self.num_dense = num_dense
+        self.latent_dim = latent_dim
+        self.num_coarse = config.num_coarse // 2 if config.num_coarse == 448 else config.num_coarse
+        self.first_conv = nn.Sequential(VNLinearLeakyReLU(1, 128, dim=4), VNLinear(128, 512))
+        self.maxpool1 = VNMaxPool(512)
+        self.second_conv = nn.Sequential(VNLinearLeakyReLU(1024, 1024, dim=4), VNLinear(1024, self.latent_dim * 2))
+        self.maxpool2 = VNMaxPool(self.latent_dim * 2)
+        self.mlp = nn.Sequential(
+            VNLinearAndLeakyReLU(self.latent_dim * 2, 1024 * 2, dim=4, use_batchnorm="none"),
+            VNLinearAndLeakyReLU(1024 * 2, 1024, dim=4, use_batchnorm="none"),
+            VNLinear(1024, self.num_coarse),
+        )
+
+    def forward(self, xyz):
+        B, N, _ = xyz.shape
+        x = xyz.contiguous().float().reshape(B * N * 3, 1)                       # rows layout with C = 1 IS xyz
+        f = self.first_conv[0].forward_rows(x)
+        f = self.first_conv[1].forward_rows(f)                                  # [B*N*3, 512]
+        g1 = self.maxpool1.forward_rows(f, B, N)                                # [B*3, 512]
+        f = self.second_conv[0].forward_rows(f, global_rows=g1, rows_per_group=N * 3)
+        f = self.second_conv[1].forward_rows(f)                                 # [B*N*3, 2*latent]
+        g2 = self.maxpool2.forward_rows(f, B, N)                                # [B*3, 2*latent]
+        h = self.mlp[0].forward_rows(g2)
+        h = self.mlp[1].forward_rows(h)
+        h = self.mlp[2].forward_rows(h)                                         # [B*3, Mc]
+        coarse = h.reshape(B, 3, self.num_coarse).permute(0, 2, 1).contiguous()  # == [B,Mc,3,1].reshape(-1,Mc,3), pcn.py:177
+        feature_global = rows_to_global(g2, B)
+        if self.num_coarse == 224:
+            inp_sparse = fps(xyz.contiguous(), 224)
+            coarse_cat = torch.cat([coarse, inp_sparse], dim=1).contiguous()
+            return (coarse, coarse_cat), feature_global
+        return coarse, feature_global
+
+
+class VN_FoldingNet(nn.Module):
+    """models/pcn.py:319-389."""
+
+    def __init__(self, config, grid_size=4):
+        super().__init__()
+        self.latent_dim = config.latent_dim
+        if config.num_coarse == 448:
+            self.num_coarse = config.num_coarse // 2
+            self.num_dense = 14336
+            self.grid_size = 8
+        else:
+            self.num_coarse = config.num_coarse
+            self.num_dense = 16384
+            self.grid_size = 4
+        self.final_conv = nn.Sequential(
+            VNLinearLeakyReLU(self.latent_dim + 1 + 1, 256, dim=4),
+            VNLinearLeakyReLU(256, 256, dim=4),
+            VNLinear(256, 1),
+        )
+        g = self.grid_size
+        lin = torch.linspace(-0.05, 0.05, steps=g, dtype=torch.float)
+        a = lin.view(1, g).expand(g, g).reshape(1, -1)
+        b = lin.view(g, 1).expand(g, g).reshape(1, -1)
+        c = torch.zeros_like(a)
+        # plain attribute (not a buffer), as in the reference (pcn.py:362): it must not appear in the state_dict
+        self.folding_seed = torch.cat([a, b, c], dim=0).reshape(1, 1, 3, -1)
+
+    def forward(self, coarse, feature_global, rot=None):
+        B, Mc, _ = coarse.shape
+        S = self.grid_size ** 2
+        if Mc * S != self.num_dense:
+            # the reference hard-codes num_dense (pcn.py:332) and its reshape would fail here; callers running other
+            # sizes set decoder.num_dense after construction — accept that as well.
+            raise RuntimeError(f"VN_FoldingNet: num_coarse*grid^2 = {Mc * S} != num_dense = {self.num_dense}")
+        dev = coarse.device
+        if self.folding_seed.device != dev:
+            self.folding_seed = self.folding_seed.to(dev)
+        seed = self.folding_seed.squeeze(1).transpose(1, 2)                     # [1, S, 3]
+        if rot is not None:
+            seed = rot.transform_points(seed)                                   # [B, S, 3]  (pcn.py:367-370)
+        seed = seed.contiguous().float()
+        l0 = self.final_conv[0]
+        latent = feature_global.shape[1]
+        g_rows = global_to_rows(feature_global.float())
+        Wf, Wd = l0.map_to_feat.weight, l0.map_to_dir.weight
+        bias = torch.cat([ops.VNLinearFn.apply(g_rows, Wf[:, :latent], None, 0),
+                          ops.VNLinearFn.apply(g_rows, Wd[:, :latent], None, 0)], dim=1)        # [B*3, 512]
+        wseed = torch.cat([Wf[:, latent], Wd[:, latent]])
+        wcoarse = torch.cat([Wf[:, latent + 1], Wd[:, latent + 1]])
+        coarse = coarse.contiguous().float()
+        pd = ops.FoldFn.apply(bias, wseed, wcoarse, seed, coarse)               # [B*Md*3, 512] = (p | d) of layer 0
+        bn = l0.batchnorm.bn
+        l0.batchnorm._tick()
+        f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                                  l0.negative_slope)
+        f = self.final_conv[1].forward_rows(f)
+        fine = ops.LinOutFn.apply(f, self.final_conv[2].map_to_feat.weight, coarse, S)          # [B*Md*3]
+        return fine.reshape(B, Mc * S, 3)

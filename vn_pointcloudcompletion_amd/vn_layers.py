@@ -1,0 +1,189 @@
+"""Vector-Neuron layer classes with the reference's names, constructor signatures and ``state_dict`` keys
+(/root/reference/models/vn_layers.py), running on the HIP kernels of libvnpcc.
+
+Every class has two entry points:
+  * ``forward(x)`` takes / returns the reference layout ``[B, C, 3, N]`` or ``[B, C, 3, N, K]`` and is what a
+    user of the reference calls;
+  * ``forward_rows(rows, ...)`` takes / returns the internal rows layout ``[P*3, C]`` (see ops.py) and is what
+    the networks in pcn.py chain, so that no layout conversion happens between layers.
+Parameters are held by ``nn.Linear(bias=False)`` / ``nn.BatchNorm*`` members exactly as in the reference, which
+keeps the ``state_dict`` keys and the default-init RNG stream identical (same seed -> same weights).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+EPS = 1e-6
+
+
+def to_rows(x):
+    """[B, C, 3, N(, K)] -> (rows [(B*N*K)*3, C], meta)."""
+    shape = tuple(x.shape)
+    B, C = shape[0], shape[1]
+    if len(shape) < 4 or shape[2] != 3:
+        raise ValueError(f"VN tensor [B, C, 3, N, ...] expected, got {shape}")
+    nflat = 1
+    for s in shape[3:]:
+        nflat *= s
+    rows = ops.ToRowsFn.apply(x.reshape(B, C, 3, nflat).float())
+    return rows, (B, shape[3:], nflat)
+
+
+def from_rows(rows, meta):
+    B, tail, nflat = meta
+    y = ops.FromRowsFn.apply(rows, B, nflat)
+    return y.reshape(B, rows.shape[1], 3, *tail)
+
+
+class VNLinear(nn.Module):
+    """models/vn_layers.py:12-22."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward_rows(self, rows, bias=None, rows_per_group=0):
+        return ops.VNLinearFn.apply(rows, self.map_to_feat.weight, bias, rows_per_group)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        return from_rows(self.forward_rows(rows), meta)
+
+
+class VNLeakyReLU(nn.Module):
+    """models/vn_layers.py:25-43."""
+
+    def __init__(self, in_channels, share_nonlinearity=False, negative_slope=0.2):
+        super().__init__()
+        self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else in_channels, bias=False)
+        self.share_nonlinearity = share_nonlinearity
+        self.negative_slope = negative_slope
+
+    def forward_rows(self, rows):
+        d = ops.VNLinearFn.apply(rows, self.map_to_dir.weight, None, 0)
+        if self.share_nonlinearity:
+            d = d.expand(-1, rows.shape[1]).contiguous()
+        return ops.VNLeakyFn.apply(rows, d, self.negative_slope)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        return from_rows(self.forward_rows(rows), meta)
+
+
+class VNBatchNorm(nn.Module):
+    """models/vn_layers.py:107-127."""
+
+    def __init__(self, num_features, dim):
+        super().__init__()
+        self.dim = dim
+        if dim == 3 or dim == 4:
+            self.bn = nn.BatchNorm1d(num_features)
+        elif dim == 5:
+            self.bn = nn.BatchNorm2d(num_features)
+
+    def _tick(self):
+        if self.training and self.bn.track_running_stats and self.bn.num_batches_tracked is not None:
+            self.bn.num_batches_tracked.add_(1)
+
+    def forward_rows(self, rows):
+        self._tick()
+        return ops.VNBnLeakyFn.apply(rows, False, self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var,
+                                     self.training, 0.0)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        return from_rows(self.forward_rows(rows), meta)
+
+
+class VNLinearLeakyReLU(nn.Module):
+    """models/vn_layers.py:46-74 (direction computed from the layer input)."""
+
+    def __init__(self, in_channels, out_channels, dim=5, share_nonlinearity=False, negative_slope=0.2):
+        super().__init__()
+        self.dim = dim
+        self.negative_slope = negative_slope
+        self.share_nonlinearity = share_nonlinearity
+        self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
+        self.batchnorm = VNBatchNorm(out_channels, dim=dim)
+        self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
+
+    def forward_rows(self, rows, global_rows=None, rows_per_group=0):
+        """``global_rows`` [B*3, Cg]: per-sample features standing for the first Cg input channels, i.e. the layer acts
+        on cat([global.expand(N), x], dim=1) (models/pcn.py:172) without materialising the broadcast."""
+        if self.share_nonlinearity:
+            raise NotImplementedError("share_nonlinearity=True is not used on the PCNNet paths")
+        bn = self.batchnorm.bn
+        self.batchnorm._tick()
+        Wf, Wd = self.map_to_feat.weight, self.map_to_dir.weight
+        bias = None
+        if global_rows is not None:
+            cg = global_rows.shape[1]
+            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wf[:, :cg], None, 0),
+                              ops.VNLinearFn.apply(global_rows, Wd[:, :cg], None, 0)], dim=1)
+            Wf, Wd = Wf[:, cg:], Wd[:, cg:]
+        return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
+                                         rows_per_group, self.training, self.negative_slope)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        return from_rows(self.forward_rows(rows), meta)
+
+
+class VNLinearAndLeakyReLU(nn.Module):
+    """models/vn_layers.py:77-104 (direction computed from the linear output)."""
+
+    def __init__(self, in_channels, out_channels, dim=5, share_nonlinearity=False, use_batchnorm="norm", negative_slope=0.2):
+        super().__init__()
+        self.dim = dim
+        self.share_nonlinearity = share_nonlinearity
+        self.use_batchnorm = use_batchnorm
+        self.negative_slope = negative_slope
+        self.linear = VNLinear(in_channels, out_channels)
+        self.leaky_relu = VNLeakyReLU(out_channels, share_nonlinearity=share_nonlinearity, negative_slope=negative_slope)
+        if use_batchnorm != "none":
+            self.batchnorm = VNBatchNorm(out_channels, dim=dim)
+
+    def forward_rows(self, rows):
+        y = self.linear.forward_rows(rows)
+        if self.use_batchnorm != "none":
+            y = self.batchnorm.forward_rows(y)
+        return self.leaky_relu.forward_rows(y)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        return from_rows(self.forward_rows(rows), meta)
+
+
+class VNMaxPool(nn.Module):
+    """models/vn_layers.py:153-167: arg-max over the LAST axis of the reference tensor."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.map_to_dir = nn.Linear(in_channels, in_channels, bias=False)
+
+    def forward_rows(self, rows, groups, group_size, return_index=False):
+        out, idx = ops.VNMaxPoolFn.apply(rows, self.map_to_dir.weight.detach(), groups, group_size)
+        return (out, idx) if return_index else out
+
+    def forward(self, x):
+        rows, (B, tail, nflat) = to_rows(x)
+        gs = tail[-1]
+        G = B * nflat // gs
+        out = self.forward_rows(rows, G, gs)                     # [G*3, C]
+        y = ops.FromRowsFn.apply(out, B, G // B)                  # [B, C, 3, G/B]
+        return y.reshape(B, rows.shape[1], 3, *tail[:-1])
+
+
+def mean_pool(x, dim=-1, keepdim=False):
+    """models/vn_layers.py:170-171 (reference layout; used on the neighbour axis)."""
+    if dim in (-1, x.dim() - 1) and not keepdim and x.dim() >= 5 and x.is_cuda:
+        rows, (B, tail, nflat) = to_rows(x)
+        gs = tail[-1]
+        G = B * nflat // gs
+        out = ops.VNMeanPoolFn.apply(rows, G, gs)
+        y = ops.FromRowsFn.apply(out, B, G // B)
+        return y.reshape(B, rows.shape[1], 3, *tail[:-1])
+    return x.mean(dim=dim, keepdim=keepdim)
