@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one full training step (forward, 2x Chamfer-L1, backward, gradient all-reduce, Adam)
+of vn_pointnet + vn_foldingnet on synthetic (B,2048,3) -> (B,16384,3) clouds, fp32, B = 32 per GPU (BASELINE config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the dominant kernel, the fp32-MFMA GEMM,
+timed per launch with HIP events on its launch stream) and `cpu_baseline` (the torch-CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+METRIC = "completed points/sec/GPU + Chamfer-L1, 2048→16384, B=32, 1/2/4/8 MI355X"
+
+
+def cpu_baseline(threads):
+    """The torch-CPU oracle (reference-as-written formulation) on a bounded sample of the same workload: ONE cloud
+    (B=1) at full size, 2048 -> 1024 -> 16384, forward + 2x Chamfer-L1 + backward (no optimizer), best of 2."""
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd.model import PCNNet
+    torch.set_num_threads(threads)
+    cfg = SimpleNamespace(num_coarse=1024, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cpu")
+    torch.manual_seed(0)
+    net = PCNNet(cfg, "vn_pointnet", "vn_foldingnet")          # parameter container only: never run on the CPU
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    p = torch.rand(1, 2048, 3, generator=g) - 0.5
+    c = torch.rand(1, 16384, 3, generator=g) - 0.5
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        coarse, fine, _ = O.pcnnet_forward(sd, p, None, True)
+        d1, d2, _, _ = O.chamfer_torch(coarse, c)
+        e1, e2, _, _ = O.chamfer_torch(fine, c)
+        loss = O.cd_loss_l1(d1, d2) + O.cd_loss_l1(e1, e2)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        for v in sd.values():
+            v.grad = None
+    return {"value": 16384.0 / best, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"torch-CPU oracle, B=1 of the B=32 step, 2048->1024->16384, fwd+2xCD-L1+bwd, best of 2, {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--num-coarse", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from vn_pointcloudcompletion_amd import _lib, ops
+    from vn_pointcloudcompletion_amd import distributed as D
+    from vn_pointcloudcompletion_amd.model import PCNNet
+    from vn_pointcloudcompletion_amd.optim import FusedAdam
+    from vn_pointcloudcompletion_amd.train import train_step
+
+    rank, local_rank, world = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+    _lib.lib()
+
+    B, N, Mc = args.batch, 2048, args.num_coarse
+    Md = Mc * 16
+    cfg = SimpleNamespace(num_coarse=Mc, latent_dim=2048, only_coarse=False, enc_pretrained="none", device=device,
+                          coarse_loss="cd", dcd_opts={"alpha": 200, "lambda": 0.5})
+    torch.manual_seed(0)
+    model = PCNNet(cfg, "vn_pointnet", "vn_foldingnet")
+    model.decoder.num_dense = Md
+    model.train()
+    D.broadcast_model(model)
+    opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    g = torch.Generator().manual_seed(1234 + rank)
+    p = (torch.rand(B, N, 3, generator=g) - 0.5).to(device)
+    c = (torch.rand(B, Md, 3, generator=g) - 0.5).to(device)
+
+    for _ in range(args.warmup):
+        train_step(cfg, model, opt, p, c)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    prof = []
+    ops.GEMM_PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, loss1, loss2 = train_step(cfg, model, opt, p, c)
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    elapsed = D.allreduce_scalar_max(elapsed)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * Md * args.steps / elapsed
+        # dominant kernel: vnp_gemm_kernel (fp32 MFMA); per-variant algorithmic FLOP / s from the per-launch HIP events
+        agg = {}
+        for variant, flops, nsplit, shape, e0, e1 in prof:
+            a = agg.setdefault(variant, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        tot_f = sum(a[0] for a in agg.values())
+        tot_t = sum(a[1] for a in agg.values())
+        nlaunch = sum(a[2] for a in agg.values())
+        achieved = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "vnp_gemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": nlaunch // max(args.steps, 1),
+                    "flop_per_launch": tot_f / max(nlaunch, 1), "avg_launch_ms": tot_t / max(nlaunch, 1) * 1e3,
+                    "gemm_ms_per_step": tot_t / args.steps * 1e3,
+                    "by_variant": {k: {"tflops": round(a[0] / a[1] / 1e12, 2), "ms_per_step": round(a[1] / args.steps * 1e3, 3),
+                                       "launches_per_step": a[2] // max(args.steps, 1)} for k, a in agg.items() if a[1] > 0}}
+        out = {"metric": METRIC, "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"vn_pointnet+vn_foldingnet train step (fwd+2xCD-L1+bwd+allreduce+Adam), B={B}/GPU, "
+                                      f"{N}->{Mc}->{Md} pts, fp32", "global_batch": B * world, "parallelism": f"dp{world}"},
+               "points_per_s_per_gpu": value / world,
+               "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))      # the GPU box gives 16 cores per GPU
+            except Exception as e:                                  # the baseline must never hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(out))
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

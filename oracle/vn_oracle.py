@@ -191,16 +191,26 @@ def pcnnet_forward(sd, xyz, rot_R=None, training=True, new_stats=None):
 
 
 # --------------------------------------------------------------------------- losses
-def chamfer_torch(a, b):
-    """Direct-form squared NN distances (same formula as chamfer3D.cu:33-36) in torch, per sample,
-    differentiable.  Returns dist1[B,n], dist2[B,m], idx1, idx2 (int32; first minimum wins)."""
+def chamfer_torch(a, b, chunk=1024):
+    """Direct-form squared NN distances (same formula as chamfer3D.cu:33-36) in torch, per sample and in row chunks
+    (bounded memory), differentiable.  Returns dist1[B,n], dist2[B,m], idx1, idx2 (int32; first minimum wins)."""
     d1, d2, i1, i2 = [], [], [], []
     for x, y in zip(a, b):
-        diff = x[:, None, :] - y[None, :, :]
-        P = (diff * diff).sum(-1)
-        v1, j1 = P.min(1)
-        v2, j2 = P.min(0)
-        d1.append(v1), d2.append(v2), i1.append(j1.int()), i2.append(j2.int())
+        v1, j1, colmin, colidx = [], [], None, None
+        for s in range(0, x.shape[0], chunk):
+            diff = x[s:s + chunk, None, :] - y[None, :, :]
+            P = (diff * diff).sum(-1)
+            v, j = P.min(1)
+            v1.append(v), j1.append(j)
+            cv, cj = P.min(0)
+            cj = cj + s
+            if colmin is None:
+                colmin, colidx = cv, cj
+            else:
+                better = cv < colmin                      # strict: the earlier chunk keeps ties (first minimum)
+                colmin = torch.where(better, cv, colmin)
+                colidx = torch.where(better, cj, colidx)
+        d1.append(torch.cat(v1)), i1.append(torch.cat(j1).int()), d2.append(colmin), i2.append(colidx.int())
     return torch.stack(d1), torch.stack(d2), torch.stack(i1), torch.stack(i2)
 
 

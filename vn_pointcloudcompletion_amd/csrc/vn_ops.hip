@@ -6,7 +6,7 @@
 // channels of a row (256 contiguous bytes) for each of the 3 Cartesian components.
 #include "vnp_common.h"
 
-#define VNP_CHUNK 256          // points per block in the chunked reductions (also exported via vnp_chunk_points)
+#define VNP_CHUNK 1024         // points (rows) per block in the chunked kernels (also exported via vnp_chunk_points)
 
 extern "C" int vnp_chunk_points() { return VNP_CHUNK; }
 
@@ -62,19 +62,30 @@ __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __rest
 
 // mean / rstd per channel from the chunk partials (Chan merge in double), running-stat update as torch does
 // (momentum, unbiased variance for running_var).
-__global__ void vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int C, long long count,
-                                       float* __restrict__ mean, float* __restrict__ rstd,
-                                       float* running_mean, float* running_var, float momentum, float eps)
+__global__ void __launch_bounds__(256) vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int C, long long count,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             float* running_mean, float* running_var, float momentum, float eps)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double rn[4][64], rm[4][64], rM[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     double na = 0.0, ma = 0.0, Ma = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        const float2 v = partial[(size_t)k * C + c];
-        const long long left = count - (long long)k * VNP_CHUNK;
-        const double nb = (double)(left < VNP_CHUNK ? left : VNP_CHUNK);
-        if (na == 0.0) { na = nb; ma = v.x; Ma = v.y; }
-        else vnp_chan_merge(na, ma, Ma, nb, (double)v.x, (double)v.y);
+    if (c < C) {
+        for (int k = py; k < nchunk; k += 4) {
+            const float2 v = partial[(size_t)k * C + c];
+            const long long left = count - (long long)k * VNP_CHUNK;
+            const double nb = (double)(left < VNP_CHUNK ? left : VNP_CHUNK);
+            if (na == 0.0) { na = nb; ma = v.x; Ma = v.y; }
+            else vnp_chan_merge(na, ma, Ma, nb, (double)v.x, (double)v.y);
+        }
+    }
+    rn[py][cx] = na; rm[py][cx] = ma; rM[py][cx] = Ma;
+    __syncthreads();
+    if (py != 0 || c >= C) return;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        if (na == 0.0) { na = rn[j][cx]; ma = rm[j][cx]; Ma = rM[j][cx]; }
+        else vnp_chan_merge(na, ma, Ma, rn[j][cx], rm[j][cx], rM[j][cx]);
     }
     const double m = ma;
     double var = Ma / (double)count;
@@ -242,15 +253,21 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
 }
 
 // out[b][j] = sum_{i<n} in[b*batch_stride + i*stride + j]   (double accumulation; small finalisation reductions)
-__global__ void vnp_reduce_rows_kernel(const float* __restrict__ in, long long batch_stride, int n, long long stride, int W,
-                                       float* __restrict__ out, long long out_stride)
+// block = 64 columns x 4 row lanes, grid (ceil(W/64), nb)
+__global__ void __launch_bounds__(256) vnp_reduce_rows_kernel(const float* __restrict__ in, long long batch_stride, int n, long long stride, int W,
+                                                             float* __restrict__ out, long long out_stride)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= W) return;
-    const float* src = in + (size_t)blockIdx.y * batch_stride + j;
+    __shared__ double red[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cx;
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += src[(size_t)i * stride];
-    out[(size_t)blockIdx.y * out_stride + j] = (float)s;
+    if (j < W) {
+        const float* src = in + (size_t)blockIdx.y * batch_stride + j;
+        for (int i = py; i < n; i += 4) s += src[(size_t)i * stride];
+    }
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && j < W) out[(size_t)blockIdx.y * out_stride + j] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
@@ -501,7 +518,7 @@ extern "C" int vnp_vn_bn_finalize(hipStream_t st, const float* partial, int nchu
                                   float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps)
 {
     if (!partial || !mean || !rstd || C <= 0 || count <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(64), 0, st, (const float2*)partial, nchunk, C, count,
+    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(256), 0, st, (const float2*)partial, nchunk, C, count,
                        mean, rstd, running_mean, running_var, momentum, eps);
     return vnp_last_error();
 }
@@ -553,7 +570,7 @@ extern "C" int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long lon
                                float* out, long long out_stride)
 {
     if (!in || !out || nb <= 0 || n <= 0 || W <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(W, 64), nb), dim3(64), 0, st, in, batch_stride, n, stride, W, out, out_stride);
+    hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(W, 64), nb), dim3(256), 0, st, in, batch_stride, n, stride, W, out, out_stride);
     return vnp_last_error();
 }
 

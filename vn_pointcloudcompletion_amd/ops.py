@@ -17,6 +17,10 @@ from ._lib import call, ptr
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
+# entries are (variant, flops, start_event, end_event)
+GEMM_PROFILE = None
+
 
 # ------------------------------------------------------------------------------------------ helpers
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -69,9 +73,17 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, A2=None, B2=None, bias=None, rows_pe
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit, M, N), device=A.device, dtype=torch.float32)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
          ptr(A2), _ld(A2) if A2 is not None else 0, ptr(B2), _ld(B2) if B2 is not None else 0, K2,
          ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))
+    if prof is not None:
+        e1.record()
+        prof.append(("NT" if (op_a, op_b) == (0, 0) else "NN" if (op_a, op_b) == (0, 1) else "TN" if (op_a, op_b) == (1, 1) else "TT",
+                     2.0 * M * N * (K + K2), nsplit, (M, N, K + K2), e0, e1))
     return out
 
 

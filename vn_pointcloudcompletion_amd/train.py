@@ -1,0 +1,192 @@
+"""Training loop with the reference's semantics (/root/reference/train.py:45-279) on the HIP path, plus the
+data-parallel step the reference lacks (one process per GPU, RCCL gradient all-reduce; distributed.py).
+
+Differences from the reference, all on purpose:
+  * ``FusedAdam`` (flat buffers, one kernel) instead of torch.optim.Adam — same update rule and state_dict format;
+  * losses are accumulated on the device and read back once per logging interval instead of 6 ``.item()`` syncs per
+    iteration (train.py:168,175-176,184-186);
+  * scalars go to ``<exp_dir>/{train,val}/scalars.jsonl`` (tensorboardX is not required); the per-epoch PNG
+    (visualization/, matplotlib) is not produced;
+  * under torch.distributed every rank trains on its shard of each batch, rank 0 logs / validates / checkpoints.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from copy import deepcopy
+
+import torch
+from torch.utils.data.dataloader import DataLoader
+
+from . import distributed as D
+from .dataset import make_dataset
+from .experiments import ScalarWriter, get_num_params_total
+from .loss import calc_dcd, cd_loss_L1, emd_loss
+from .metric import l1_cd
+from .model import PCNNet
+from .optim import FusedAdam
+from .transforms import Rotate, RotateAxisAngle, random_rotations
+
+log = logging.getLogger("train")
+log_dataset = logging.getLogger("dataset")
+
+
+def make_rotation(kind, batch, device):
+    """train.py:130-134."""
+    if kind == "z":
+        return RotateAxisAngle(angle=torch.rand(batch) * 360, axis="Z", degrees=True).to(device)
+    if kind == "so3":
+        return Rotate(R=random_rotations(batch)).to(device)
+    return None
+
+
+def compute_losses(config, coarse_pred, dense_pred, c):
+    """train.py:146-167: returns (loss, loss1, loss2)."""
+    if config.coarse_loss == "cd":
+        loss1 = cd_loss_L1(coarse_pred, c)
+    elif config.coarse_loss == "emd":
+        loss1 = emd_loss(coarse_pred, c[:, :1024, :])
+    elif config.coarse_loss == "dcd":
+        opts = config.dcd_opts
+        t_alpha = opts["alpha"] if isinstance(opts, dict) else opts.alpha
+        n_lambda = opts["lambda"] if isinstance(opts, dict) else getattr(opts, "lambda")
+        loss1, _, _ = calc_dcd(coarse_pred, c, alpha=t_alpha, n_lambda=n_lambda)
+        loss1 = loss1.mean()
+    else:
+        raise ValueError("Not implemented loss {}".format(config.coarse_loss))
+    if config.only_coarse:
+        return loss1, loss1, torch.zeros((), device=loss1.device)
+    loss2 = cd_loss_L1(dense_pred, c)
+    return loss1 + loss2, loss1, loss2
+
+
+def train_step(config, model, optimizer, p, c, trot=None):
+    """One iteration of the hot loop (train.py:140-173): zero_grad, forward, losses, backward, gradient all-reduce
+    (world > 1), Adam.  Returns the three loss tensors (on device, no host sync)."""
+    optimizer.zero_grad()
+    coarse_pred, dense_pred = model(p, trot)
+    loss, loss1, loss2 = compute_losses(config, coarse_pred, dense_pred, c)
+    loss.backward()
+    D.allreduce_gradients(optimizer)
+    optimizer.step()
+    return loss.detach(), loss1.detach(), loss2.detach()
+
+
+def train(config, args):
+    rank, world = D.get_rank(), D.world_size()
+    is_main = rank == 0
+    model_dir = os.path.join(config.exp_dir, "models")
+    optim_dir = os.path.join(config.exp_dir, "optimizer")
+    train_writer = ScalarWriter(os.path.join(config.exp_dir, "train")) if is_main else None
+    val_writer = ScalarWriter(os.path.join(config.exp_dir, "val")) if is_main else None
+
+    log_dataset.info("Loading Data...")
+    train_dataset = make_dataset(config, "train", config.category)
+    val_dataset = make_dataset(config, "valid", config.category)
+    train_loader = DataLoader(train_dataset, batch_size=config.batch_size, shuffle=True, num_workers=config.num_workers,
+                              generator=torch.Generator().manual_seed(0))
+    val_loader = DataLoader(val_dataset, batch_size=config.batch_size, shuffle=False, num_workers=config.num_workers)
+    log_dataset.info("Dataset loaded!")
+
+    model = PCNNet(config, enc_type=config.enc_type, dec_type=config.dec_type)
+    if config.freeze_decoder:
+        for param in model.decoder.parameters():
+            param.requires_grad = False
+    if config.freeze_encoder:
+        for param in model.encoder.parameters():
+            param.requires_grad = False
+    D.broadcast_model(model)
+
+    optimizer = FusedAdam(model.parameters(), lr=config.lr, betas=(0.9, 0.999))
+    start_epoch, best_cd_l1, best_epoch_l1 = 0, 1e8, -1
+    if args.resume:
+        model_path = os.path.join(config.exp_dir, "models/model_last.pth")
+        optim_path = os.path.join(config.exp_dir, "optimizer/optim_last.pth")
+        if os.path.exists(model_path) and os.path.exists(optim_path):
+            model.load_state_dict(torch.load(model_path, map_location=config.device))
+            optim_dict = torch.load(optim_path, map_location=config.device)
+            optimizer.load_state_dict(optim_dict["optim_state_dict"])
+            start_epoch = optim_dict["epoch"] + 1
+            best_cd_l1, best_epoch_l1 = optim_dict["best_metrics"], optim_dict["best_epoch"]
+            log.info(f"[RESUME INFO] resume ckpts @ {start_epoch - 1} epoch( best_metrics = {str(best_cd_l1 * 1e3):s})")
+        else:
+            log.info(f"Tried to resume training from experiment: {config.exp_dir}, however, model.pth or optim.pth "
+                     "not existant. Train from start")
+    else:
+        log.info(f"Start a brand new experiment: {config.run_name}")
+    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=50, gamma=0.8, last_epoch=-1)
+    for _ in range(start_epoch):
+        scheduler.step()
+
+    n_batches = len(train_loader)
+    step = max(n_batches // config.log_frequency, 1)
+    log.info(f"Model total params: {get_num_params_total(model)}")
+    log.info(f"Producing coarse only: {config.only_coarse}")
+    log.info(f"Producing num of coarse points: {config.num_coarse}")
+
+    for epoch in range(start_epoch, config.max_epochs + 1):
+        model.train()
+        sums = torch.zeros(3, device=config.device)          # total, coarse, dense — accumulated on the device
+        for i, (p, c) in enumerate(train_loader):
+            lo, hi = D.shard_batch(p.shape[0]) if world > 1 and p.shape[0] % world == 0 else (0, p.shape[0])
+            p, c = p[lo:hi].to(config.device), c[lo:hi].to(config.device)
+            trot = make_rotation(config.rotation, p.shape[0], config.device)
+            if trot is not None:
+                p, c = trot.transform_points(p), trot.transform_points(c)
+            loss, loss1, loss2 = train_step(config, model, optimizer, p, c, trot)
+            sums += torch.stack([loss, loss1, loss2])
+            if is_main and (i + 1) % step == 0:
+                l, l1, l2 = loss.item(), loss1.item(), loss2.item()
+                log.info("Training Epoch [{:03d}/{:03d}] - Iteration [{:03d}/{:03d}]: coarse loss = {:.6f}, dense loss = {:.6f}, "
+                         "total loss = {:.6f}, lr = {:.6f}".format(epoch, config.max_epochs, i + 1, n_batches, l1 * 1e3, l2 * 1e3,
+                                                                    l * 1e3, scheduler.get_last_lr()[0]))
+                ts = epoch * n_batches + i
+                train_writer.add_scalar("Loss/Batch/Coarse", l1, ts)
+                train_writer.add_scalar("Loss/Batch/Dense", l2, ts)
+                train_writer.add_scalar("Loss/Batch/Total", l, ts)
+        scheduler.step()
+        tot, co, de = (sums / max(n_batches, 1)).tolist()
+        if is_main:
+            log.info("Training Epoch [{:03d}/{:03d}]: Coarse Loss = {:.6f}, Dense Loss = {:.6f}, Total Loss = {:.6f}".format(
+                epoch, config.max_epochs, co * 1e3, de * 1e3, tot * 1e3))
+            train_writer.add_scalar("Loss/Epoch/Coarse", co * 1e3, epoch)
+            train_writer.add_scalar("Loss/Epoch/Dense", de * 1e3, epoch)
+            train_writer.add_scalar("Loss/Epoch/Total", tot * 1e3, epoch)
+
+        # evaluation (train.py:198-250) — rank 0 only; replicas are identical after the all-reduced step
+        if is_main:
+            model.eval()
+            val = torch.zeros(2, device=config.device)
+            with torch.no_grad():
+                for p, c in val_loader:
+                    p, c = p.to(config.device), c.to(config.device)
+                    trot = make_rotation(config.val_rotation, p.shape[0], config.device)
+                    if trot is not None:
+                        p, c = trot.transform_points(p), trot.transform_points(c)
+                    coarse_pred, dense_pred = model(p, trot)
+                    val[0] += l1_cd(coarse_pred, c)
+                    if not config.only_coarse:
+                        val[1] += l1_cd(dense_pred, c)
+            vc, vd = (val / len(val_dataset)).tolist()
+            vt = vc if config.only_coarse else vc + vd
+            val_writer.add_scalar("Loss/Epoch/Coarse", vc * 1e3, epoch)
+            val_writer.add_scalar("Loss/Epoch/Dense", vd * 1e3, epoch)
+            val_writer.add_scalar("Loss/Epoch/Total", vt * 1e3, epoch)
+            log.info("Validate Epoch [{:03d}/{:03d}]: Coarse Loss = {:.6f}, Dense Loss = {:.6f}, Total Loss = {:.6f}".format(
+                epoch, config.max_epochs, vc * 1e3, vd * 1e3, vt * 1e3))
+            ckpt = {"epoch": epoch, "optim_state_dict": None, "best_metrics": best_cd_l1, "best_epoch": best_epoch_l1}
+            if vt < best_cd_l1:
+                best_epoch_l1, best_cd_l1 = epoch, vt
+                torch.save(model.state_dict(), os.path.join(model_dir, "model_best.pth"))
+                log.info(f"Save checkpoint at {os.path.join(model_dir, 'model_best.pth')}")
+                ckpt.update(optim_state_dict=deepcopy(optimizer.state_dict()), best_metrics=best_cd_l1, best_epoch=best_epoch_l1)
+                torch.save(ckpt, os.path.join(optim_dir, "optim_best.pth"))
+            torch.save(model.state_dict(), os.path.join(model_dir, "model_last.pth"))
+            log.info(f"Save checkpoint at {os.path.join(model_dir, 'model_last.pth')}")
+            ckpt.update(optim_state_dict=deepcopy(optimizer.state_dict()), best_metrics=best_cd_l1, best_epoch=best_epoch_l1)
+            torch.save(ckpt, os.path.join(optim_dir, "optim_last.pth"))
+        D.barrier()
+    if is_main:
+        log.info("Best l1 cd model in epoch {}, the minimum l1 cd is {}".format(best_epoch_l1, best_cd_l1 * 1e3))
+        train_writer.close()
+        val_writer.close()
