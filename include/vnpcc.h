@@ -86,6 +86,13 @@ int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int
                     int* idx, float* out, int ldo, float* ws_val, int* ws_idx);
 int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
                     float* gx, int ldgx);
+/* Backward of VNLinear followed by VNMaxPool (models/pcn.py:169-170,173-174) without the dense gradient of the linear output:
+ * gW[Co][Ci] = sum_{g,t} gout[g*3+t][o] x[(g*gs+idx[g][o])*3+t][:]   (NULL: skip)
+ * gx[G*gs*3][Ci] (zero-filled here) gets, for every selected point, sum_{o: idx[g][o]==n} gout[g*3+t][o] W[o][:]   (NULL: skip)
+ * order/pts [G][Co]: channels of each group sorted by arg-max point, and those points (ascending). */
+int vnp_pool_lin_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, const int* order, const int* pts,
+                     const float* x, int ldx, const float* W, int ldw, int G, int gs, int Co, int Ci,
+                     float* gW, int ldgw, float* gx, int ldgx);
 /* mean_pool (models/vn_layers.py:170-171) over groups of gs consecutive points */
 int vnp_vn_mean_pool_fwd(hipStream_t st, const float* x, int ldx, long long G, int gs, int C, float* out, int ldo);
 int vnp_vn_mean_pool_bwd(hipStream_t st, const float* gout, int ldgo, long long G, int gs, int C, float* gx, int ldgx);

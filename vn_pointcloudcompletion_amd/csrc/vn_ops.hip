@@ -504,6 +504,94 @@ extern "C" int vnp_outer(hipStream_t st, const float* u, const float* w, long lo
     return vnp_last_error();
 }
 
+
+// ------------------------------------------------------------------------------------------------ sparse pool backward
+// VNLinear followed by VNMaxPool (models/pcn.py:169-170, 173-174): y = x W^T, out[g,t,o] = y[(g, idx[g,o]), t, o].
+// The gradient of y has ONE non-zero point per (group, channel), so instead of materialising it and running two dense
+// GEMMs (25.8 GFLOP per sample each for 1024 -> 2048), both gradients are gathered directly:
+//   dW[o][c]        = sum_{g,t} gout[g*3+t][o] * x[(g*gs + idx[g][o])*3 + t][c]
+//   dx[(g,n)*3+t][c] = sum_{o : idx[g][o] == n} gout[g*3+t][o] * W[o][c]
+// dW: grid (Co), threads over c.  Deterministic (fixed g,t order).
+__global__ void __launch_bounds__(256) vnp_pool_lin_bwd_w_kernel(const float* __restrict__ gout, int ldgo, const int* __restrict__ idx,
+                                                                const float* __restrict__ x, int ldx, int G, int gs, int Co, int Ci,
+                                                                float* __restrict__ gW, int ldgw)
+{
+    const int o = blockIdx.x;
+    for (int c0 = threadIdx.x * 4; c0 < Ci; c0 += 1024) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const bool vec = (c0 + 3 < Ci) && ((ldx & 3) == 0);
+        for (int g = 0; g < G; ++g) {
+            const size_t row = ((size_t)g * gs + idx[(size_t)g * Co + o]) * 3;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float w = gout[((size_t)g * 3 + t) * ldgo + o];
+                const float* r = x + (row + t) * ldx + c0;
+                if (vec) { const vnp_f4 v = *(const vnp_f4*)r; a0 += w * v[0]; a1 += w * v[1]; a2 += w * v[2]; a3 += w * v[3]; }
+                else {
+                    a0 += w * r[0];
+                    if (c0 + 1 < Ci) a1 += w * r[1];
+                    if (c0 + 2 < Ci) a2 += w * r[2];
+                    if (c0 + 3 < Ci) a3 += w * r[3];
+                }
+            }
+        }
+        float* dst = gW + (size_t)o * ldgw + c0;
+        dst[0] = a0;
+        if (c0 + 1 < Ci) dst[1] = a1;
+        if (c0 + 2 < Ci) dst[2] = a2;
+        if (c0 + 3 < Ci) dst[3] = a3;
+    }
+}
+
+// dx: `order`[g][j] lists the channels of group g sorted by their arg-max point, `pts`[g][j] that point.  Block (j, g)
+// owns the run of equal points starting at j (blocks inside a run exit), so every selected point's 3 rows are
+// written exactly once, without atomics; all other rows of dx were zero-filled beforehand.
+__global__ void __launch_bounds__(256) vnp_pool_lin_bwd_x_kernel(const float* __restrict__ gout, int ldgo, const int* __restrict__ order,
+                                                                const int* __restrict__ pts, const float* __restrict__ W, int ldw,
+                                                                int gs, int Co, int Ci, float* __restrict__ gx, int ldgx)
+{
+    const int j0 = blockIdx.x, g = blockIdx.y;
+    const int* pg = pts + (size_t)g * Co;
+    const int n = pg[j0];
+    if (j0 > 0 && pg[j0 - 1] == n) return;
+    int j1 = j0 + 1;
+    while (j1 < Co && pg[j1] == n) ++j1;
+    const int* og = order + (size_t)g * Co;
+    for (int c0 = threadIdx.x; c0 < Ci; c0 += 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int j = j0; j < j1; ++j) {
+            const int o = og[j];
+            const float w = W[(size_t)o * ldw + c0];
+            a0 += gout[((size_t)g * 3 + 0) * ldgo + o] * w;
+            a1 += gout[((size_t)g * 3 + 1) * ldgo + o] * w;
+            a2 += gout[((size_t)g * 3 + 2) * ldgo + o] * w;
+        }
+        const size_t row = ((size_t)g * gs + n) * 3;
+        gx[(row + 0) * ldgx + c0] = a0;
+        gx[(row + 1) * ldgx + c0] = a1;
+        gx[(row + 2) * ldgx + c0] = a2;
+    }
+}
+
+extern "C" int vnp_pool_lin_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, const int* order, const int* pts,
+                                const float* x, int ldx, const float* W, int ldw, int G, int gs, int Co, int Ci,
+                                float* gW, int ldgw, float* gx, int ldgx)
+{
+    if (!gout || !idx || G <= 0 || gs <= 0 || Co <= 0 || Ci <= 0 || G > 65535) return VNP_EINVAL;
+    if (gW) {
+        if (!x) return VNP_EINVAL;
+        hipLaunchKernelGGL(vnp_pool_lin_bwd_w_kernel, dim3(Co), dim3(256), 0, st, gout, ldgo, idx, x, ldx, G, gs, Co, Ci, gW, ldgw);
+    }
+    if (gx) {
+        if (!order || !pts || !W) return VNP_EINVAL;
+        hipError_t e = ldgx == Ci ? hipMemsetAsync(gx, 0, (size_t)G * gs * 3 * Ci * 4, st)
+                                  : hipMemset2DAsync(gx, (size_t)ldgx * 4, 0, (size_t)Ci * 4, (size_t)G * gs * 3, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(vnp_pool_lin_bwd_x_kernel, dim3(Co, G), dim3(256), 0, st, gout, ldgo, order, pts, W, ldw, gs, Co, Ci, gx, ldgx);
+    }
+    return vnp_last_error();
+}
+
 // ================================================================================================ C-ABI
 static inline dim3 vnp_grid_pc(long long P, int C) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, VNP_CHUNK)); }
 

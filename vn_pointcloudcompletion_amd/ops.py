@@ -87,6 +87,23 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, A2=None, B2=None, bias=None, rows_pe
     return out
 
 
+def reduce_rows(part, nb, n, W):
+    """part: contiguous [nb][n][W] partials -> [nb][W] (sum over n; two passes when n is large so that no thread
+    walks more than a few hundred partials)."""
+    dev = part.device
+    if n > 1024:
+        m = 256
+        n1 = (n + m - 1) // m
+        if n % m:
+            raise _lib.VnpError("reduce_rows: large partial counts must be a multiple of 256")
+        tmp = torch.empty((nb, n1, W), device=dev, dtype=torch.float32)
+        call("vnp_reduce_rows", ptr(part), nb * n1, m * W, m, W, W, ptr(tmp), W)
+        part, n = tmp, n1
+    out = torch.empty((nb, W), device=dev, dtype=torch.float32)
+    call("vnp_reduce_rows", ptr(part), nb, n * W, n, W, W, ptr(out), W)
+    return out
+
+
 def _per_sample_colsum(g, rows_per_group):
     """g [R, W] contiguous -> [R/rows_per_group*3, W]: sum over the points of each sample, per (t, column)."""
     R, W = g.shape
@@ -343,6 +360,49 @@ class VNMaxPoolFn(Function):
         return gx, None, None, None
 
 
+class VNLinearMaxPoolFn(Function):
+    """VNLinear followed by VNMaxPool when the pool is the linear output's ONLY consumer (encoder second_conv[1] ->
+    maxpool2, models/pcn.py:173-174).  Forward: y = x W^T, d = y Wd^T, arg-max pool (y and d are dropped afterwards).
+    Backward: the gradient of y has one non-zero point per (sample, channel); dW and dx are gathered directly
+    (vnp_pool_lin_bwd) instead of two dense GEMMs over a 1.6 GB mostly-zero matrix."""
+
+    @staticmethod
+    def forward(ctx, x, W, Wd, G, gs):
+        x = _rows(x)
+        y = gemm(x, W, nsplit=1)
+        C = y.shape[1]
+        d = gemm(y, Wd, nsplit=1)
+        nch = _nchunk(gs)
+        ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
+        ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
+        idx = torch.empty((G, C), device=x.device, dtype=torch.int32)
+        out = torch.empty((G * 3, C), device=x.device, dtype=torch.float32)
+        call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        ctx.save_for_backward(x, W, idx)
+        ctx.cfg = (G, gs, C)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, _gidx):
+        x, W, idx = ctx.saved_tensors
+        G, gs, C = ctx.cfg
+        gout = _rows(gout)
+        Ci = x.shape[1]
+        dev = x.device
+        gW = torch.empty((C, Ci), device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        gx = order = pts = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((G * gs * 3, Ci), device=dev, dtype=torch.float32)
+            pts64, order64 = torch.sort(idx, dim=1, stable=True)        # index bookkeeping only
+            pts, order = pts64.int().contiguous(), order64.int().contiguous()
+        Wc = _rows(W)
+        call("vnp_pool_lin_bwd", ptr(gout), _ld(gout), ptr(idx), ptr(order), ptr(pts), ptr(x), _ld(x), ptr(Wc), _ld(Wc),
+             G, gs, C, Ci, ptr(gW), Ci, ptr(gx), Ci)
+        return gx, gW, None, None, None
+
+
 class VNMeanPoolFn(Function):
     """mean_pool (models/vn_layers.py:170-171) over groups of gs consecutive points."""
 
@@ -397,12 +457,10 @@ class FoldFn(Function):
         dev = g.device
         part = torch.empty((B * Mc, 5, W), device=dev, dtype=torch.float32)
         call("vnp_fold_bwd", ptr(g), _ld(g), ptr(seed), batched, ptr(coarse), B, Mc, S, W, ptr(part))
-        gbias = torch.empty((B * 3, W), device=dev, dtype=torch.float32)
-        call("vnp_reduce_rows", ptr(part), B, Mc * 5 * W, Mc, 5 * W, 3 * W, ptr(gbias), 3 * W)
-        gws = torch.empty(W, device=dev, dtype=torch.float32)
-        gwc = torch.empty(W, device=dev, dtype=torch.float32)
-        call("vnp_reduce_rows", part.data_ptr() + 3 * W * 4, 1, 0, B * Mc, 5 * W, W, ptr(gws), W)
-        call("vnp_reduce_rows", part.data_ptr() + 4 * W * 4, 1, 0, B * Mc, 5 * W, W, ptr(gwc), W)
+        per_sample = reduce_rows(part, B, Mc, 5 * W)                    # [B][5W]: sums over the coarse points
+        gbias = per_sample[:, :3 * W].reshape(B * 3, W)
+        tot = reduce_rows(per_sample, 1, B, 5 * W)                      # [1][5W]
+        gws, gwc = tot[0, 3 * W:4 * W], tot[0, 4 * W:]
         gcoarse = None
         if ctx.needs_input_grad[4]:
             R = B * Mc * S * 3
@@ -442,10 +500,11 @@ class LinOutFn(Function):
             gx = torch.empty((R, C), device=dev, dtype=torch.float32)
             call("vnp_outer", ptr(g), ptr(w), R, C, ptr(gx), C)
         nch = _nchunk(R)
-        part = torch.empty((nch, C), device=dev, dtype=torch.float32)
+        nch_pad = (nch + 255) // 256 * 256 if nch > 1024 else nch
+        part = torch.zeros((nch_pad, C), device=dev, dtype=torch.float32) if nch_pad != nch else \
+            torch.empty((nch, C), device=dev, dtype=torch.float32)
         call("vnp_colsum", ptr(x), 0, _ld(x), 1, R, C, ptr(g), ptr(part))
-        gw = torch.empty((1, C), device=dev, dtype=torch.float32)
-        call("vnp_reduce_rows", ptr(part), 1, 0, nch, C, C, ptr(gw), C)
+        gw = reduce_rows(part, 1, nch_pad, C)
         gcoarse = torch.empty(cshape, device=dev, dtype=torch.float32)
         call("vnp_group_sum3", ptr(g), R // 3 // S, S, ptr(gcoarse), 0)
         return gx, gw, gcoarse, None

@@ -61,8 +61,10 @@ class VN_PointNet(nn.Module):
         f = self.first_conv[1].forward_rows(f)                                  # [B*N*3, 512]
         g1 = self.maxpool1.forward_rows(f, B, N)                                # [B*3, 512]
         f = self.second_conv[0].forward_rows(f, global_rows=g1, rows_per_group=N * 3)
-        f = self.second_conv[1].forward_rows(f)                                 # [B*N*3, 2*latent]
-        g2 = self.maxpool2.forward_rows(f, B, N)                                # [B*3, 2*latent]
+        # second_conv[1] + maxpool2 fused: the linear output has no other consumer, so its (one-point-per-channel)
+        # gradient is never materialised (ops.VNLinearMaxPoolFn)
+        g2, _ = ops.VNLinearMaxPoolFn.apply(f, self.second_conv[1].map_to_feat.weight,
+                                            self.maxpool2.map_to_dir.weight.detach(), B, N)    # [B*3, 2*latent]
         h = self.mlp[0].forward_rows(g2)
         h = self.mlp[1].forward_rows(h)
         h = self.mlp[2].forward_rows(h)                                         # [B*3, Mc]
