@@ -124,9 +124,24 @@ def main():
         tot_t = sum(a[1] for a in agg.values())
         nlaunch = sum(a[2] for a in agg.values())
         achieved = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction);
+        # bench.py cannot run the counters on itself, so this is read from profiles/ (null when absent)
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")))[-1]
+            tr = json.load(open(summ)).get("traffic", {})
+            num = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items() if "vnp_gemm_kernel" in k)
+            den = sum(v["launches"] for k, v in tr.items() if "vnp_gemm_kernel" in k)
+            if den:
+                traffic, traffic_src = num / den, os.path.relpath(summ, ROOT)
+        except Exception:
+            pass
+        alg_bytes = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in prof) / max(nlaunch, 1)
         roofline = {"bound": "mfma", "kernel": "vnp_gemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                     "launches_per_step": nlaunch // max(args.steps, 1),
                     "flop_per_launch": tot_f / max(nlaunch, 1), "avg_launch_ms": tot_t / max(nlaunch, 1) * 1e3,
                     "gemm_ms_per_step": tot_t / args.steps * 1e3,

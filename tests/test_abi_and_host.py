@@ -1,0 +1,112 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vnpcc.h declares (no compute calls without a GPU), and
+the host-side logic (transforms, experiment directories, dataset readers, flat optimizer buffers)."""
+import ctypes
+import json
+import os
+import re
+import struct
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    from vn_pointcloudcompletion_amd import _lib
+    header = open(os.path.join(ROOT, "include", "vnpcc.h")).read()
+    declared = sorted(set(re.findall(r"^\s*int\s+(vnp_\w+)\s*\(", header, flags=re.M)))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/vnpcc.h but not exported by libvnpcc.so"
+    assert declared == _lib.exported_symbols(), "ctypes signature table and header disagree"
+    assert _lib.chunk_points() > 0
+
+
+def test_no_cpu_fallback():
+    from vn_pointcloudcompletion_amd import _lib, ops
+    from vn_pointcloudcompletion_amd.chamfer_distance import ChamferDistance
+    with pytest.raises(_lib.VnpError):
+        ChamferDistance()(torch.rand(1, 8, 3), torch.rand(1, 9, 3))
+    with pytest.raises(_lib.VnpError):
+        ops.gemm(torch.rand(4, 4), torch.rand(4, 4))
+    import vn_pointcloudcompletion_amd as pkg
+    src = "".join(open(os.path.join(os.path.dirname(pkg.__file__), f)).read()
+                  for f in os.listdir(os.path.dirname(pkg.__file__)) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src          # the product never touches the oracle
+
+
+def test_transforms():
+    from vn_pointcloudcompletion_amd.transforms import Rotate, RotateAxisAngle, random_rotations
+    R = random_rotations(5, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(5, 3, 3), atol=1e-5)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(5), atol=1e-5)
+    p = torch.randn(5, 7, 3)
+    assert torch.allclose(Rotate(R).transform_points(p), p @ R)
+    assert Rotate(R).transform_points(torch.randn(1, 16, 3)).shape == (5, 16, 3)        # pcn.py:369-370 broadcast
+    z = RotateAxisAngle(torch.tensor([90.0]), axis="Z")
+    # pytorch3d convention: +90 deg about Z maps x -> y for row vectors p @ R
+    assert torch.allclose(z.transform_points(torch.tensor([[[1.0, 0.0, 0.0]]])), torch.tensor([[[0.0, 1.0, 0.0]]]), atol=1e-6)
+
+
+def test_experiment_dirs_and_config(tmp_path, monkeypatch):
+    from vn_pointcloudcompletion_amd import experiments as X
+    monkeypatch.setenv("OUTPUT_DIR", str(tmp_path / "exp"))
+    cfg_path = tmp_path / "config.json"
+    cfg_path.write_text(json.dumps({"name": "unit", "lr": 1e-4, "dcd_opts": {"alpha": 200, "lambda": 0.5}, "checkpoint": 0}))
+    cfg = X.load_config(config_path=str(cfg_path))
+    assert cfg.dcd_opts.alpha == 200 and cfg.data_path
+    cfg = X.create_experiment(cfg)
+    assert re.fullmatch(r"\d\d-\d\d_unit_000", cfg.run_name)
+    for sub in ("models", "optimizer", "visualizations", "train", "val"):
+        assert os.path.isdir(os.path.join(cfg.exp_dir, sub))
+    X.store_config(cfg)
+    again = X.load_config(config_path=os.path.join(cfg.exp_dir, "config.json"))
+    assert again.run_name == cfg.run_name and again.dcd_opts.alpha == 200
+    cfg2 = X.create_experiment(X.load_config(config_path=str(cfg_path)))
+    assert cfg2.run_name.endswith("_001")
+
+
+def test_ply_reader_and_datasets(tmp_path):
+    from vn_pointcloudcompletion_amd.dataset import ShapeNet, SyntheticShapes, read_ply_xyz
+    pts = np.random.rand(50, 3).astype(np.float32)
+    a = tmp_path / "a.ply"
+    a.write_text("ply\nformat ascii 1.0\nelement vertex 50\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+                 + "\n".join(" ".join(f"{v:.7g}" for v in p) for p in pts) + "\n")
+    assert np.allclose(read_ply_xyz(str(a)), pts, atol=1e-6)
+    b = tmp_path / "b.ply"
+    with open(b, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 50\nproperty float x\nproperty float y\n"
+                b"property float z\nproperty uchar red\nend_header\n")
+        for p in pts:
+            f.write(struct.pack("<fffB", *p, 7))
+    assert np.array_equal(read_ply_xyz(str(b)), pts)
+    assert ShapeNet.random_sample(pts, 2048).shape == (2048, 3) and ShapeNet.random_sample(pts, 10).shape == (10, 3)
+    ds = SyntheticShapes(4, 32, 64)
+    p0, c0 = ds[1]
+    p1, c1 = ds[1]
+    assert p0.shape == (32, 3) and c0.shape == (64, 3) and torch.equal(p0, p1) and p0.abs().max() <= 0.5
+
+
+def test_flat_buffers_and_adam_state_dict_format():
+    from vn_pointcloudcompletion_amd.optim import FlatBuffers
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3, bias=False), torch.nn.BatchNorm1d(3), torch.nn.Linear(3, 2, bias=False))
+    m[2].weight.requires_grad = False
+    before = [p.detach().clone() for p in m.parameters()]
+    fb = FlatBuffers(m.parameters())
+    assert [p.shape for p in fb.params] == [(3, 5), (3,), (3,)]
+    assert all(o % 4 == 0 for o in fb.offsets) and fb.numel % 4 == 0
+    for p, b in zip(m.parameters(), before):
+        assert torch.equal(p, b)
+    m(torch.randn(4, 5)).sum().backward()
+    g = m[0].weight.grad
+    assert g.data_ptr() == fb.flat_grad.data_ptr()                  # autograd accumulated IN PLACE into the flat buffer
+    assert fb.flat_grad[:15].abs().sum() > 0
+    fb.zero_grad()
+    assert fb.flat_grad.abs().sum() == 0 and m[0].weight.grad.data_ptr() == fb.flat_grad.data_ptr()
+    m[0].weight.grad = None                                          # a caller used set_to_none=True
+    fb.zero_grad()
+    assert m[0].weight.grad is not None

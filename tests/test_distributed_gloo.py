@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of distributed.py (sharding rule, weight broadcast,
+flat-buffer gradient averaging with never-used parameters present)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from vn_pointcloudcompletion_amd import distributed as D
+    from vn_pointcloudcompletion_amd.optim import FlatBuffers
+    r, lr, w = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world and D.get_rank() == rank
+    lo, hi = D.shard_batch(8)
+    assert (lo, hi) == (rank * 4, rank * 4 + 4)
+    with pytest.raises(ValueError):
+        D.shard_batch(7)
+    torch.manual_seed(100 + rank)                                   # different init on every rank ...
+    model = torch.nn.Sequential(torch.nn.Linear(6, 4, bias=False), torch.nn.Linear(4, 4, bias=False), torch.nn.Linear(4, 1, bias=False))
+    D.broadcast_model(model)                                        # ... identical after the broadcast
+    w0 = model[0].weight.detach().clone()
+    fb = FlatBuffers(model.parameters())
+
+    class Holder:                                                   # what allreduce_gradients needs from FusedAdam
+        flat_buffers = [fb]
+    torch.manual_seed(7)
+    x = torch.randn(8, 6)[lo:hi]                                    # each rank: its shard of the same global batch
+    y = model[2](model[0](x))                                       # model[1] is never used: grad stays zero (not None)
+    y.sum().backward()
+    local = fb.flat_grad.clone()
+    D.allreduce_gradients(Holder)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(gathered) / world
+    ok = torch.allclose(fb.flat_grad, expect, atol=1e-6) and fb.view(fb.flat_grad, 1).abs().sum().item() == 0.0
+    mx = D.allreduce_scalar_max(float(rank + 1))
+    q.put((rank, ok, w0.sum().item(), mx))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    out.sort()
+    assert all(o[1] for o in out)
+    assert abs(out[0][2] - out[1][2]) < 1e-7                        # same weights on both ranks
+    assert out[0][3] == out[1][3] == 2.0

@@ -1,0 +1,155 @@
+"""CPU: the oracle (oracle/) against the golden fixtures generated from the reference (tests/golden/make_golden.py).
+This is what pins the oracle; the GPU tests then compare the HIP path with the goldens and with the oracle."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+from oracle import chamfer_oracle as CO
+from oracle import vn_oracle as O
+
+T = torch.as_tensor
+
+
+@pytest.fixture(scope="module")
+def G():
+    return load_golden("layers.npz")
+
+
+@pytest.mark.parametrize("tag", ["d4", "d5"])
+def test_layers_forward_and_autograd(G, tag):
+    x = T(G[f"x_{tag}"])
+    # VNLinear
+    w = T(G[f"lin_{tag}_w"]).requires_grad_(True)
+    xr = T(G[f"lin_{tag}_x"]).requires_grad_(True)
+    y = O.vn_linear(xr, w)
+    assert relerr(y, G[f"lin_{tag}_y"]) < 1e-5
+    y.backward(T(G[f"lin_{tag}_g"]))
+    assert relerr(xr.grad, G[f"lin_{tag}_gx"]) < 1e-5 and relerr(w.grad, G[f"lin_{tag}_gw"]) < 1e-5
+    # VNLeakyReLU
+    w = T(G[f"leaky_{tag}_w"]).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = O.vn_leaky_relu(xr, w)
+    assert relerr(y, G[f"leaky_{tag}_y"]) < 1e-5
+    y.backward(T(G[f"leaky_{tag}_g"]))
+    assert relerr(xr.grad, G[f"leaky_{tag}_gx"]) < 1e-5 and relerr(w.grad, G[f"leaky_{tag}_gw"]) < 1e-5
+    # VNBatchNorm (train: output, grads, running stats; eval)
+    ga, be = T(G[f"bn_{tag}_gamma"]).requires_grad_(True), T(G[f"bn_{tag}_beta"]).requires_grad_(True)
+    C = ga.shape[0]
+    xr = x.clone().requires_grad_(True)
+    y, rm, rv = O.vn_batchnorm(xr, ga, be, torch.zeros(C), torch.ones(C), True)
+    assert relerr(y, G[f"bn_{tag}_y"]) < 1e-5 and relerr(rm, G[f"bn_{tag}_rm"]) < 1e-5 and relerr(rv, G[f"bn_{tag}_rv"]) < 1e-5
+    y.backward(T(G[f"bn_{tag}_g"]))
+    assert relerr(xr.grad, G[f"bn_{tag}_gx"]) < 5e-5
+    assert relerr(ga.grad, G[f"bn_{tag}_ggamma"]) < 1e-5 and relerr(be.grad, G[f"bn_{tag}_gbeta"]) < 1e-5
+    ye, _, _ = O.vn_batchnorm(x, ga.detach(), be.detach(), rm, rv, False)
+    assert relerr(ye, G[f"bn_{tag}_y_eval"]) < 1e-5
+    # VNLinearLeakyReLU
+    wf, wd = T(G[f"ll_{tag}_wf"]).requires_grad_(True), T(G[f"ll_{tag}_wd"]).requires_grad_(True)
+    ga, be = T(G[f"ll_{tag}_gamma"]).requires_grad_(True), T(G[f"ll_{tag}_beta"]).requires_grad_(True)
+    Co = wf.shape[0]
+    xr = x.clone().requires_grad_(True)
+    y, rm, rv = O.vn_linear_leaky_relu(xr, wf, wd, ga, be, torch.zeros(Co), torch.ones(Co), True)
+    assert relerr(y, G[f"ll_{tag}_y"]) < 1e-5 and relerr(rm, G[f"ll_{tag}_rm"]) < 1e-5 and relerr(rv, G[f"ll_{tag}_rv"]) < 1e-5
+    y.backward(T(G[f"ll_{tag}_g"]))
+    for got, key in ((xr.grad, "gx"), (wf.grad, "gwf"), (wd.grad, "gwd"), (ga.grad, "ggamma"), (be.grad, "gbeta")):
+        assert relerr(got, G[f"ll_{tag}_{key}"]) < 5e-5, key
+    ye, _, _ = O.vn_linear_leaky_relu(x, wf.detach(), wd.detach(), ga.detach(), be.detach(), rm, rv, False)
+    assert relerr(ye, G[f"ll_{tag}_y_eval"]) < 1e-5
+    # VNLinearAndLeakyReLU (no BN)
+    wl, wd = T(G[f"lal_{tag}_wl"]).requires_grad_(True), T(G[f"lal_{tag}_wd"]).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = O.vn_linear_and_leaky_relu(xr, wl, wd)
+    assert relerr(y, G[f"lal_{tag}_y"]) < 1e-5
+    y.backward(T(G[f"lal_{tag}_g"]))
+    assert relerr(xr.grad, G[f"lal_{tag}_gx"]) < 1e-5 and relerr(wl.grad, G[f"lal_{tag}_gwl"]) < 1e-5
+    assert relerr(wd.grad, G[f"lal_{tag}_gwd"]) < 1e-5
+    # VNMaxPool
+    xr = x.clone().requires_grad_(True)
+    y = O.vn_max_pool(xr, T(G[f"pool_{tag}_w"]))
+    assert relerr(y, G[f"pool_{tag}_y"]) < 1e-6
+    y.backward(T(G[f"pool_{tag}_g"]))
+    assert relerr(xr.grad, G[f"pool_{tag}_gx"]) < 1e-6
+
+
+def test_layer_norm(G):
+    xr = T(G["x_d4"]).requires_grad_(True)
+    ga, be = T(G["ln_gamma"]).requires_grad_(True), T(G["ln_beta"]).requires_grad_(True)
+    y = O.vn_layer_norm(xr, ga, be)
+    assert relerr(y, G["ln_y"]) < 1e-5
+    y.backward(T(G["ln_g"]))
+    assert relerr(xr.grad, G["ln_gx"]) < 5e-5 and relerr(ga.grad, G["ln_ggamma"]) < 1e-5 and relerr(be.grad, G["ln_gbeta"]) < 1e-5
+
+
+def _closed_form_decoder_sd():
+    """Shapes of VN_FoldingNet(latent_dim=8) filled by the closed-form rule (the fixture does not store weights)."""
+    from vn_pointcloudcompletion_amd.pcn import VN_FoldingNet
+    dec = VN_FoldingNet(SimpleNamespace(num_coarse=4, latent_dim=8))
+    O.closed_form_fill(dec.state_dict())
+    return {"decoder." + k: v.clone() for k, v in dec.state_dict().items()}
+
+
+@pytest.mark.parametrize("tag", ["norot", "rot"])
+def test_small_foldingnet(tag):
+    F = load_golden("foldingnet_small.npz")
+    sd = _closed_form_decoder_sd()
+    for k in sd:
+        if sd[k].dtype.is_floating_point and "running" not in k:
+            sd[k].requires_grad_(True)
+    coarse, fg = T(F["coarse"]).requires_grad_(True), T(F["fg"]).requires_grad_(True)
+    new = {}
+    fine = O.vn_foldingnet_forward(sd, coarse, fg, T(F["R"]) if tag == "rot" else None, True, new_stats=new)
+    assert relerr(fine, F[f"{tag}_fine"]) < 5e-5
+    fine.backward(T(F[f"{tag}_g"]))
+    assert relerr(coarse.grad, F[f"{tag}_gcoarse"]) < 1e-3 and relerr(fg.grad, F[f"{tag}_gfg"]) < 1e-3
+    for k, v in sd.items():
+        full = f"{tag}_grad.{k}"
+        if full in F:
+            assert relerr(v.grad, F[full]) < 1e-3, k
+    for k, v in new.items():
+        assert relerr(v, F[f"{tag}_after.{k}"]) < 1e-5, k
+
+
+def test_cfg1_teacher_forced():
+    """Config 1 (B=2, 256 -> 64 -> 1024): weights = torch default init under the fixture's seed (same RNG stream as the
+    reference, checked through per-tensor checksums); encoder up to the pools with an arg-max-flip allowance, mlp and
+    decoder teacher-forced on the reference's own intermediate tensors."""
+    from vn_pointcloudcompletion_amd.model import PCNNet          # parameter container only (never run on the CPU)
+    E = load_golden("cfg1_e2e.npz")
+    torch.manual_seed(int(E["seed"]))
+    net = PCNNet(SimpleNamespace(num_coarse=64, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cpu"),
+                 "vn_pointnet", "vn_foldingnet")
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for (k, p), s_, a_ in zip(net.named_parameters(), E["weight_sum"], E["weight_abssum"]):
+        assert abs(p.double().sum().item() - s_) <= 1e-9 * max(1.0, a_), k
+    p, g_ref, coarse_ref = T(E["p"]), T(E["feature_global"]), T(E["coarse"])
+    with torch.no_grad():
+        co, go = O.vn_pointnet_forward(sd, p, True)
+        flipped = ((go - g_ref).abs().amax(dim=(2, 3)) > 1e-4).sum().item()
+        assert flipped <= 0.005 * go.shape[0] * go.shape[1]
+        assert (co - coarse_ref).abs().max().item() < 1e-4
+        fo = O.vn_foldingnet_forward(sd, coarse_ref, g_ref, None, True)
+        assert (fo - T(E["fine"])).abs().max().item() < 5e-4
+        d1, d2, i1, i2 = O.chamfer_torch(T(E["fine"]), T(E["c"]))
+        assert abs(O.cd_loss_l1(d1, d2).item() - float(E["loss2"])) < 1e-6
+        assert np.array_equal(i1.numpy(), E["i1f"]) and np.array_equal(i2.numpy(), E["i2f"])
+
+
+def test_chamfer_c_oracle_vs_golden():
+    Gc = load_golden("chamfer.npz")
+    d1, d2, i1, i2 = CO.chamfer_forward(Gc["a"], Gc["b"])
+    assert np.abs(d1 - Gc["d1"]).max() < 1e-6 and np.abs(d2 - Gc["d2"]).max() < 1e-6
+    assert np.array_equal(i1, Gc["i1"]) and np.array_equal(i2, Gc["i2"])          # unit_test.py:29-33: exact indices
+    ga, gb = CO.chamfer_backward(Gc["a"], Gc["b"], Gc["g1"], Gc["g2"], i1, i2)
+    assert np.abs(ga - Gc["ga"]).max() < 1e-5 and np.abs(gb - Gc["gb"]).max() < 1e-5
+    e1, e2, j1, j2 = CO.chamfer_forward(Gc["a2"], Gc["b2"])
+    assert np.abs(e1 - Gc["e1"]).max() < 1e-6 and np.abs(e2 - Gc["e2"]).max() < 1e-6
+    assert np.array_equal(j1, Gc["j1"]) and np.array_equal(j2, Gc["j2"])
+    # the torch oracle (chunked) agrees with the C oracle, ties included
+    a = torch.rand(2, 300, 3)
+    b = a[:, :150].repeat(1, 3, 1)
+    t1, t2, k1, k2 = O.chamfer_torch(a, b, chunk=64)
+    c1, c2, l1, l2 = CO.chamfer_forward(a.numpy(), b.numpy())
+    assert np.abs(t1.numpy() - c1).max() < 1e-6 and np.array_equal(k1.numpy(), l1) and np.array_equal(k2.numpy(), l2)
