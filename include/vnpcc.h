@@ -106,6 +106,21 @@ int vnp_fold_fwd(hipStream_t st, const float* bias, int ldb, const float* wseed,
 int vnp_fold_bwd(hipStream_t st, const float* g, int ldg, const float* seed, int seed_batched, const float* coarse,
                  int B, int Mc, int S, int W, float* part);
 
+/* ---- graph construction / gathers: replace KNN_CUDA 0.2 and pointnet2_ops (third-party CUDA packages, README.md:29-31;
+ * call sites models/dgcnn.py:11,210-218,236,257-259, models/pcn.py:6-9).  Point-major clouds [B,N,D].
+ * knn: k nearest (squared L2) of each query among ref, sorted by (distance, index); idx [B][Nq][k] local indices. */
+int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k, int* idx, float* dist);
+/* furthest_point_sample: starts at index 0, ties to the lowest index; idx [B][M]; N <= 16384 */
+int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx);
+/* rows layout: out point i <- x point src[i] (gather_operation); and its adjoint gx[src[i]] += g[i] (gx zeroed here) */
+int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo);
+int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* src, long long Pout, int W,
+                           float* gx, int ldgx, long long Pin);
+/* out[(p*k+j)*3+t][c] = u[nbr[p*k+j]*3+t][c] + v[p*3+t][c]: edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278)
+ * with the layer's weights applied per point first (W [feat-x | x] = W1 feat + (W2-W1) x) */
+int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr,
+                        long long P, int k, int W, float* out, int ldo);
+
 /* ---- small reductions -------------------------------------------------------------------------------------- */
 /* out[r] = sum_c X[r][c]*w[c] (+ add[((r/3)/add_group)*3 + r%3]) : final VNLinear(C->1) + point_feat (pcn.py:387) */
 int vnp_rowdot(hipStream_t st, const float* X, int ldx, const float* w, long long R, int C,

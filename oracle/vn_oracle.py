@@ -190,6 +190,73 @@ def pcnnet_forward(sd, xyz, rot_R=None, training=True, new_stats=None):
     return coarse, fine, g
 
 
+# ------------------------------------------------------------------- graph helpers / VN-DGCNN
+def knn_torch(ref, query, k):
+    """ref [B,Nr,D], query [B,Nq,D] -> idx [B,Nq,k]: k smallest squared-L2 distances, ascending (direct-form distances).
+    Stands for KNN_CUDA 0.2 (third party, source absent; call sites models/dgcnn.py:236,257-259): PARITY UNPINNED for
+    tie order — the convention (distance, then index) is ours."""
+    d = ((query[:, :, None, :] - ref[:, None, :, :]) ** 2).sum(-1)
+    # lexicographic (distance, index): stable sort on the distances
+    return torch.sort(d, dim=-1, stable=True)[1][..., :k]
+
+
+def fps_torch(xyz, m):
+    """xyz [B,N,3] -> idx [B,m] (int64): iterative furthest point sampling starting at index 0, ties to the lowest index.
+    Stands for pointnet2_ops.furthest_point_sample (third party, source absent; models/dgcnn.py:210): PARITY UNPINNED."""
+    B, N, _ = xyz.shape
+    idx = torch.zeros(B, m, dtype=torch.long)
+    md = torch.full((B, N), 1e10, dtype=xyz.dtype)
+    cur = torch.zeros(B, dtype=torch.long)
+    ar = torch.arange(B)
+    for r in range(1, m):
+        c = xyz[ar, cur]                                          # [B,3]
+        d = ((xyz - c[:, None, :]) ** 2).sum(-1)
+        md = torch.minimum(md, d)
+        cur = md.argmax(dim=1)                                    # first maximum
+        idx[:, r] = cur
+    return idx
+
+
+def vn_graph_feature(x, idx):
+    """models/dgcnn.py:250-278: x [B,C,3,N], idx [B,N,k] -> cat(feature - x, x) [B,2C,3,N,k]."""
+    B, C, _, N = x.shape
+    k = idx.shape[-1]
+    xt = x.permute(0, 3, 1, 2)                                    # [B,N,C,3]
+    feat = torch.gather(xt.unsqueeze(1).expand(-1, N, -1, -1, -1), 2,
+                        idx[..., None, None].expand(-1, -1, -1, C, 3))          # [B,N,k,C,3]
+    xc = xt.unsqueeze(2).expand(-1, -1, k, -1, -1)
+    return torch.cat([feat - xc, xc], dim=3).permute(0, 3, 4, 1, 2)
+
+
+def vn_dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats=None):
+    """models/dgcnn.py:282-324 (VN_DGCNN_fps.forward, num_coarse != 224).  x [B,N,3] -> (coarse [B,Mc,3], global [B,512,3,1])."""
+    p = prefix
+    B, N, _ = x.shape
+    coor = x                                                       # [B,N,3]
+    f = x.transpose(1, 2).unsqueeze(1)                             # [B,1,3,N]
+
+    def conv(name, f, coords):
+        e = vn_graph_feature(f, knn_torch(coords, coords, k))
+        return mean_pool(_lin_leaky(sd, f"{p}.{name}", e, training, new_stats))
+
+    def down(coords, f, m):
+        i = fps_torch(coords, m)
+        nc = torch.gather(coords, 1, i[..., None].expand(-1, -1, 3))
+        nf = torch.gather(f, 3, i[:, None, None, :].expand(-1, f.shape[1], 3, -1))
+        return nc, nf
+
+    f = conv("conv1.0", f, coor)
+    cq, fq = down(coor, f, 512)
+    f = conv("conv4", fq, cq)
+    f = conv("conv5", f, cq)
+    cq, fq = down(cq, f, 128)
+    f = conv("conv6", fq, cq)
+    g = vn_max_pool(f, sd[f"{p}.pool5.map_to_dir.weight"]).unsqueeze(-1)
+    h = _lin_leaky(sd, f"{p}.conv7.0", g, training, new_stats)
+    h = vn_linear(h, sd[f"{p}.conv7.1.map_to_feat.weight"])
+    return h.squeeze(-1).contiguous(), g
+
+
 # --------------------------------------------------------------------------- losses
 def chamfer_torch(a, b, chunk=1024):
     """Direct-form squared NN distances (same formula as chamfer3D.cu:33-36) in torch, per sample and in row chunks

@@ -1,0 +1,126 @@
+"""BASELINE config 3 path (vn_dgcnn_fps + vn_foldingnet): HIP kNN / FPS / gathers against the oracle's conventions and
+the VN_DGCNN_fps encoder against tests/golden/dgcnn_small.npz (reference run with functional stand-ins for the
+CUDA-only KNN_CUDA / pointnet2_ops packages: parity for their tie order is unpinned; random fp32 data
+has no ties).  Index outputs are compared exactly; floats at 2e-4 of the tensor's max."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D(lib_built):
+    return load_golden("dgcnn_small.npz")
+
+
+def test_knn_matches_oracle(D):
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd import ops
+    x = t(D["x"])
+    idx = ops.knn_indices(x, x, 16)
+    assert np.array_equal(idx.cpu().numpy(), D["knn_idx"])
+    # query != ref, k = 8, ragged sizes; generic-D path (feature-space graphs of VN-PoinTr: D = 3*C)
+    g = torch.Generator().manual_seed(3)
+    for Dm, Nr, Nq, k in ((3, 700, 300, 8), (12, 130, 130, 8), (96, 128, 128, 8), (192, 70, 33, 5)):
+        r, q = torch.randn(2, Nr, Dm, generator=g), torch.randn(2, Nq, Dm, generator=g)
+        got, dist = ops.knn_indices(r.cuda(), q.cuda(), k, return_dist=True)
+        want = O.knn_torch(r, q, k)
+        assert np.array_equal(got.cpu().numpy(), want.numpy()), (Dm, Nr, Nq, k)
+        dref = ((q[:, :, None] - r[:, None]) ** 2).sum(-1).gather(2, want)
+        assert relerr(dist, dref) < 1e-5
+    # exact duplicates: (distance, index) order
+    r = torch.randn(1, 40, 3).repeat(1, 3, 1)
+    got = ops.knn_indices(r.cuda(), r[:, :40].cuda(), 6)
+    assert np.array_equal(got.cpu().numpy(), O.knn_torch(r, r[:, :40], 6).numpy())
+
+
+def test_knn_module_surface(lib_built):
+    from vn_pointcloudcompletion_amd.sampling import KNN
+    x = torch.randn(2, 3, 100).cuda()
+    dist, idx = KNN(k=16, transpose_mode=False)(x, x)
+    assert idx.shape == (2, 16, 100) and dist.shape == (2, 16, 100)          # "bs k np", dgcnn.py:236-237
+    assert torch.equal(idx[:, 0], torch.arange(100, device="cuda").expand(2, -1))
+
+
+def test_fps_matches_oracle(D):
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd import ops
+    idx = ops.fps_indices(t(D["x"]), 512)
+    assert np.array_equal(idx.cpu().numpy(), D["fps_idx"])
+    x = torch.rand(3, 5000, 3)
+    assert np.array_equal(ops.fps_indices(x.cuda(), 224).cpu().numpy(), O.fps_torch(x, 224).numpy())
+    assert np.array_equal(ops.fps_indices(x[:, :7].cuda(), 7).cpu().numpy(), O.fps_torch(x[:, :7], 7).numpy())
+
+
+def test_gather_and_edge_ops(lib_built):
+    from vn_pointcloudcompletion_amd import ops
+    P, k, W = 50, 4, 70
+    u = torch.randn(P * 3, W, device="cuda", requires_grad=True)
+    v = torch.randn(P * 3, W, device="cuda", requires_grad=True)
+    nbr = torch.randint(0, P, (P, k), device="cuda", dtype=torch.int32)
+    out = ops.EdgeGatherAddFn.apply(u, v, nbr)
+    u3, v3 = u.detach().view(P, 3, W), v.detach().view(P, 3, W)
+    ref = (u3[nbr.long()] + v3[:, None]).reshape(P * k * 3, W)
+    assert torch.equal(out, ref)
+    g = torch.randn_like(out)
+    out.backward(g)
+    g4 = g.view(P, k, 3, W)
+    assert relerr(v.grad, g4.sum(1).reshape(P * 3, W)) < 1e-6
+    gu = torch.zeros(P, 3, W, device="cuda").index_add_(0, nbr.long().reshape(-1), g4.reshape(P * k, 3, W))
+    assert relerr(u.grad, gu.reshape(P * 3, W)) < 1e-5
+    src = torch.randperm(P, device="cuda")[:20].int()
+    x = torch.randn(P * 3, W, device="cuda", requires_grad=True)
+    y = ops.GatherPointsFn.apply(x, src)
+    assert torch.equal(y, x.detach().view(P, 3, W)[src.long()].reshape(60, W))
+    y.backward(torch.ones_like(y))
+    assert x.grad.view(P, 3, W)[src.long()].min().item() == 1.0 and x.grad.sum().item() == 20 * 3 * W
+
+
+def _build(D):
+    from vn_pointcloudcompletion_amd.model import PCNNet
+    torch.manual_seed(int(D["seed"]))
+    cfg = SimpleNamespace(num_coarse=32, latent_dim=512, only_coarse=False, enc_pretrained="none", device="cuda")
+    net = PCNNet(cfg, "vn_dgcnn_fps", "vn_foldingnet")
+    net.decoder.num_dense = 512
+    return net.train()
+
+
+def test_vn_dgcnn_fps_matches_reference(D):
+    net = _build(D)
+    names = [k for k, _ in net.encoder.named_parameters()]
+    assert names == list(D["grad_names"])
+    for (k, p), s, a in zip(net.encoder.named_parameters(), D["weight_sum"], D["weight_abssum"]):
+        assert abs(p.double().sum().item() - s) <= 1e-9 * max(1.0, a), k
+    x = t(D["x"])
+    coarse, g = net.encoder(x)
+    assert coarse.shape == (2, 32, 3) and g.shape == (2, 512, 3, 1)
+    assert relerr(coarse, D["coarse"]) < 2e-4
+    flipped = ((g.cpu() - torch.as_tensor(D["global"])).abs().amax(dim=(2, 3)) > 1e-4).sum().item()
+    assert flipped <= 0.01 * 1024
+    (coarse * t(D["gc"])).sum().backward(retain_graph=True)
+    (g * t(D["gg"])).sum().backward()
+    bad = []
+    for (k, prm), n in zip(net.encoder.named_parameters(), D["grad_norms"]):
+        if n < 0:
+            assert prm.grad is None, k
+            continue
+        if abs(prm.grad.double().norm().item() - n) > 5e-3 * n:
+            bad.append((k, prm.grad.double().norm().item(), n))
+    assert not bad, bad
+    sd = net.state_dict()
+    for k in D:
+        if k.startswith("after."):
+            assert relerr(sd[k[6:]], D[k]) < 1e-4, k
+
+
+def test_pcnnet_dgcnn_foldingnet_end_to_end(D):
+    net = _build(D)
+    with torch.no_grad():
+        coarse, fine = net(t(D["x"]))
+    assert fine.shape == (2, 512, 3)
+    assert (fine.cpu() - torch.as_tensor(D["fine"])).abs().max().item() < 2e-3

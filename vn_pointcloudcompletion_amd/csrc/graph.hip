@@ -1,0 +1,222 @@
+// Graph construction and gather kernels for the VN-DGCNN / VN-PoinTr encoders: replacements for the two CUDA-only
+// third-party packages the reference imports (sources not vendored):
+//   KNN_CUDA 0.2            knn(ref, query) -> k nearest indices      (models/dgcnn.py:11,236,257-259)
+//   pointnet2_ops           furthest_point_sample, gather_operation   (models/dgcnn.py:210-218, models/pcn.py:6-9)
+// Conventions chosen here (the packages' tie behaviour is not pinned by any reference test): squared L2, neighbours
+// sorted by (distance, index) ascending, the query itself included when it is in the reference set; FPS starts at
+// index 0 and resolves ties to the lowest index.  Point clouds / features are point-major: [B, N, D], D contiguous
+// (coordinates [B,N,3]; VN features = the rows layout viewed as [B*N, 3*C]).
+#include "vnp_common.h"
+
+// ------------------------------------------------------------------------------------------------ kNN
+// One thread per query, k selection passes over the reference cloud: pass p takes the smallest (d, idx) pair that is
+// lexicographically greater than the pair chosen in pass p-1.  No per-thread arrays, deterministic order, exact ties.
+// The reference tile is staged in LDS ([KNN_TILE][D] floats); the query vector is re-read from LDS as well.
+#define KNN_THREADS 128
+template <int DT>     // DT = 3: coordinates (registers); DT = 0: generic D through LDS
+__global__ void __launch_bounds__(KNN_THREADS) vnp_knn_kernel(const float* __restrict__ ref, int Nr, const float* __restrict__ qry, int Nq,
+                                                            int D, int k, int tile, int* __restrict__ idx_out, float* __restrict__ dist_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* rt = sm;                                   // [tile][D]
+    float* qs = sm + (size_t)tile * D;                // [KNN_THREADS][D] (generic path only)
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * KNN_THREADS + threadIdx.x;
+    const bool live = q < Nq;
+    const float* rb = ref + (size_t)b * Nr * D;
+    const float* qb = qry + ((size_t)b * Nq + (live ? q : Nq - 1)) * D;
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (DT == 3) { q0 = qb[0]; q1 = qb[1]; q2 = qb[2]; }
+    else for (int d = 0; d < D; ++d) qs[threadIdx.x * D + d] = qb[d];
+    float last_d = -1.f; int last_i = -1;
+    for (int p = 0; p < k; ++p) {
+        float best = INFINITY; int bi = 0x7fffffff;
+        for (int r0 = 0; r0 < Nr; r0 += tile) {
+            const int cnt = min(tile, Nr - r0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt * D; i += KNN_THREADS) rt[i] = rb[(size_t)r0 * D + i];
+            __syncthreads();
+            for (int i = 0; i < cnt; ++i) {
+                float dd;
+                if (DT == 3) {
+                    const float dx = rt[i * 3] - q0, dy = rt[i * 3 + 1] - q1, dz = rt[i * 3 + 2] - q2;
+                    dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                } else {
+                    dd = 0.f;
+                    for (int d = 0; d < D; ++d) { const float t = rt[i * D + d] - qs[threadIdx.x * D + d]; dd = fmaf(t, t, dd); }
+                }
+                const int gi = r0 + i;
+                const bool after = dd > last_d || (dd == last_d && gi > last_i);
+                if (after && (dd < best || (dd == best && gi < bi))) { best = dd; bi = gi; }
+            }
+        }
+        last_d = best; last_i = bi;
+        if (live) {
+            idx_out[((size_t)b * Nq + q) * k + p] = bi == 0x7fffffff ? 0 : bi;
+            if (dist_out) dist_out[((size_t)b * Nq + q) * k + p] = best;
+        }
+    }
+}
+
+// idx [B][Nq][k] (indices local to the sample), dist (optional) squared distances.  k <= Nr.
+extern "C" int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k,
+                       int* idx, float* dist)
+{
+    if (!ref || !qry || !idx || B <= 0 || D <= 0 || Nr <= 0 || Nq <= 0 || k <= 0 || k > Nr || B > 65535) return VNP_EINVAL;
+    if (D == 3) {
+        const int tile = 1024;
+        hipLaunchKernelGGL((vnp_knn_kernel<3>), dim3(vnp_cdiv(Nq, KNN_THREADS), B), dim3(KNN_THREADS), (size_t)tile * 3 * 4, st,
+                           ref, Nr, qry, Nq, D, k, tile, idx, dist);
+    } else {
+        if (D > 320) return VNP_EINVAL;                      // [128][D] query copy + tile must fit the 160 KB LDS
+        int tile = (160 * 1024 / 4 - KNN_THREADS * D) / D;
+        if (tile > 256) tile = 256;
+        if (tile < 1) return VNP_EINVAL;
+        const size_t lds = ((size_t)tile * D + (size_t)KNN_THREADS * D) * 4;
+        hipError_t e = hipFuncSetAttribute((const void*)vnp_knn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((vnp_knn_kernel<0>), dim3(vnp_cdiv(Nq, KNN_THREADS), B), dim3(KNN_THREADS), lds, st,
+                           ref, Nr, qry, Nq, D, k, tile, idx, dist);
+    }
+    return vnp_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------ FPS
+// One 1024-thread block per sample; each thread keeps the running min-distance of up to FPS_PER_THREAD points in
+// registers; every round: update against the last pick, block arg-max (wave shuffles + one LDS exchange).
+#define FPS_THREADS 1024
+#define FPS_PER_THREAD 16       // N <= 16384
+__global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __restrict__ xyz, int N, int M, int* __restrict__ out)
+{
+    __shared__ float sv[FPS_THREADS / 64];
+    __shared__ int si[FPS_THREADS / 64];
+    __shared__ int pick;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = xyz + (size_t)b * N * 3;
+    float px[FPS_PER_THREAD], py[FPS_PER_THREAD], pz[FPS_PER_THREAD], md[FPS_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < FPS_PER_THREAD; ++u) {
+        const int i = tid + u * FPS_THREADS;
+        if (i < N) { px[u] = p[i * 3]; py[u] = p[i * 3 + 1]; pz[u] = p[i * 3 + 2]; md[u] = 1e10f; }
+        else { px[u] = py[u] = pz[u] = 0.f; md[u] = -1.f; }
+    }
+    int cur = 0;
+    if (tid == 0) out[(size_t)b * M] = 0;
+    for (int r = 1; r < M; ++r) {
+        const float cx = p[cur * 3], cy = p[cur * 3 + 1], cz = p[cur * 3 + 2];
+        float best = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < FPS_PER_THREAD; ++u) {
+            const int i = tid + u * FPS_THREADS;
+            if (i < N) {
+                const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
+                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                md[u] = fminf(md[u], d);
+                if (md[u] > best) { best = md[u]; bi = i; }       // ascending i within a thread: first max kept
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid < 64) {
+            float v = tid < FPS_THREADS / 64 ? sv[tid] : -2.f; int i = tid < FPS_THREADS / 64 ? si[tid] : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(i, o);
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            if (tid == 0) { pick = i; out[(size_t)b * M + r] = i; }
+        }
+        __syncthreads();
+        cur = pick;
+    }
+}
+
+// furthest_point_sample(xyz[B,N,3], M) -> idx [B][M]; N <= 16384
+extern "C" int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx)
+{
+    if (!xyz || !idx || B <= 0 || N <= 0 || M <= 0 || M > N || N > FPS_THREADS * FPS_PER_THREAD) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_fps_kernel, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    return vnp_last_error();
+}
+
+// ------------------------------------------------------------------------------------------------ gathers
+// rows layout: out point i (3 rows) <- source point src[i];  grid (ceil(W/256), Pout)
+__global__ void vnp_gather_points_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ src, int W,
+                                         float* __restrict__ out, int ldo)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    const size_t i = blockIdx.y, s = (size_t)src[i] * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) out[(i * 3 + t) * ldo + c] = x[(s + t) * ldx + c];
+}
+
+// gx[src[i]] += g[i]  (atomics; gx zeroed by the caller side of the C entry point)
+__global__ void vnp_scatter_add_points_kernel(const float* __restrict__ g, int ldg, const int* __restrict__ src, int W,
+                                              float* __restrict__ gx, int ldgx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    const size_t i = blockIdx.y, s = (size_t)src[i] * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) atomicAdd(&gx[(s + t) * ldgx + c], g[(i * 3 + t) * ldg + c]);
+}
+
+// Edge tensor of a kNN graph with the EdgeConv weights already applied (see ops.EdgeGatherAddFn):
+//   out[(p*k + j)*3 + t][c] = u[nbr[p*k+j]*3 + t][c] + v[p*3 + t][c]        grid (ceil(W/256), P*k)
+__global__ void vnp_edge_gather_add_kernel(const float* __restrict__ u, int ldu, const float* __restrict__ v, int ldv,
+                                           const int* __restrict__ nbr, int k, int W, float* __restrict__ out, int ldo)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    const size_t e = blockIdx.y, p = e / k, s = (size_t)nbr[e];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) out[(e * 3 + t) * ldo + c] = u[(s * 3 + t) * ldu + c] + v[(p * 3 + t) * ldv + c];
+}
+
+// out [Pout*3][ldo] : point i copies point src[i] (global point ids) of x
+extern "C" int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo)
+{
+    if (!x || !src || !out || Pout <= 0 || W <= 0) return VNP_EINVAL;
+    for (long long p0 = 0; p0 < Pout; p0 += 65535) {
+        const int n = (int)((Pout - p0) < 65535 ? (Pout - p0) : 65535);
+        hipLaunchKernelGGL(vnp_gather_points_kernel, dim3(vnp_cdiv(W, 256), n), dim3(256), 0, st, x, ldx, src + p0, W,
+                           out + (size_t)p0 * 3 * ldo, ldo);
+    }
+    return vnp_last_error();
+}
+
+// gx [Pin*3][ldgx] = 0; then gx[src[i]] += g[i] for i < Pout
+extern "C" int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* src, long long Pout, int W,
+                                      float* gx, int ldgx, long long Pin)
+{
+    if (!g || !src || !gx || Pout <= 0 || W <= 0 || Pin <= 0) return VNP_EINVAL;
+    hipError_t e = ldgx == W ? hipMemsetAsync(gx, 0, (size_t)Pin * 3 * W * 4, st)
+                             : hipMemset2DAsync(gx, (size_t)ldgx * 4, 0, (size_t)W * 4, (size_t)Pin * 3, st);
+    if (e != hipSuccess) return (int)e;
+    for (long long p0 = 0; p0 < Pout; p0 += 65535) {
+        const int n = (int)((Pout - p0) < 65535 ? (Pout - p0) : 65535);
+        hipLaunchKernelGGL(vnp_scatter_add_points_kernel, dim3(vnp_cdiv(W, 256), n), dim3(256), 0, st,
+                           g + (size_t)p0 * 3 * ldg, ldg, src + p0, W, gx, ldgx);
+    }
+    return vnp_last_error();
+}
+
+extern "C" int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr,
+                                   long long P, int k, int W, float* out, int ldo)
+{
+    if (!u || !v || !nbr || !out || P <= 0 || k <= 0 || W <= 0) return VNP_EINVAL;
+    const long long E = P * k;
+    const long long step = (65535 / k) * (long long)k;          // whole points per launch so that p = e / k stays valid
+    for (long long e0 = 0; e0 < E; e0 += step) {
+        const int n = (int)((E - e0) < step ? (E - e0) : step);
+        hipLaunchKernelGGL(vnp_edge_gather_add_kernel, dim3(vnp_cdiv(W, 256), n), dim3(256), 0, st, u, ldu,
+                           v + (size_t)(e0 / k) * 3 * ldv, ldv, nbr + e0, k, W, out + (size_t)e0 * 3 * ldo, ldo);
+    }
+    return vnp_last_error();
+}

@@ -1,0 +1,91 @@
+"""VN-DGCNN encoder with FPS down-sampling: reference class name, constructor signature and ``state_dict`` keys
+(/root/reference/models/dgcnn.py:164-324), on libvnpcc kernels (kNN, FPS, gathers, fp32-MFMA GEMMs, VN pointwise).
+
+EdgeConv restructuring (same math): the reference builds the edge tensor cat(feature - x, x) of shape [B,2C,3,N,k]
+(dgcnn.py:250-278) and applies W to it; here u = x W1^T and v = x (W2 - W1)^T are computed once per point and the edge
+pre-activations are u[neighbour] + v[centre] (ops.EdgeGatherAddFn): k/2 = 8x fewer GEMM FLOPs and no 2C-wide edge tensor.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .pcn import fps, rows_to_global
+from .vn_layers import VNLinear, VNLinearLeakyReLU, VNMaxPool, mean_pool
+
+
+def edge_conv_rows(layer: VNLinearLeakyReLU, x_rows, nbr, k):
+    """VNLinearLeakyReLU(2C -> C') on the kNN edge tensor followed by mean_pool over the k neighbours.
+    x_rows [P*3, C]; nbr [P,k] global neighbour ids.  Returns [P*3, C']."""
+    C = x_rows.shape[1]
+    Wf, Wd = layer.map_to_feat.weight, layer.map_to_dir.weight
+    Cout = Wf.shape[0]
+    Wu = torch.cat([Wf[:, :C], Wd[:, :C]], dim=0)                           # [2C', C]  (feat | dir)
+    Wv = torch.cat([Wf[:, C:] - Wf[:, :C], Wd[:, C:] - Wd[:, :C]], dim=0)
+    u = ops.VNLinearFn.apply(x_rows, Wu, None, 0)
+    v = ops.VNLinearFn.apply(x_rows, Wv, None, 0)
+    pd = ops.EdgeGatherAddFn.apply(u, v, nbr)                              # [P*k*3, 2C']
+    bn = layer.batchnorm.bn
+    layer.batchnorm._tick()
+    f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
+                              layer.negative_slope)                         # [P*k*3, C']
+    return ops.VNMeanPoolFn.apply(f, x_rows.shape[0] // 3, k)
+
+
+def knn_graph(coords, k):
+    """coords [B,N,3] -> global neighbour ids [B*N, k] int32 (no gradient, dgcnn.py:235-241)."""
+    B, N, _ = coords.shape
+    with torch.no_grad():
+        idx = ops.knn_indices(coords, coords, k)                           # [B,N,k] local
+        base = (torch.arange(B, device=coords.device, dtype=torch.int32) * N).view(B, 1, 1)
+        return (idx + base).reshape(B * N, k)
+
+
+def fps_downsample_rows(coords, f_rows, m):
+    """dgcnn.py:201-222: FPS on the coordinates, gather coordinates and features.  coords [B,N,3], f_rows [B*N*3, C]."""
+    B, N, _ = coords.shape
+    with torch.no_grad():
+        idx = ops.fps_indices(coords, m)                                   # [B,m]
+        gid = (idx + (torch.arange(B, device=coords.device, dtype=torch.int32) * N).view(B, 1)).reshape(-1)
+    new_coords = torch.gather(coords, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    return new_coords, ops.GatherPointsFn.apply(f_rows, gid)
+
+
+class VN_DGCNN_fps(nn.Module):
+    K = 16       # hard-coded in the reference (dgcnn.py:11,230,251); exposed as an attribute for the k=20 benchmark config
+
+    def __init__(self, config, only_coarse=False):
+        super().__init__()
+        self.num_coarse = config.num_coarse // 2 if config.num_coarse == 448 else config.num_coarse
+        self.k = getattr(config, "knn_k", self.K)
+        self.conv1 = nn.Sequential(VNLinearLeakyReLU(2, 32))
+        self.conv4 = VNLinearLeakyReLU(64, 64)
+        self.conv5 = VNLinearLeakyReLU(128, 128)
+        self.conv6 = VNLinearLeakyReLU(256, 512)
+        self.conv7 = nn.Sequential(VNLinearLeakyReLU(512, 1024, dim=4), VNLinear(1024, self.num_coarse))
+        self.pool1 = self.pool2 = self.pool3 = self.pool4 = mean_pool
+        self.pool5 = VNMaxPool(512)
+
+    def forward(self, x):
+        B, N, _ = x.shape
+        k = self.k
+        coords = x.contiguous().float()
+        f = coords.reshape(B * N * 3, 1)
+        f = edge_conv_rows(self.conv1[0], f, knn_graph(coords, k), k)                  # dynamic graph == coordinates here
+        coor_q, f_q = fps_downsample_rows(coords, f, 512)
+        nbr = knn_graph(coor_q, k)
+        f = edge_conv_rows(self.conv4, f_q, nbr, k)
+        f = edge_conv_rows(self.conv5, f, nbr, k)
+        coor_q, f_q = fps_downsample_rows(coor_q, f, 128)
+        f = edge_conv_rows(self.conv6, f_q, knn_graph(coor_q, k), k)                   # [B*128*3, 512]
+        g = self.pool5.forward_rows(f, B, 128)                                         # [B*3, 512]
+        h = self.conv7[0].forward_rows(g)
+        h = self.conv7[1].forward_rows(h)                                              # [B*3, Mc]
+        coarse = h.reshape(B, 3, self.num_coarse).permute(0, 2, 1).contiguous()
+        global_feature = rows_to_global(g, B)
+        if self.num_coarse == 224:
+            inp_sparse = fps(coords, 224)
+            coarse_cat = torch.cat([coarse, inp_sparse], dim=1).contiguous()
+            return (coarse, coarse_cat), global_feature
+        return coarse, global_feature

@@ -541,3 +541,85 @@ class ChamferFn(Function):
         gx2 = torch.empty_like(xyz2)
         call("vnp_chamfer_bwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(g1), ptr(idx1), ptr(g2), ptr(idx2), ptr(gx1), ptr(gx2))
         return gx1, gx2
+
+
+# ------------------------------------------------------------------------------- graph ops (configs 3, 5)
+def knn_indices(ref, query, k, return_dist=False):
+    """ref [B,Nr,D], query [B,Nq,D] (point-major, fp32, contiguous) -> idx [B,Nq,k] int32 local indices, sorted by
+    (squared distance, index).  Replaces KNN_CUDA (models/dgcnn.py:11,236)."""
+    _lib.require_gpu(ref, query)
+    ref, query = ref.contiguous().float(), query.contiguous().float()
+    B, Nr, D = ref.shape
+    Nq = query.shape[1]
+    idx = torch.empty((B, Nq, k), device=ref.device, dtype=torch.int32)
+    dist = torch.empty((B, Nq, k), device=ref.device, dtype=torch.float32) if return_dist else None
+    call("vnp_knn", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist))
+    return (idx, dist) if return_dist else idx
+
+
+def fps_indices(xyz, m):
+    """furthest_point_sample(xyz[B,N,3], m) -> idx [B,m] int32 (starts at 0).  Replaces pointnet2_ops (models/pcn.py:7)."""
+    _lib.require_gpu(xyz)
+    xyz = xyz.contiguous().float()
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, m), device=xyz.device, dtype=torch.int32)
+    call("vnp_fps", B, N, ptr(xyz), m, ptr(idx))
+    return idx
+
+
+class GatherPointsFn(Function):
+    """rows layout: out point i <- x point src[i] (global point ids, int32 [Pout]).  gather_operation of pointnet2_ops
+    (models/dgcnn.py:214-218) on VN features; backward = scatter-add."""
+
+    @staticmethod
+    def forward(ctx, x, src):
+        x = _rows(x)
+        src = src.reshape(-1).contiguous()
+        P_out, W = src.numel(), x.shape[1]
+        out = torch.empty((P_out * 3, W), device=x.device, dtype=torch.float32)
+        call("vnp_gather_points", ptr(x), _ld(x), ptr(src), P_out, W, ptr(out), W)
+        ctx.save_for_backward(src)
+        ctx.cfg = (x.shape[0] // 3, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (src,) = ctx.saved_tensors
+        P_in, W = ctx.cfg
+        g = _rows(g)
+        gx = torch.empty((P_in * 3, W), device=g.device, dtype=torch.float32)
+        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(src), src.numel(), W, ptr(gx), W, P_in)
+        return gx, None
+
+
+class EdgeGatherAddFn(Function):
+    """Edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278) after the layer's linear maps:
+    out[(p,j)] = u[nbr[p,j]] + v[p], with u = x W1^T and v = x (W2-W1)^T computed per POINT (k times fewer GEMM rows than
+    applying W to cat(feature - x, x) per EDGE).  nbr: global point ids [P,k] int32."""
+
+    @staticmethod
+    def forward(ctx, u, v, nbr):
+        u, v = _rows(u), _rows(v)
+        nbr = nbr.contiguous()
+        P, k = nbr.shape
+        W = u.shape[1]
+        out = torch.empty((P * k * 3, W), device=u.device, dtype=torch.float32)
+        call("vnp_edge_gather_add", ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), P, k, W, ptr(out), W)
+        ctx.save_for_backward(nbr)
+        ctx.cfg = (u.shape[0] // 3, P, k, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (nbr,) = ctx.saved_tensors
+        Pu, P, k, W = ctx.cfg
+        g = _rows(g)
+        dev = g.device
+        gu = torch.empty((Pu * 3, W), device=dev, dtype=torch.float32)
+        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(nbr), P * k, W, ptr(gu), W, Pu)
+        gv = torch.empty((P * 3, W), device=dev, dtype=torch.float32)
+        call("vnp_vn_mean_pool_fwd", ptr(g), _ld(g), P, k, W, ptr(gv), W)          # mean over k ...
+        gv.mul_(float(k))                                                          # ... times k = sum
+        return gu, gv, None
