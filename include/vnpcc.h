@@ -37,6 +37,16 @@ int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, cons
                     const float* grad_dist1, const int* idx1, const float* grad_dist2, const int* idx2,
                     float* grad_xyz1, float* grad_xyz2);
 
+/* ---- Earth Mover's Distance ---------------------------------------------------------------------------------------
+ * replaces emd_cuda.approxmatch_forward / matchcost_forward / matchcost_backward
+ *   (/root/reference/extensions/earth_movers_distance/emd.cpp:8-27, emd_kernel.cu:171-193, 257-279, 373-398).
+ * match [B,m,n] (zeroed here), temp B*(n+m)*2 floats, ws ceil(m/64)*B floats; outputs are written, not accumulated. */
+int vnp_emd_approxmatch(hipStream_t st, int B, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp);
+int vnp_emd_matchcost(hipStream_t st, int B, int n, int m, const float* xyz1, const float* xyz2, const float* match,
+                      float* cost, float* ws);
+int vnp_emd_matchcost_bwd(hipStream_t st, int B, int n, int m, const float* grad_cost, const float* xyz1, const float* xyz2,
+                          const float* match, float* grad1, float* grad2);
+
 /* ---- fp32 MFMA GEMM -----------------------------------------------------------------------------------------
  * replaces the x.transpose(1,-1) -> nn.Linear -> transpose chains of models/vn_layers.py:21,36,65,69,162 and their
  * autograd.  C[M,N] (+)= op(A) op(B) (+ A2 B2) (+ bias).
@@ -49,6 +59,25 @@ int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A2, int lda2, const float* B2, int ldb2, int K2,
              const float* bias, int ldbias, int rows_per_group,
              int accumulate, int nsplit, float* ws);
+
+/* nbatch independent products C_i = op(A_i) op(B_i), element strides bsa/bsb/bsc (attention: one per (sample, head)) */
+int vnp_gemm_batched(hipStream_t st, int op_a, int op_b, int M, int N, int K,
+                     const float* A, int lda, long long bsa, const float* B, int ldb, long long bsb,
+                     float* C, int ldc, long long bsc, int nbatch, int accumulate);
+
+/* ---- VN transformer pieces (models/transformer.py:25-106, models/vn_layers.py:129-150) ------------------------------
+ * VNLayerNorm: LayerNorm over the channel axis of the vector norms of each point; stats [P][2] = (mean, rstd) */
+int vnp_vn_layernorm_fwd(hipStream_t st, const float* x, int ldx, long long P, int C, const float* gamma, const float* beta,
+                         float* out, int ldo, float* stats);
+/* part [ceil(P/4)][2][C] partial (dgamma | dbeta) sums, reduce over the first axis with vnp_reduce_rows */
+int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, const float* x, int ldx, long long P, int C,
+                         const float* gamma, const float* beta, const float* stats, float* gx, int ldgx, float* part);
+/* rows [B*N*3][ld] <-> heads [B][H][N][(C/H)*3] (transformer.py:91-93: reshape(B,H,C/H,3,N).permute(0,1,4,2,3)) */
+int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads);
+int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int N, int C, int H, float* rows, int ld);
+/* S[R][L] <- softmax(S*scale) in place; backward: dP <- P*(dP - sum(dP*P))*scale */
+int vnp_softmax_fwd(hipStream_t st, float* S, long long R, int L, float scale);
+int vnp_softmax_bwd(hipStream_t st, const float* P, float* dP, long long R, int L, float scale);
 
 /* ---- VN BatchNorm / leaky projection ------------------------------------------------------------------------
  * VNBatchNorm (models/vn_layers.py:107-127), VNLeakyReLU (:25-43), VNLinearLeakyReLU tail (:66-73).

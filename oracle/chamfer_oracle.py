@@ -53,3 +53,29 @@ def chamfer_backward(xyz1, xyz2, gd1, gd2, idx1, idx2):
     i1 = np.ascontiguousarray(idx1, np.int32); i2 = np.ascontiguousarray(idx2, np.int32)
     lib().chamfer_oracle_backward(B, n, _p(a), m, _p(b), _p(_f(gd1)), _p(i1), _p(_f(gd2)), _p(i2), _p(g1), _p(g2))
     return g1, g2
+
+
+def emd_approxmatch(xyz1, xyz2):
+    """oracle/emd_oracle.c: xyz1 [B,n,3], xyz2 [B,m,3] -> match [B,m,n]."""
+    a, b = _f(xyz1), _f(xyz2)
+    B, n, _ = a.shape
+    m = b.shape[1]
+    match = np.empty((B, m, n), np.float32)
+    lib().emd_oracle_approxmatch(B, n, m, _p(a), _p(b), _p(match))
+    return match
+
+
+def emd_matchcost(xyz1, xyz2, match):
+    a, b, mt = _f(xyz1), _f(xyz2), _f(match)
+    B, n, _ = a.shape
+    cost = np.empty(B, np.float32)
+    lib().emd_oracle_matchcost(B, n, b.shape[1], _p(a), _p(b), _p(mt), _p(cost))
+    return cost
+
+
+def emd_matchcost_backward(grad_cost, xyz1, xyz2, match):
+    a, b, mt, gc = _f(xyz1), _f(xyz2), _f(match), _f(grad_cost)
+    B, n, _ = a.shape
+    g1, g2 = np.empty_like(a), np.empty_like(b)
+    lib().emd_oracle_matchcost_backward(B, n, b.shape[1], _p(gc), _p(a), _p(b), _p(mt), _p(g1), _p(g2))
+    return g1, g2

@@ -257,6 +257,61 @@ def vn_dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats
     return h.squeeze(-1).contiguous(), g
 
 
+# ------------------------------------------------------------- VN transformer / attention decoder
+def vn_attention(sd, prefix, vn_x, num_heads, scale):
+    """models/transformer.py:90-106 (Attention.forward).  vn_x [B,C,3,N]."""
+    B, C, _, N = vn_x.shape
+    H = num_heads
+
+    def heads(w):
+        return vn_linear(vn_x, sd[f"{prefix}.{w}.map_to_feat.weight"]).reshape(B, H, C // H, 3, N).permute(0, 1, 4, 2, 3).reshape(B, H, N, -1)
+    q, k, v = heads("proj_vnq"), heads("proj_vnk"), heads("proj_vnv")
+    attn = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B, N, C, 3).permute(0, 2, 3, 1)
+    return vn_linear(x, sd[f"{prefix}.proj_vn.map_to_feat.weight"])
+
+
+def vn_block(sd, prefix, x, num_heads, scale, training=True, new_stats=None):
+    """models/transformer.py:43-74 (VN_Block.forward, knn_index=None).  x [B,N,C*3] tokens."""
+    B, N, _ = x.shape
+    vn_x = x.transpose(1, 2).reshape(B, -1, 3, N)
+    norm_x = vn_layer_norm(vn_x, sd[f"{prefix}.norm1.layer_norm.weight"], sd[f"{prefix}.norm1.layer_norm.bias"])
+    vn_x = vn_x + vn_attention(sd, f"{prefix}.attn", norm_x, num_heads, scale)
+    n2 = vn_layer_norm(vn_x, sd[f"{prefix}.norm2.layer_norm.weight"], sd[f"{prefix}.norm2.layer_norm.bias"])
+    x_2 = _lin_leaky(sd, f"{prefix}.conv4", _lin_leaky(sd, f"{prefix}.conv3", n2, training, new_stats), training, new_stats)
+    vn_x = vn_x + x_2
+    return vn_x.reshape(B, -1, N).transpose(1, 2)
+
+
+def attention_vn_foldingnet_forward(sd, coarse, feature_global, training=True, grid_size=4, prefix="decoder", new_stats=None):
+    """models/pcn.py:462-520 (Attention_VN_FoldingNet.forward; rot is ignored by the reference)."""
+    p = prefix
+    bs, N, _ = coarse.shape
+    S = grid_size * grid_size
+    centers = coarse.unsqueeze(1).expand(-1, 384, -1, -1).reshape(bs, -1, N).transpose(2, 1)
+    fg = vn_linear(feature_global, sd[f"{p}.downsize_global.map_to_feat.weight"]).expand(-1, -1, -1, N).reshape(bs, -1, N).transpose(2, 1)
+    fg = fg + centers
+    for i in range(2):
+        fg = vn_block(sd, f"{p}.transformer.{i}", fg, 8, 1, training, new_stats)
+    fg = fg.reshape(bs, N, -1, 3).permute(0, 2, 3, 1)
+    dim = fg.shape[1]
+    x = fg.permute(0, 3, 1, 2).reshape(bs * N, -1, 3)
+    features = x.reshape(bs * N, dim, 3, 1).expand(-1, -1, -1, S)
+    lin = torch.linspace(-1., 1., steps=grid_size, dtype=torch.float)
+    a = lin.view(1, grid_size).expand(grid_size, grid_size).reshape(1, -1)
+    b = lin.view(grid_size, 1).expand(grid_size, grid_size).reshape(1, -1)
+    seed = torch.cat([a, b, torch.zeros_like(a)], dim=0).to(coarse).view(1, 1, 3, S).expand(bs * N, -1, -1, -1)
+
+    def fold(name, x):
+        h = _lin_leaky(sd, f"{p}.{name}.0", x, training, new_stats)
+        h = _lin_leaky(sd, f"{p}.{name}.1", h, training, new_stats)
+        return vn_linear(h, sd[f"{p}.{name}.2.map_to_feat.weight"])
+    fd1 = fold("vn_folding1", torch.cat([seed, features], dim=1))
+    fd2 = fold("vn_folding2", torch.cat([fd1, features], dim=1))
+    rel = fd2.reshape(bs, N, 3, -1)
+    return (rel + coarse.unsqueeze(-1)).transpose(2, 3).reshape(bs, -1, 3)
+
+
 # --------------------------------------------------------------------------- losses
 def chamfer_torch(a, b, chunk=1024):
     """Direct-form squared NN distances (same formula as chamfer3D.cu:33-36) in torch, per sample and in row chunks

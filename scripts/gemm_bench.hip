@@ -12,7 +12,7 @@ float run(const VnpGemmArgs& p0, int iters)
 {
     VnpGemmArgs p = p0;
     const int nk = (p.K + BK - 1) / BK;
-    p.tiles_per_split = nk;
+    p.tiles_per_split = nk; p.nsplit = 1; p.bsa = p.bsb = p.bsc = 0;
     dim3 grid(vnp_cdiv(p.M, BM) * vnp_cdiv(p.N, BN), 1), block(256);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((vnp_gemm_kernel<BM, BN, BK, AKC, BKC, DBUF, PRIO>), grid, block, 0, 0, p);

@@ -440,10 +440,99 @@ def main_dgcnn():
     npz("dgcnn_small.npz", **out)
 
 
+def main_attention():
+    """Section 6: Attention_VN_FoldingNet (BASELINE config 4 decoder) at reduced size: B=2, 128 centres -> 2048 points.
+    The decoder (two transformer blocks + two folding stages, 6 train-mode BatchNorms over few hundred samples) amplifies
+    fp32 rounding to ~1e-3 in the reference itself; the best-conditioned of 12 default-init seeds is kept together with
+    the reference's fp64 run as the yardstick."""
+    _standins()
+    from oracle import vn_oracle as O
+    from models.pcn import Attention_VN_FoldingNet
+    from types import SimpleNamespace
+    gen = torch.Generator().manual_seed(4242)
+    cfg = SimpleNamespace(num_coarse=128, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cpu")
+    coarse = 0.4 * (torch.rand(2, 128, 3, generator=gen) - 0.5)
+    fg = 0.3 * torch.randn(2, 2048, 3, 1, generator=gen)
+
+    def build(seed, dtype, sd=None):
+        torch.manual_seed(seed)
+        d = Attention_VN_FoldingNet(cfg)
+        if sd is not None:
+            d = d.to(dtype)
+            d.folding_seed = d.folding_seed.to(dtype)
+            d.load_state_dict({k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()})
+        return d.train()
+
+    best = (None, 1e9)
+    for seed in range(12):
+        dec = build(seed, torch.float32)
+        sd0 = {k: v.clone() for k, v in dec.state_dict().items()}
+        with torch.no_grad():
+            fine = dec(coarse, fg)
+            f64 = build(seed, torch.float64, sd0)(coarse.double(), fg.double())
+        d = (fine.double() - f64).abs().max().item()
+        print(f"attention decoder seed {seed}: reference fp32 vs fp64 max |fine| diff {d:.2e}")
+        if d < best[1]:
+            best = (seed, d)
+    chosen = best[0]
+    dec = build(chosen, torch.float32)
+    sd0 = {k: v.clone() for k, v in dec.state_dict().items()}
+    cr, fr = coarse.clone().requires_grad_(True), fg.clone().requires_grad_(True)
+    fine = dec(cr, fr)
+    with torch.no_grad():
+        f64 = build(chosen, torch.float64, sd0)(coarse.double(), fg.double())
+    gout = torch.randn(*fine.shape, generator=gen)
+    fine.backward(gout)
+    out = {"seed": chosen, "coarse": coarse, "fg": fg, "fine": fine, "fine64": f64, "g": gout, "gcoarse": cr.grad, "gfg": fr.grad}
+    names, norms, heads, wsum, wabs = [], [], [], [], []
+    for k, prm in dec.named_parameters():
+        names.append(k)
+        wsum.append(sd0[k].double().sum().item())
+        wabs.append(sd0[k].double().abs().sum().item())
+        if prm.grad is None:
+            norms.append(-1.0)
+            heads.append(np.zeros(16, np.float32))
+        else:
+            norms.append(prm.grad.double().norm().item())
+            hh = torch.zeros(16)
+            hh[:min(16, prm.numel())] = prm.grad.flatten()[:16]
+            heads.append(hh.numpy())
+    out.update({"grad_names": np.array(names), "grad_norms": np.array(norms), "grad_heads": np.stack(heads),
+                "weight_sum": np.array(wsum), "weight_abssum": np.array(wabs)})
+    for k, v in dec.state_dict().items():
+        if "running" in k:
+            out["after." + k] = v.clone()
+    # stage-level captures for teacher-forced checks (each stage alone is far better conditioned than the chain)
+    dec2 = build(chosen, torch.float32)
+    with torch.no_grad():
+        bs, N = 2, 128
+        centers = coarse.unsqueeze(1).expand(-1, 384, -1, -1).reshape(bs, -1, N).transpose(2, 1)
+        tok = dec2.downsize_global(fg).expand(-1, -1, -1, N).reshape(bs, -1, N).transpose(2, 1) + centers
+        b0 = dec2.transformer[0](tok)
+        b1 = dec2.transformer[1](b0)
+        feat = b1.reshape(bs, N, -1, 3).permute(0, 2, 3, 1).permute(0, 3, 1, 2).reshape(bs * N, -1, 3)
+        features = feat.view(bs * N, 384, 3, 1).expand(-1, -1, -1, 16)
+        seed_ = dec2.folding_seed.view(1, 1, 3, 16).expand(bs * N, -1, -1, -1)
+        fd1 = dec2.vn_folding1(torch.cat([seed_, features], dim=1))
+    out.update({"tok_in": tok, "blk0_out": b0, "blk1_out": b1, "fd1": fd1})
+    sdd = {"decoder." + k: v for k, v in sd0.items()}
+    check(O.vn_block(sdd, "decoder.transformer.0", tok, 8, 1, True), b0, "vn_block 0 (teacher-forced)", 1e-4)
+    check(O.vn_block(sdd, "decoder.transformer.1", b0, 8, 1, True), b1, "vn_block 1 (teacher-forced)", 1e-4)
+    fo = O.attention_vn_foldingnet_forward(sdd, coarse, fg, True)
+    gap = (fine.double() - f64).abs().max().item()
+    err = (fo - fine).abs().max().item()
+    print(f"attention decoder: oracle vs reference {err:.2e} (reference fp32 vs fp64 {gap:.2e})")
+    assert err <= max(10 * gap, 1e-3)
+    # single VN_Block / VNLayerNorm-level pins come from layers.npz (ln_*) and this end-to-end decoder
+    npz("attention_small.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "dgcnn":
-        main_dgcnn()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "base"):
         main()
+    if which in ("all", "dgcnn"):
         main_dgcnn()
+    if which in ("all", "attention"):
+        main_attention()

@@ -1,0 +1,148 @@
+"""BASELINE config 4 path: Earth Mover's Distance kernels vs the C oracle (oracle/emd_oracle.c — PARITY UNPINNED: the
+reference has no EMD test / CPU equivalent; tolerance 2e-4 relative because the reference and the HIP
+kernels use the fast __expf), VNLayerNorm / attention pieces vs float64 torch, and Attention_VN_FoldingNet vs
+tests/golden/attention_small.npz (reference run; stage-wise teacher-forced at 2e-4, end to end at
+max(10 x the reference's own fp32-vs-fp64 gap, 5e-3) — the chain amplifies rounding to ~1e-3 in the reference itself)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 256, 256), (1, 300, 150), (2, 128, 512), (1, 1024, 1024)])
+def test_emd_vs_c_oracle(lib_built, B, n, m):
+    from oracle import chamfer_oracle as CO
+    from vn_pointcloudcompletion_amd.emd import EarthMoverDistance
+    g = torch.Generator().manual_seed(n + m)
+    a = (torch.rand(B, n, 3, generator=g) - 0.5)
+    b = (torch.rand(B, m, 3, generator=g) - 0.5)
+    ar, br = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    cost = EarthMoverDistance()(ar, br)
+    match = CO.emd_approxmatch(a.numpy(), b.numpy())
+    ref_cost = CO.emd_matchcost(a.numpy(), b.numpy(), match)
+    assert relerr(cost, ref_cost) < 2e-4
+    gc = torch.rand(B, generator=g) + 0.5
+    (cost * gc.cuda()).sum().backward()
+    g1, g2 = CO.emd_matchcost_backward(gc.numpy(), a.numpy(), b.numpy(), match)
+    assert relerr(ar.grad, g1) < 5e-4 and relerr(br.grad, g2) < 5e-4
+
+
+def test_emd_surface(lib_built):
+    from vn_pointcloudcompletion_amd import _lib
+    from vn_pointcloudcompletion_amd.emd import EarthMoverDistance
+    from vn_pointcloudcompletion_amd.loss import emd_loss
+    a, b = torch.rand(64, 3).cuda(), torch.rand(64, 3).cuda()
+    assert EarthMoverDistance()(a, b).shape == (1,)                          # 2-D inputs are unsqueezed (emd.py:38-41)
+    assert emd_loss(a[None], b[None]).dim() == 0
+    assert EarthMoverDistance()(a, a).item() < 1e-4                          # identical clouds: zero transport cost
+    with pytest.raises(_lib.VnpError):
+        EarthMoverDistance()(torch.rand(1, 8, 3), torch.rand(1, 8, 3))       # CPU tensors: no fallback
+
+
+def test_layernorm_module_vs_golden(lib_built):
+    from vn_pointcloudcompletion_amd.vn_layers import VNLayerNorm
+    G = load_golden("layers.npz")
+    m = VNLayerNorm(G["ln_gamma"].shape[0])
+    m.layer_norm.weight.data.copy_(torch.as_tensor(G["ln_gamma"]))
+    m.layer_norm.bias.data.copy_(torch.as_tensor(G["ln_beta"]))
+    m = m.cuda()
+    x = t(G["x_d4"]).requires_grad_(True)
+    y = m(x)
+    assert relerr(y, G["ln_y"]) < 3e-5
+    y.backward(t(G["ln_g"]))
+    assert relerr(x.grad, G["ln_gx"]) < 1e-4
+    assert relerr(m.layer_norm.weight.grad, G["ln_ggamma"]) < 3e-5 and relerr(m.layer_norm.bias.grad, G["ln_gbeta"]) < 3e-5
+
+
+def test_batched_gemm_and_attention_core(lib_built):
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(1)
+    A, Bm = torch.randn(6, 70, 40, generator=g).cuda(), torch.randn(6, 50, 40, generator=g).cuda()
+    assert relerr(ops.gemm_batched(A, Bm), A.double() @ Bm.double().transpose(1, 2)) < 2e-5
+    Bn = torch.randn(6, 40, 33, generator=g).cuda()
+    assert relerr(ops.gemm_batched(A, Bn, op_b=1), A.double() @ Bn.double()) < 2e-5
+    At = torch.randn(6, 40, 70, generator=g).cuda()
+    assert relerr(ops.gemm_batched(At, Bn, op_a=1, op_b=1), At.double().transpose(1, 2) @ Bn.double()) < 2e-5
+    # attention core vs float64 torch (models/transformer.py:91-104)
+    B, N, C, H, scale = 2, 37, 24, 4, 0.7
+    q, k, v = (torch.randn(B * N * 3, C, generator=g).cuda().requires_grad_(True) for _ in range(3))
+    out = ops.VNAttentionFn.apply(q, k, v, B, N, H, scale)
+    go = torch.randn(B * N * 3, C, generator=g).cuda()
+    out.backward(go)
+
+    def heads(r):
+        return r.double().reshape(B, N, 3, H, C // H).permute(0, 3, 1, 4, 2).reshape(B, H, N, -1)
+    qd, kd, vd = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
+    o = ((heads(qd) @ heads(kd).transpose(-1, -2)) * scale).softmax(-1) @ heads(vd)
+    o = o.reshape(B, H, N, C // H, 3).permute(0, 2, 4, 1, 3).reshape(B * N * 3, C)
+    assert relerr(out, o) < 2e-5
+    o.backward(go.double())
+    assert relerr(q.grad, qd.grad) < 5e-5 and relerr(k.grad, kd.grad) < 5e-5 and relerr(v.grad, vd.grad) < 5e-5
+
+
+@pytest.fixture(scope="module")
+def A(lib_built):
+    return load_golden("attention_small.npz")
+
+
+def _build(A):
+    from vn_pointcloudcompletion_amd.attention_decoder import Attention_VN_FoldingNet
+    torch.manual_seed(int(A["seed"]))
+    dec = Attention_VN_FoldingNet(SimpleNamespace(num_coarse=128, latent_dim=2048))
+    names = [k for k, _ in dec.named_parameters()]
+    assert names == list(A["grad_names"])
+    for (k, p), s, a in zip(dec.named_parameters(), A["weight_sum"], A["weight_abssum"]):
+        assert abs(p.double().sum().item() - s) <= 1e-9 * max(1.0, a), k
+    return dec.cuda().train()
+
+
+def test_vn_blocks_teacher_forced(A):
+    dec = _build(A)
+    with torch.no_grad():
+        b0 = dec.transformer[0](t(A["tok_in"]))
+        b1 = dec.transformer[1](t(A["blk0_out"]))
+    assert relerr(b0, A["blk0_out"]) < 2e-4
+    assert relerr(b1, A["blk1_out"]) < 2e-4
+
+
+def test_attention_decoder_matches_reference(A):
+    dec = _build(A)
+    coarse, fg = t(A["coarse"]).requires_grad_(True), t(A["fg"]).requires_grad_(True)
+    fine = dec(coarse, fg)
+    assert fine.shape == (2, 2048, 3)
+    gap = np.abs(A["fine"].astype(np.float64) - A["fine64"]).max()
+    tol = max(10 * gap, 5e-3)
+    assert (fine.detach().cpu().double() - torch.as_tensor(A["fine64"])).abs().max().item() < tol
+    fine.backward(t(A["g"]))
+    bad = []
+    for (k, prm), n in zip(dec.named_parameters(), A["grad_norms"]):
+        if n < 0:
+            assert prm.grad is None, k                     # final_conv, attn.qkv/proj, conv1/conv2 are never used
+            continue
+        if abs(prm.grad.double().norm().item() - n) > 5e-2 * n:
+            bad.append((k, prm.grad.double().norm().item(), n))
+    assert not bad, bad
+    assert relerr(coarse.grad, A["gcoarse"]) < 5e-2 and relerr(fg.grad, A["gfg"]) < 5e-2
+
+
+def test_pcnnet_config4_step(lib_built):
+    """vn_pointnet + attention_vn_foldingnet + EMD coarse loss: one optimizer step runs and every used parameter moves."""
+    from vn_pointcloudcompletion_amd.model import PCNNet
+    from vn_pointcloudcompletion_amd.optim import FusedAdam
+    from vn_pointcloudcompletion_amd.train import train_step
+    torch.manual_seed(0)
+    cfg = SimpleNamespace(num_coarse=64, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cuda",
+                          coarse_loss="emd", dcd_opts={"alpha": 200, "lambda": 0.5})
+    net = PCNNet(cfg, "vn_pointnet", "attention_vn_foldingnet").train()
+    opt = FusedAdam(net.parameters(), lr=1e-3)
+    p = torch.rand(2, 256, 3, device="cuda") - 0.5
+    c = torch.rand(2, 1024, 3, device="cuda") - 0.5
+    before = net.decoder.vn_folding2[2].map_to_feat.weight.detach().clone()
+    loss, l1, l2 = train_step(cfg, net, opt, p, c)
+    assert torch.isfinite(loss) and l1.item() > 0 and l2.item() > 0
+    assert not torch.equal(before, net.decoder.vn_folding2[2].map_to_feat.weight)

@@ -61,7 +61,17 @@ _vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_fl
 _SIGNATURES = {
     "vnp_chamfer_fwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_chamfer_bwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vnp_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp],
+    "vnp_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "vnp_emd_matchcost_bwd": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_gemm": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "vnp_gemm_batched": [_i, _i, _i, _i, _i, _vp, _i, _ll, _vp, _i, _ll, _vp, _i, _ll, _i, _i],
+    "vnp_vn_layernorm_fwd": [_vp, _i, _ll, _i, _vp, _vp, _vp, _i, _vp],
+    "vnp_vn_layernorm_bwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "vnp_rows_to_heads": [_vp, _i, _i, _i, _i, _i, _vp],
+    "vnp_heads_to_rows": [_vp, _i, _i, _i, _i, _vp, _i],
+    "vnp_softmax_fwd": [_vp, _ll, _i, _f],
+    "vnp_softmax_bwd": [_vp, _vp, _ll, _i, _f],
     "vnp_vn_norm_stats": [_vp, _i, _ll, _i, _vp],
     "vnp_vn_bn_finalize": [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _f, _f],
     "vnp_rstd_from_var": [_vp, _vp, _i, _f],

@@ -1,0 +1,196 @@
+// Kernels for the VN transformer blocks (models/transformer.py:25-106, models/pointr/vn_pointr.py:101-160, 366-412):
+//   VNLayerNorm (models/vn_layers.py:129-150)  : LayerNorm over the CHANNEL axis of the vector norms, per point
+//   rows <-> heads layout change               : [B*N*3, C] rows  <->  [B, H, N, (C/H)*3] tokens (transformer.py:91-93,103)
+//   row softmax forward / backward             : attn = softmax(q k^T * scale) (transformer.py:98-99)
+// The two attention matrix products run on the batched fp32-MFMA GEMM (vnp_gemm_batched).  All kernels are HBM-bound.
+#include "vnp_common.h"
+
+#define LN_EPS 1e-5f
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per point (4 points per block).  stats[pt] = (mean, rstd) of the C norms of that point.
+__global__ void __launch_bounds__(256) vnp_ln_fwd_kernel(const float* __restrict__ x, int ldx, long long P, int C,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out, int ldo, float2* __restrict__ stats)
+{
+    const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pt >= P) return;
+    const float* r = x + (size_t)pt * 3 * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += sqrtf(r[c] * r[c] + r[ldx + c] * r[ldx + c] + r[2 * ldx + c] * r[2 * ldx + c]) + VNP_EPS;
+    const float mean = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float n = sqrtf(r[c] * r[c] + r[ldx + c] * r[ldx + c] + r[2 * ldx + c] * r[2 * ldx + c]) + VNP_EPS;
+        v += (n - mean) * (n - mean);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)C + LN_EPS);
+    float* o = out + (size_t)pt * 3 * ldo;
+    for (int c = lane; c < C; c += 64) {
+        const float x0 = r[c], x1 = r[ldx + c], x2 = r[2 * ldx + c];
+        const float n = sqrtf(x0 * x0 + x1 * x1 + x2 * x2) + VNP_EPS;
+        const float sc = ((n - mean) * rstd * gamma[c] + beta[c]) / n;
+        o[c] = x0 * sc; o[ldo + c] = x1 * sc; o[2 * ldo + c] = x2 * sc;
+    }
+    if (lane == 0 && stats) stats[pt] = make_float2(mean, rstd);
+}
+
+// Backward: gx, and per-block partial sums of dgamma / dbeta (part[block][2][C]).
+__global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict__ go, int ldgo, const float* __restrict__ x, int ldx,
+                                                        long long P, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float2* __restrict__ stats, float* __restrict__ gx, int ldgx,
+                                                        float* __restrict__ part)
+{
+    extern __shared__ float sm[];                 // [4 waves][2][C]
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long pt = (long long)blockIdx.x * 4 + w;
+    float* my = sm + (size_t)w * 2 * C;
+    for (int c = lane; c < C; c += 64) { my[c] = 0.f; my[C + c] = 0.f; }
+    if (pt < P) {
+        const float* r = x + (size_t)pt * 3 * ldx;
+        const float* g = go + (size_t)pt * 3 * ldgo;
+        const float mean = stats[pt].x, rstd = stats[pt].y;
+        // sums over channels of gamma*g_nl and gamma*g_nl*xhat
+        float a = 0.f, b = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float x0 = r[c], x1 = r[ldx + c], x2 = r[2 * ldx + c];
+            const float n = sqrtf(x0 * x0 + x1 * x1 + x2 * x2) + VNP_EPS;
+            const float xh = (n - mean) * rstd;
+            const float gnl = (g[c] * x0 + g[ldgo + c] * x1 + g[2 * ldgo + c] * x2) / n;
+            a += gamma[c] * gnl; b += gamma[c] * gnl * xh;
+            my[c] = gnl * xh; my[C + c] = gnl;               // dgamma, dbeta contributions of this point
+        }
+        a = wave_sum(a) / (float)C; b = wave_sum(b) / (float)C;
+        float* o = gx + (size_t)pt * 3 * ldgx;
+        for (int c = lane; c < C; c += 64) {
+            const float x0 = r[c], x1 = r[ldx + c], x2 = r[2 * ldx + c];
+            const float pn = sqrtf(x0 * x0 + x1 * x1 + x2 * x2), n = pn + VNP_EPS;
+            const float xh = (n - mean) * rstd;
+            const float nl = xh * gamma[c] + beta[c];
+            const float g0 = g[c], g1 = g[ldgo + c], g2 = g[2 * ldgo + c];
+            const float gs = g0 * x0 + g1 * x1 + g2 * x2;
+            const float gnl = gs / n;
+            const float gn = rstd * (gamma[c] * gnl - a - xh * b) - gs * nl / (n * n);
+            const float sc = nl / n, kk = pn > 0.f ? gn / pn : 0.f;
+            o[c] = sc * g0 + kk * x0; o[ldgx + c] = sc * g1 + kk * x1; o[2 * ldgx + c] = sc * g2 + kk * x2;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        part[(size_t)blockIdx.x * 2 * C + i] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
+}
+
+// heads[((b*H + h)*N + n)*Dh + cl*3 + t] = rows[((b*N + n)*3 + t)*ld + h*(C/H) + cl],  Dh = (C/H)*3
+__global__ void vnp_rows_to_heads_kernel(const float* __restrict__ rows, int ld, int B, int N, int C, int H, float* __restrict__ heads)
+{
+    const int ch = C / H, Dh = ch * 3;
+    const long long total = (long long)B * N * 3 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long long k = i / C;
+        const int t = (int)(k % 3); k /= 3;
+        const int n = (int)(k % N); const int b = (int)(k / N);
+        const int h = c / ch, cl = c % ch;
+        heads[(((size_t)b * H + h) * N + n) * Dh + cl * 3 + t] = rows[(((size_t)b * N + n) * 3 + t) * ld + c];
+    }
+}
+
+__global__ void vnp_heads_to_rows_kernel(const float* __restrict__ heads, int B, int N, int C, int H, float* __restrict__ rows, int ld)
+{
+    const int ch = C / H, Dh = ch * 3;
+    const long long total = (long long)B * N * 3 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long long k = i / C;
+        const int t = (int)(k % 3); k /= 3;
+        const int n = (int)(k % N); const int b = (int)(k / N);
+        const int h = c / ch, cl = c % ch;
+        rows[(((size_t)b * N + n) * 3 + t) * ld + c] = heads[(((size_t)b * H + h) * N + n) * Dh + cl * 3 + t];
+    }
+}
+
+// in-place row softmax of S[R][L] * scale; one wave per row
+__global__ void __launch_bounds__(256) vnp_softmax_fwd_kernel(float* __restrict__ S, long long R, int L, float scale)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float* row = S + (size_t)r * L;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, row[j] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) { const float e = expf(row[j] * scale - mx); row[j] = e; s += e; }
+    const float inv = 1.0f / wave_sum(s);
+    for (int j = lane; j < L; j += 64) row[j] *= inv;
+}
+
+// dS = P * (dP - sum_j dP*P) * scale, written over dP
+__global__ void __launch_bounds__(256) vnp_softmax_bwd_kernel(const float* __restrict__ Pm, float* __restrict__ dP, long long R, int L, float scale)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* p = Pm + (size_t)r * L;
+    float* d = dP + (size_t)r * L;
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) s += d[j] * p[j];
+    s = wave_sum(s);
+    for (int j = lane; j < L; j += 64) d[j] = p[j] * (d[j] - s) * scale;
+}
+
+extern "C" int vnp_vn_layernorm_fwd(hipStream_t st, const float* x, int ldx, long long P, int C, const float* gamma, const float* beta,
+                                    float* out, int ldo, float* stats)
+{
+    if (!x || !gamma || !beta || !out || P <= 0 || C <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_ln_fwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), 0, st, x, ldx, P, C, gamma, beta, out, ldo, (float2*)stats);
+    return vnp_last_error();
+}
+
+// part: ceil(P/4) * 2 * C floats ([block][dgamma | dbeta][C]); the caller reduces it over the blocks
+extern "C" int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, const float* x, int ldx, long long P, int C,
+                                    const float* gamma, const float* beta, const float* stats, float* gx, int ldgx, float* part)
+{
+    if (!go || !x || !gamma || !beta || !stats || !gx || !part || P <= 0 || C <= 0 || C > 4096) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_ln_bwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), (size_t)8 * C * 4, st, go, ldgo, x, ldx, P, C, gamma, beta,
+                       (const float2*)stats, gx, ldgx, part);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads)
+{
+    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H) return VNP_EINVAL;
+    const long long total = (long long)B * N * 3 * C;
+    hipLaunchKernelGGL(vnp_rows_to_heads_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
+                       rows, ld, B, N, C, H, heads);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int N, int C, int H, float* rows, int ld)
+{
+    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H) return VNP_EINVAL;
+    const long long total = (long long)B * N * 3 * C;
+    hipLaunchKernelGGL(vnp_heads_to_rows_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
+                       heads, B, N, C, H, rows, ld);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_softmax_fwd(hipStream_t st, float* S, long long R, int L, float scale)
+{
+    if (!S || R <= 0 || L <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_softmax_fwd_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, S, R, L, scale);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_softmax_bwd(hipStream_t st, const float* Pm, float* dP, long long R, int L, float scale)
+{
+    if (!Pm || !dP || R <= 0 || L <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_softmax_bwd_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, Pm, dP, R, L, scale);
+    return vnp_last_error();
+}

@@ -33,23 +33,26 @@ __global__ void vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit
 // op_a: 0 = A is [M, K] row-major (K contiguous), 1 = A is [K, M] row-major (M contiguous)
 // op_b: 0 = B is [N, K] row-major (K contiguous), 1 = B is [K, N] row-major (N contiguous)
 // nsplit > 1: split-K; `ws` must hold nsplit * M * N floats; the result is reduced into C afterwards.
-extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
-                        const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                        const float* A2, int lda2, const float* B2, int ldb2, int K2,
-                        const float* bias, int ldbias, int rows_per_group,
-                        int accumulate, int nsplit, float* ws)
+static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
+                         const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         const float* A2, int lda2, const float* B2, int ldb2, int K2,
+                         const float* bias, int ldbias, int rows_per_group,
+                         int accumulate, int nsplit, float* ws,
+                         int nbatch, long long bsa, long long bsb, long long bsc)
 {
     if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return VNP_EINVAL;
     if (K2 > 0 && (!A2 || !B2)) return VNP_EINVAL;
     if (bias && rows_per_group <= 0) return VNP_EINVAL;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1 && !ws) return VNP_EINVAL;
+    if (nbatch < 1 || (nbatch > 1 && (nsplit > 1 || K2 > 0))) return VNP_EINVAL;
     constexpr int BK = 32;
     VnpGemmArgs p;
     p.A = A; p.B = B; p.A2 = A2; p.B2 = B2; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.K2 = K2 > 0 ? K2 : 0;
     p.lda = lda; p.ldb = ldb; p.lda2 = lda2; p.ldb2 = ldb2; p.ldbias = ldbias;
     p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+    p.bsa = bsa; p.bsb = bsb; p.bsc = bsc;
     const int nk = vnp_cdiv(K, BK) + (p.K2 ? vnp_cdiv(p.K2, BK) : 0);
     if (nsplit > nk) nsplit = nk > 0 ? nk : 1;
     p.tiles_per_split = vnp_cdiv(nk > 0 ? nk : 1, nsplit);
@@ -60,22 +63,23 @@ extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, in
     } else {
         p.C = C; p.ldc = ldc; p.slab = 0; p.accumulate = accumulate;
     }
-    const bool big_m = (op_a == 0);      // activations on the M side: 192-row tiles; weight gradients: 128
+    p.nsplit = nsplit;
+    const int gy = nsplit * nbatch;
+    if (gy > 65535) return VNP_EINVAL;
     dim3 block(256);
     if (op_a == 0 && op_b == 0) {
-        dim3 grid(vnp_cdiv(M, 192) * vnp_cdiv(N, 128), nsplit);
+        dim3 grid(vnp_cdiv(M, 192) * vnp_cdiv(N, 128), gy);
         hipLaunchKernelGGL((vnp_gemm_kernel<192, 128, BK, true, true>), grid, block, 0, stream, p);
     } else if (op_a == 0 && op_b == 1) {
-        dim3 grid(vnp_cdiv(M, 192) * vnp_cdiv(N, 128), nsplit);
+        dim3 grid(vnp_cdiv(M, 192) * vnp_cdiv(N, 128), gy);
         hipLaunchKernelGGL((vnp_gemm_kernel<192, 128, BK, true, false>), grid, block, 0, stream, p);
     } else if (op_a == 1 && op_b == 1) {
-        dim3 grid(vnp_cdiv(M, 128) * vnp_cdiv(N, 128), nsplit);
+        dim3 grid(vnp_cdiv(M, 128) * vnp_cdiv(N, 128), gy);
         hipLaunchKernelGGL((vnp_gemm_kernel<128, 128, BK, false, false>), grid, block, 0, stream, p);
     } else {
-        dim3 grid(vnp_cdiv(M, 128) * vnp_cdiv(N, 128), nsplit);
+        dim3 grid(vnp_cdiv(M, 128) * vnp_cdiv(N, 128), gy);
         hipLaunchKernelGGL((vnp_gemm_kernel<128, 128, BK, false, true>), grid, block, 0, stream, p);
     }
-    (void)big_m;
     int rc = vnp_last_error();
     if (rc) return rc;
     if (nsplit > 1) {
@@ -87,4 +91,23 @@ extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, in
         rc = vnp_last_error();
     }
     return rc;
+}
+
+extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
+                        const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                        const float* A2, int lda2, const float* B2, int ldb2, int K2,
+                        const float* bias, int ldbias, int rows_per_group,
+                        int accumulate, int nsplit, float* ws)
+{
+    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, A2, lda2, B2, ldb2, K2, bias, ldbias, rows_per_group,
+                         accumulate, nsplit, ws, 1, 0, 0, 0);
+}
+
+// nbatch independent products C_i = op(A_i) op(B_i) with element strides bsa / bsb / bsc (attention: one per (sample, head))
+extern "C" int vnp_gemm_batched(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
+                                const float* A, int lda, long long bsa, const float* B, int ldb, long long bsb,
+                                float* C, int ldc, long long bsc, int nbatch, int accumulate)
+{
+    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0,
+                         accumulate, 1, nullptr, nbatch, bsa, bsb, bsc);
 }

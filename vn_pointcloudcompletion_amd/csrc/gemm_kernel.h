@@ -12,6 +12,8 @@ struct VnpGemmArgs {
     int accumulate;                      // C += result instead of C = result
     int tiles_per_split;                 // K-tiles handled by one blockIdx.y
     long long slab;                      // elements between the output slabs of consecutive splits
+    int nsplit;                          // gridDim.y = nsplit * nbatch: blockIdx.y = batch * nsplit + split
+    long long bsa, bsb, bsc;             // batch strides (elements) of A, B, C (batched GEMM: attention heads)
 };
 
 template <int R, int BK, bool KC, int NV>
@@ -112,7 +114,8 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
     const int nk1 = (p.K + BK - 1) / BK;
     const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
     const int nk = nk1 + nk2;
-    const int kt0 = blockIdx.y * p.tiles_per_split;
+    const int split = blockIdx.y % p.nsplit, batch = blockIdx.y / p.nsplit;
+    const int kt0 = split * p.tiles_per_split;
     const int kt1 = min(nk, kt0 + p.tiles_per_split);
 
     const bool va1 = ((p.lda & 3) == 0) && ((((uintptr_t)p.A) & 15) == 0);
@@ -139,8 +142,10 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
         vnp_tile_offsets<BM, BK, AKC>(oa2, sa2, p.lda2, tid);
         vnp_tile_offsets<BN, BK, BKC>(ob2, sb2, p.ldb2, tid);
     }
-    const float* bA1 = AKC ? p.A + (size_t)m0 * p.lda : p.A + m0;
-    const float* bB1 = BKC ? p.B + (size_t)n0 * p.ldb : p.B + n0;
+    const float* pA = p.A + (size_t)batch * p.bsa;
+    const float* pB = p.B + (size_t)batch * p.bsb;
+    const float* bA1 = AKC ? pA + (size_t)m0 * p.lda : pA + m0;
+    const float* bB1 = BKC ? pB + (size_t)n0 * p.ldb : pB + n0;
     const float* bA2 = nk2 ? (AKC ? p.A2 + (size_t)m0 * p.lda2 : p.A2 + m0) : nullptr;
     const float* bB2 = nk2 ? (BKC ? p.B2 + (size_t)n0 * p.ldb2 : p.B2 + n0) : nullptr;
 
@@ -149,9 +154,9 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
             const int k0 = kt * BK;
             const bool full = k0 + BK <= p.K;
             if (fa1 && full) vnp_load_tile_fast<AV>(ra, AKC ? bA1 + k0 : bA1 + (size_t)k0 * p.lda, oa1, sa1);
-            else vnp_load_tile<BM, BK, AKC, AV>(ra, p.A, p.lda, m0, p.M, k0, p.K, va1, tid);
+            else vnp_load_tile<BM, BK, AKC, AV>(ra, pA, p.lda, m0, p.M, k0, p.K, va1, tid);
             if (fb1 && full) vnp_load_tile_fast<BV>(rb, BKC ? bB1 + k0 : bB1 + (size_t)k0 * p.ldb, ob1, sb1);
-            else vnp_load_tile<BN, BK, BKC, BV>(rb, p.B, p.ldb, n0, p.N, k0, p.K, vb1, tid);
+            else vnp_load_tile<BN, BK, BKC, BV>(rb, pB, p.ldb, n0, p.N, k0, p.K, vb1, tid);
         } else {
             const int k0 = (kt - nk1) * BK;
             const bool full = k0 + BK <= p.K2;
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* Cz = p.C + (size_t)blockIdx.y * p.slab;
+    float* Cz = p.C + (size_t)split * p.slab + (size_t)batch * p.bsc;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -623,3 +623,92 @@ class EdgeGatherAddFn(Function):
         call("vnp_vn_mean_pool_fwd", ptr(g), _ld(g), P, k, W, ptr(gv), W)          # mean over k ...
         gv.mul_(float(k))                                                          # ... times k = sum
         return gu, gv, None
+
+
+# ------------------------------------------------------------------------------- transformer ops (configs 4, 5)
+def gemm_batched(A, B, *, op_a=0, op_b=0, out=None):
+    """A, B: 3-D contiguous [nbatch, ., .]; C_i = op(A_i) op(B_i)."""
+    _lib.require_gpu(A, B)
+    A, B = A.contiguous(), B.contiguous()
+    nb = A.shape[0]
+    M, K = (A.shape[1], A.shape[2]) if op_a == 0 else (A.shape[2], A.shape[1])
+    N = B.shape[1] if op_b == 0 else B.shape[2]
+    if out is None:
+        out = torch.empty((nb, M, N), device=A.device, dtype=torch.float32)
+    call("vnp_gemm_batched", op_a, op_b, M, N, K, ptr(A), A.shape[2], A.shape[1] * A.shape[2], ptr(B), B.shape[2],
+         B.shape[1] * B.shape[2], ptr(out), N, M * N, nb, 0)
+    return out
+
+
+def _to_heads(rows, B, N, H):
+    C = rows.shape[1]
+    heads = torch.empty((B * H, N, (C // H) * 3), device=rows.device, dtype=torch.float32)
+    call("vnp_rows_to_heads", ptr(rows), _ld(rows), B, N, C, H, ptr(heads))
+    return heads
+
+
+def _from_heads(heads, B, N, C, H):
+    rows = torch.empty((B * N * 3, C), device=heads.device, dtype=torch.float32)
+    call("vnp_heads_to_rows", ptr(heads), B, N, C, H, ptr(rows), C)
+    return rows
+
+
+class VNAttentionFn(Function):
+    """softmax(q k^T * scale) v over tokens whose features are the flattened (C/H, 3) vectors of each head
+    (models/transformer.py:91-104).  q, k, v: rows [B*N*3, C].  The two matrix products are batched fp32-MFMA GEMMs."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, N, H, scale):
+        q, k, v = _rows(q), _rows(k), _rows(v)
+        C = q.shape[1]
+        qh, kh, vh = _to_heads(q, B, N, H), _to_heads(k, B, N, H), _to_heads(v, B, N, H)
+        P = gemm_batched(qh, kh)                                      # [B*H, N, N] scores
+        call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
+        oh = gemm_batched(P, vh, op_b=1)                               # [B*H, N, Dh]
+        ctx.save_for_backward(qh, kh, vh, P)
+        ctx.cfg = (B, N, C, H, float(scale))
+        return _from_heads(oh, B, N, C, H)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        qh, kh, vh, P = ctx.saved_tensors
+        B, N, C, H, scale = ctx.cfg
+        goh = _to_heads(_rows(go), B, N, H)
+        dP = gemm_batched(goh, vh)                                     # [B*H, N, N]
+        dvh = gemm_batched(P, goh, op_a=1, op_b=1)                     # P^T goh
+        call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
+        dqh = gemm_batched(dP, kh, op_b=1)
+        dkh = gemm_batched(dP, qh, op_a=1, op_b=1)
+        return (_from_heads(dqh, B, N, C, H), _from_heads(dkh, B, N, C, H), _from_heads(dvh, B, N, C, H),
+                None, None, None, None)
+
+
+class VNLayerNormFn(Function):
+    """VNLayerNorm (models/vn_layers.py:129-150) on the rows layout."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x = _rows(x)
+        R, C = x.shape
+        P = R // 3
+        out = torch.empty((R, C), device=x.device, dtype=torch.float32)
+        stats = torch.empty((P, 2), device=x.device, dtype=torch.float32)
+        call("vnp_vn_layernorm_fwd", ptr(x), _ld(x), P, C, ptr(gamma), ptr(beta), ptr(out), C, ptr(stats))
+        ctx.save_for_backward(x, gamma, beta, stats)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, gamma, beta, stats = ctx.saved_tensors
+        go = _rows(go)
+        R, C = x.shape
+        P = R // 3
+        nblk = (P + 3) // 4
+        nblk_pad = (nblk + 255) // 256 * 256 if nblk > 1024 else nblk
+        gx = torch.empty((R, C), device=x.device, dtype=torch.float32)
+        part = (torch.zeros if nblk_pad != nblk else torch.empty)((nblk_pad, 2 * C), device=x.device, dtype=torch.float32)
+        call("vnp_vn_layernorm_bwd", ptr(go), _ld(go), ptr(x), _ld(x), P, C, ptr(gamma), ptr(beta), ptr(stats), ptr(gx), C, ptr(part))
+        gb = reduce_rows(part, 1, nblk_pad, 2 * C)[0]
+        return gx, gb[:C].contiguous(), gb[C:].contiguous()

@@ -98,6 +98,21 @@ class VNBatchNorm(nn.Module):
         return from_rows(self.forward_rows(rows), meta)
 
 
+class VNLayerNorm(nn.Module):
+    """models/vn_layers.py:129-150."""
+
+    def __init__(self, num_features):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(num_features)
+
+    def forward_rows(self, rows):
+        return ops.VNLayerNormFn.apply(rows, self.layer_norm.weight, self.layer_norm.bias)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        return from_rows(self.forward_rows(rows), meta)
+
+
 class VNLinearLeakyReLU(nn.Module):
     """models/vn_layers.py:46-74 (direction computed from the layer input)."""
 
@@ -110,9 +125,10 @@ class VNLinearLeakyReLU(nn.Module):
         self.batchnorm = VNBatchNorm(out_channels, dim=dim)
         self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
 
-    def forward_rows(self, rows, global_rows=None, rows_per_group=0):
-        """``global_rows`` [B*3, Cg]: per-sample features standing for the first Cg input channels, i.e. the layer acts
-        on cat([global.expand(N), x], dim=1) (models/pcn.py:172) without materialising the broadcast."""
+    def forward_rows(self, rows, global_rows=None, rows_per_group=0, global_first=True):
+        """``global_rows`` [G*3, Cg]: per-group features standing for Cg of the input channels, i.e. the layer acts on
+        cat([global.expand(n), x], dim=1) (``global_first``, models/pcn.py:172) or cat([x, global.expand(n)], dim=1)
+        (models/pcn.py:486,488) without materialising the broadcast; a group is ``rows_per_group``/3 consecutive points."""
         if self.share_nonlinearity:
             raise NotImplementedError("share_nonlinearity=True is not used on the PCNNet paths")
         bn = self.batchnorm.bn
@@ -121,9 +137,11 @@ class VNLinearLeakyReLU(nn.Module):
         bias = None
         if global_rows is not None:
             cg = global_rows.shape[1]
-            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wf[:, :cg], None, 0),
-                              ops.VNLinearFn.apply(global_rows, Wd[:, :cg], None, 0)], dim=1)
-            Wf, Wd = Wf[:, cg:], Wd[:, cg:]
+            cx = Wf.shape[1] - cg
+            gsl, xsl = (slice(0, cg), slice(cg, None)) if global_first else (slice(cx, None), slice(0, cx))
+            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wf[:, gsl], None, 0),
+                              ops.VNLinearFn.apply(global_rows, Wd[:, gsl], None, 0)], dim=1)
+            Wf, Wd = Wf[:, xsl], Wd[:, xsl]
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                          rows_per_group, self.training, self.negative_slope)
 
