@@ -312,6 +312,92 @@ def attention_vn_foldingnet_forward(sd, coarse, feature_global, training=True, g
     return (rel + coarse.unsqueeze(-1)).transpose(2, 3).reshape(bs, -1, 3)
 
 
+# ------------------------------------------------------------------------ VN-PoinTr encoder
+def _lin_and_leaky_bn(sd, prefix, x, training, new_stats):
+    """VNLinearAndLeakyReLU with use_batchnorm='norm' (models/vn_layers.py:92-104)."""
+    y = vn_linear(x, sd[f"{prefix}.linear.map_to_feat.weight"])
+    g, b = sd[f"{prefix}.batchnorm.bn.weight"], sd[f"{prefix}.batchnorm.bn.bias"]
+    rm, rv = sd.get(f"{prefix}.batchnorm.bn.running_mean"), sd.get(f"{prefix}.batchnorm.bn.running_var")
+    y, nrm, nrv = vn_batchnorm(y, g, b, rm, rv, training)
+    if new_stats is not None and nrm is not None:
+        new_stats[f"{prefix}.batchnorm.bn.running_mean"], new_stats[f"{prefix}.batchnorm.bn.running_var"] = nrm, nrv
+    return vn_leaky_relu(y, sd[f"{prefix}.leaky_relu.map_to_dir.weight"])
+
+
+def vn_dgcnn_grouper_forward(sd, prefix, coords, training=True, k=16, new_stats=None):
+    """models/pointr/utils/dgcnn_group.py:214-247: every kNN graph is built on the flattened VN FEATURES.
+    coords [B,N,3] -> (proxy coords [B,128,3], features [B,128,3,128])."""
+    p = prefix
+
+    def conv(name, f):
+        B, C, _, N = f.shape
+        feats = f.permute(0, 3, 1, 2).reshape(B, N, C * 3)
+        e = vn_graph_feature(f, knn_torch(feats, feats, k))
+        return mean_pool(_lin_leaky(sd, f"{p}.{name}", e, training, new_stats))
+
+    def down(c, f, m):
+        i = fps_torch(c, m)
+        return (torch.gather(c, 1, i[..., None].expand(-1, -1, 3)),
+                torch.gather(f, 3, i[:, None, None, :].expand(-1, f.shape[1], 3, -1)))
+
+    f = conv("conv1.0", coords.transpose(1, 2).unsqueeze(1))
+    cq, fq = down(coords, f, 512)
+    f = conv("conv4", fq)
+    f = conv("conv5", f)
+    cq, fq = down(cq, f, 128)
+    return cq, conv("conv6", fq)
+
+
+def pointr_vn_block(sd, prefix, x, knn_idx, training=True, new_stats=None):
+    """models/pointr/vn_pointr.py:384-412 (VN_Block.forward).  x [B,N,384] tokens; knn_idx [B,N,8] or None."""
+    B, N, _ = x.shape
+    vn_x = x.transpose(1, 2).reshape(B, -1, 3, N)                          # [B,128,3,N]
+    norm_x = vn_layer_norm(vn_x, sd[f"{prefix}.norm1.layer_norm.weight"], sd[f"{prefix}.norm1.layer_norm.bias"])
+    C, H = 128, 4
+    scale = (384 // H) ** -0.5
+
+    def heads(w):
+        return vn_linear(norm_x, sd[f"{prefix}.attn.{w}.map_to_feat.weight"]).reshape(B, H, 3 * C // H, 3, N).permute(0, 1, 4, 2, 3).reshape(B, H, N, -1)
+    q, kk, v = heads("proj_vnq"), heads("proj_vnk"), heads("proj_vnv")
+    attn = ((q @ kk.transpose(-2, -1)) * scale).softmax(dim=-1)
+    a = (attn @ v).transpose(1, 2).reshape(B, N, 3 * C, 3).permute(0, 2, 3, 1)
+    x_1 = vn_linear(a, sd[f"{prefix}.attn.proj_vn.map_to_feat.weight"])
+    if knn_idx is not None:
+        f = mean_pool(_lin_leaky(sd, f"{prefix}.conv1", vn_graph_feature(norm_x, knn_idx), training, new_stats))
+        x_1 = vn_linear(torch.cat([x_1, f], dim=1), sd[f"{prefix}.conv2.map_to_feat.weight"])
+    vn_x = vn_x + x_1
+    n2 = vn_layer_norm(vn_x, sd[f"{prefix}.norm2.layer_norm.weight"], sd[f"{prefix}.norm2.layer_norm.bias"])
+    vn_x = vn_x + _lin_leaky(sd, f"{prefix}.conv4", _lin_leaky(sd, f"{prefix}.conv3", n2, training, new_stats), training, new_stats)
+    return vn_x.reshape(B, -1, N).transpose(1, 2)
+
+
+def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encoder", new_stats=None):
+    """models/pointr/vn_pointr.py:575-722 (VN_PCTransformer.forward, dgcnn='vn_dgcnn', trans='vn_trans', only_coarse=True).
+    inpc [B,N,3] -> (coarse [B,1248,3], global_feature [B,1024,3,1])."""
+    p = prefix
+    B = inpc.shape[0]
+    coor, f = vn_dgcnn_grouper_forward(sd, f"{p}.grouper", inpc, training, 16, new_stats)      # [B,128,3], [B,128,3,128]
+    nc = f.shape[-1]
+    f = vn_linear(_lin_leaky(sd, f"{p}.vn_input_proj.0", f, training, new_stats), sd[f"{p}.vn_input_proj.1.map_to_feat.weight"])
+    x = f.reshape(B, -1, nc).transpose(1, 2)
+    knn_idx = knn_torch(coor, coor, 8)
+    centers = inpc.mean(dim=1)
+    pos_in = torch.cat([coor.transpose(1, 2).unsqueeze(1), centers.unsqueeze(-1).expand(-1, -1, nc).unsqueeze(1)], dim=1)   # [B,2,3,nc]
+    pos = vn_linear(_lin_and_leaky_bn(sd, f"{p}.fourth_vn_pos_embed.0", pos_in, training, new_stats),
+                    sd[f"{p}.fourth_vn_pos_embed.1.map_to_feat.weight"]).reshape(B, -1, nc).transpose(1, 2)
+    for i in range(6):
+        x = pointr_vn_block(sd, f"{p}.encoder.{i}", x + pos, knn_idx if i < knn_layer else None, training, new_stats)
+    vn_x = x.transpose(1, 2).reshape(B, -1, 3, nc)
+    g = vn_linear(_lin_and_leaky_bn(sd, f"{p}.vn_increase_dim.0", vn_x, training, new_stats), sd[f"{p}.vn_increase_dim.1.map_to_feat.weight"])
+    g = vn_max_pool(g, sd[f"{p}.vn_global_pool.map_to_dir.weight"]).unsqueeze(-1)                 # [B,1024,3,1]
+    h = vn_linear(g, sd[f"{p}.vn_coarse_pred.0.map_to_feat.weight"])
+    h = vn_leaky_relu(h, sd[f"{p}.vn_coarse_pred.1.map_to_dir.weight"])
+    h = vn_linear(h, sd[f"{p}.vn_coarse_pred.2.map_to_feat.weight"]).squeeze(-1)                  # [B,1024,3]
+    i = fps_torch(inpc, 224)
+    sparse = torch.gather(inpc, 1, i[..., None].expand(-1, -1, 3))
+    return torch.cat([h, sparse], dim=1).contiguous(), g
+
+
 # --------------------------------------------------------------------------- losses
 def chamfer_torch(a, b, chunk=1024):
     """Direct-form squared NN distances (same formula as chamfer3D.cu:33-36) in torch, per sample and in row chunks

@@ -527,9 +527,121 @@ def main_attention():
     npz("attention_small.npz", **out)
 
 
+def main_pointr():
+    """Section 7: VN_PCTransformer encoder (BASELINE config 5) on B=2, N=640 points (-> 512 -> 128 proxies)."""
+    _standins()
+    from oracle import vn_oracle as O
+    from models.pointr.vn_pointr import VN_PCTransformer
+    gen = torch.Generator().manual_seed(555)
+    x = torch.rand(2, 640, 3, generator=gen) - 0.5
+    gc, gg = torch.randn(2, 1248, 3, generator=gen), torch.randn(2, 1024, 3, 1, generator=gen)
+
+    def build(seed, dtype, sd=None):
+        torch.manual_seed(seed)
+        n_ = VN_PCTransformer(in_chans=3, embed_dim=384, depth=[6, 8], drop_rate=0., num_query=224, knn_layer=1,
+                              dgcnn="vn_dgcnn", trans="vn_trans", memory_profile=False, only_coarse=True)
+        if sd is not None:
+            n_ = n_.to(dtype)
+            n_.load_state_dict({k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in sd.items()})
+        return n_.train()
+
+    best = (None, 1e9)
+    for seed in range(6):
+        net = build(seed, torch.float32)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            c32, g32 = net(x)
+            c64, g64 = build(seed, torch.float64, sd0)(x.double())
+        d = max((c32.double() - c64).abs().max().item(), (g32.double() - g64).abs().max().item())
+        print(f"vn_pointr seed {seed}: reference fp32 vs fp64 gap {d:.2e}")
+        if d < best[1]:
+            best = (seed, d)
+    chosen = best[0]
+    net = build(chosen, torch.float32)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    coarse, g = net(x)
+    with torch.no_grad():
+        c64, g64 = build(chosen, torch.float64, sd0)(x.double())
+    (coarse * gc).sum().backward(retain_graph=True)
+    (g * gg).sum().backward()
+    out = {"seed": chosen, "x": x, "coarse": coarse, "global": g, "coarse64": c64, "global64": g64, "gc": gc, "gg": gg}
+    names, norms, wsum, wabs = [], [], [], []
+    for k, prm in net.named_parameters():
+        names.append(k)
+        wsum.append(sd0[k].double().sum().item())
+        wabs.append(sd0[k].double().abs().sum().item())
+        norms.append(-1.0 if prm.grad is None else prm.grad.double().norm().item())
+    out.update({"grad_names": np.array(names), "grad_norms": np.array(norms), "weight_sum": np.array(wsum), "weight_abssum": np.array(wabs)})
+    print("vn_pointr: parameters without gradient:", sum(1 for n in norms if n < 0), "of", len(norms),
+          "=", sum(p.numel() for p in net.parameters() if p.grad is None), "elements")
+    # The encoder is chaotic end to end even inside the reference (fp32 vs fp64 differ by O(1): feature-space kNN graphs
+    # and arg-max pools flip), so parity is pinned STAGE BY STAGE with the reference's own discrete decisions (graphs, FPS
+    # picks) and inputs teacher-forced.  Re-run the forward manually with the reference's sub-modules, capturing them.
+    import models.pointr.utils.dgcnn_group as DG
+    import models.pointr.vn_pointr as VP
+    net = build(chosen, torch.float32)
+    cap = {}
+    with torch.no_grad():
+        gr = net.grouper
+        coor0 = x.transpose(1, 2).contiguous()                                   # [B,3,N]
+        xf = gr.vn_get_graph_feature(coor0.unsqueeze(1))
+        x1 = gr.pool1(gr.conv1(xf))
+        # fps_downsample + dynamic graphs, recording indices
+        def knn_feat(f):
+            B_, C_, _, N_ = f.shape
+            return DG.knn(f.view(B_, -1, N_), f.view(B_, -1, N_))[1]             # [B,k,N]
+        fps1 = O.fps_torch(x, 512)
+        coor_q, f_q = gr.fps_downsample(coor0, x1, 512)
+        i4 = knn_feat(f_q)
+        f4 = gr.pool2(gr.conv4(gr.vn_get_graph_feature(f_q, idx=i4)))
+        i5 = knn_feat(f4)
+        f5 = gr.pool3(gr.conv5(gr.vn_get_graph_feature(f4, idx=i5)))
+        fps2 = O.fps_torch(coor_q.transpose(1, 2).contiguous(), 128)
+        coor_q2, f_q2 = gr.fps_downsample(coor_q, f5, 128)
+        i6 = knn_feat(f_q2)
+        f6 = gr.pool4(gr.conv6(gr.vn_get_graph_feature(f_q2, idx=i6)))
+        coor_ref, f_ref = gr(coor0)
+        assert torch.equal(f6, f_ref) and torch.equal(coor_q2, coor_ref), "manual staging != reference grouper"
+        cap.update({"g_fq1": f_q, "g_i4": i4.transpose(1, 2).short(), "g_f4": f4, "g_i5": i5.transpose(1, 2).short(), "g_f5": f5,
+                    "g_fps1": fps1.short(), "g_fps2": fps2.short(), "g_fq2": f_q2, "g_i6": i6.transpose(1, 2).short(), "g_f6": f6,
+                    "g_coor": coor_q2})
+        bs, nc = 2, 128
+        f = net.vn_input_proj(f6).contiguous().view(bs, -1, nc)
+        tok = f.transpose(1, 2)
+        knn_index = VP.get_knn_index(coor_q2)
+        centers = torch.mean(x, dim=1)
+        rep = centers.unsqueeze(-1).expand(-1, -1, nc).unsqueeze(1)
+        pos = net.fourth_vn_pos_embed(torch.concat([coor_q2.unsqueeze(1), rep], dim=1)).reshape(bs, -1, nc).transpose(1, 2)
+        cap.update({"t_in": tok, "t_pos": pos, "t_knn": (knn_index.view(bs, 8, nc) - (torch.arange(bs) * nc).view(bs, 1, 1)).transpose(1, 2).short()})
+        xx = tok
+        for i, blk in enumerate(net.encoder):
+            xx = blk(xx + pos, knn_index) if i < net.knn_layer else blk(xx + pos)
+            if i in (0, 1, 5):
+                cap[f"t_blk{i}"] = xx
+        vn_x = xx.transpose(1, 2).contiguous().view(bs, -1, 3, nc)
+        gfull = net.vn_increase_dim(vn_x)
+        cap["g_pre_pool_proj"] = (gfull * torch.sin(torch.arange(gfull.numel(), dtype=torch.float32).view_as(gfull))).sum(dim=(1, 2))   # [B,nc] compact
+        gl = net.vn_global_pool(gfull).unsqueeze(-1)
+        cp = net.vn_coarse_pred(gl).squeeze(-1)
+        assert torch.allclose(gl, g.detach(), atol=1e-6) and torch.allclose(cp, coarse.detach()[:, :1024], atol=1e-6)
+    out.update(cap)
+    sdd = {"encoder." + k: v for k, v in sd0.items()}
+    # oracle, teacher-forced per stage
+    check(O.pointr_vn_block(sdd, "encoder.encoder.0", cap["t_in"] + cap["t_pos"], cap["t_knn"].long(), True), cap["t_blk0"], "pointr block 0", 1e-4)
+    check(O.pointr_vn_block(sdd, "encoder.encoder.1", cap["t_blk0"] + cap["t_pos"], None, True), cap["t_blk1"], "pointr block 1", 1e-4)
+    e4 = O.mean_pool(O._lin_leaky(sdd, "encoder.grouper.conv4", O.vn_graph_feature(cap["g_fq1"], cap["g_i4"].long()), True, None))
+    check(e4, cap["g_f4"], "grouper conv4 (teacher-forced graph)", 1e-4)
+    co, go = O.vn_pctransformer_forward(sdd, x, True)
+    print(f"vn_pointr: oracle vs reference END TO END (chaotic, informational): coarse {(co - coarse).abs().max().item():.2e} "
+          f"global {(go - g).abs().max().item():.2e}; reference fp32 vs fp64 {best[1]:.2e}")
+    npz("pointr_small.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "pointr"):
+        main_pointr()
     if which in ("all", "base"):
         main()
     if which in ("all", "dgcnn"):

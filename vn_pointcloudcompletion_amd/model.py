@@ -53,6 +53,12 @@ class PCNNet(nn.Module):
                 param.requires_grad = False
         if not config.only_coarse:
             self.decoder = _make_decoder(config, dec_type, enc_type).to(config.device)
+            if enc_type == "vn_pointr" and dec_type == "vn_foldingnet":
+                # The reference as written cannot run this pair: VN_PCTransformer returns 1024 + 224 coarse points and a
+                # 1024-channel global feature, while VN_FoldingNet hard-codes 16384 dense points (models/pcn.py:332,376;
+                # SURVEY.md §8a B4).  Definition used here (= the reference with these two attributes overridden after
+                # construction): num_coarse = 1248, num_dense = 19968; config.latent_dim must be 1024.
+                self.decoder.num_coarse, self.decoder.num_dense = 1248, 1248 * 16
 
     def forward(self, input, rot=None):
         coarse, feature_global = self.encoder(input)
