@@ -120,6 +120,14 @@ def main():
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+        if os.environ.get("VNP_BENCH_SHAPES"):
+            per = {}
+            for variant, flops, nsplit, shape, e0, e1 in prof:
+                a = per.setdefault((variant, shape, nsplit), [0.0, 0.0, 0])
+                a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            for (variant, shape, nsplit), a in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {variant} M={shape[0]:8d} N={shape[1]:5d} K={shape[2]:8d} split={nsplit:4d} x{a[2] // args.steps:2d}/step "
+                      f"{a[1] / args.steps * 1e3:7.3f} ms/step {a[0] / a[1] / 1e12:6.1f} TF/s", file=sys.stderr)
         tot_f = sum(a[0] for a in agg.values())
         tot_t = sum(a[1] for a in agg.values())
         nlaunch = sum(a[2] for a in agg.values())

@@ -49,14 +49,12 @@ int vnp_emd_matchcost_bwd(hipStream_t st, int B, int n, int m, const float* grad
 
 /* ---- fp32 MFMA GEMM -----------------------------------------------------------------------------------------
  * replaces the x.transpose(1,-1) -> nn.Linear -> transpose chains of models/vn_layers.py:21,36,65,69,162 and their
- * autograd.  C[M,N] (+)= op(A) op(B) (+ A2 B2) (+ bias).
+ * autograd.  C[M,N] (+)= op(A) op(B) (+ bias).
  *   op_a = 0: A is [M,K] row-major; 1: A is [K,M] row-major.   op_b = 0: B is [N,K] row-major; 1: B is [K,N].
- *   (A2,B2,K2): optional second product with the same op flags accumulated in the same tile (K2 = 0: none).
  *   bias: optional [groups*3, ldbias]; row r gets bias[(r / rows_per_group)*3 + r%3] (per-sample VN bias).
  *   accumulate != 0: C += result.   nsplit > 1: split-K through ws (nsplit*M*N floats), bias not allowed. */
 int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-             const float* A2, int lda2, const float* B2, int ldb2, int K2,
              const float* bias, int ldbias, int rows_per_group,
              int accumulate, int nsplit, float* ws);
 

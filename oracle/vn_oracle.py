@@ -442,6 +442,37 @@ def l2_cd_metric(dist1, dist2):
     return (dist1.mean(1) + dist2.mean(1)).sum()
 
 
+def calc_dcd_oracle(x, gt, alpha=1000, n_lambda=1, non_reg=False):
+    """metrics/loss.py:77-118 (density-aware Chamfer distance) with the reference's per-sample bincount loop.
+    Returns (loss [B], cd_p [B], cd_t [B])."""
+    B, n_x, _ = x.shape
+    n_gt = gt.shape[1]
+    frac_12 = max(1, n_x / n_gt) if non_reg else n_x / n_gt
+    frac_21 = max(1, n_gt / n_x) if non_reg else n_gt / n_x
+    dist1, dist2, idx1, idx2 = chamfer_torch(gt, x)                 # calc_cd passes (gt, output), loss.py:61
+    cd_p = (torch.sqrt(dist1).mean(1) + torch.sqrt(dist2).mean(1)) / 2
+    cd_t = dist1.mean(1) + dist2.mean(1)
+    e1, e2 = torch.exp(-dist1 * alpha), torch.exp(-dist2 * alpha)
+    l1, l2 = [], []
+    for b in range(B):
+        c1 = torch.bincount(idx1[b].long())
+        w1 = (c1[idx1[b].long()].float().detach() ** n_lambda + 1e-6) ** (-1) * frac_21
+        l1.append((-e1[b] * w1 + 1.).mean())
+        c2 = torch.bincount(idx2[b].long())
+        w2 = (c2[idx2[b].long()].float().detach() ** n_lambda + 1e-6) ** (-1) * frac_12
+        l2.append((-e2[b] * w2 + 1.).mean())
+    return (torch.stack(l1) + torch.stack(l2)) / 2, cd_p, cd_t
+
+
+def fscore_oracle(dist1, dist2, threshold=0.001):
+    """extensions/ChamferDistancePytorch/fscore.py:3-16."""
+    p1 = (dist1 < threshold).float().mean(1)
+    p2 = (dist2 < threshold).float().mean(1)
+    f = 2 * p1 * p2 / (p1 + p2)
+    f[torch.isnan(f)] = 0
+    return f, p1, p2
+
+
 # ----------------------------------------------------------------- deterministic fill
 def closed_form_fill(state_dict):
     """Fill a state_dict in place with a closed-form rule keyed by (position, flat index), so the

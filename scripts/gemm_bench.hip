@@ -7,18 +7,19 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool DBUF, bool PRIO>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool FAST, int PER_CU = 2>
 float run(const VnpGemmArgs& p0, int iters)
 {
     VnpGemmArgs p = p0;
     const int nk = (p.K + BK - 1) / BK;
-    p.tiles_per_split = nk; p.nsplit = 1; p.bsa = p.bsb = p.bsc = 0;
-    dim3 grid(vnp_cdiv(p.M, BM) * vnp_cdiv(p.N, BN), 1), block(256);
+    p.tiles_per_split = nk; p.nsplit = 1; p.nbatch = 1; p.bsa = p.bsb = p.bsc = 0;
+    int items = vnp_cdiv(p.M, BM) * vnp_cdiv(p.N, BN);
+    dim3 grid(items < PER_CU * 256 ? items : PER_CU * 256), block(256);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((vnp_gemm_kernel<BM, BN, BK, AKC, BKC, DBUF, PRIO>), grid, block, 0, 0, p);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((vnp_gemm_kernel<BM, BN, BK, AKC, BKC, FAST>), grid, block, 0, 0, p);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((vnp_gemm_kernel<BM, BN, BK, AKC, BKC, DBUF, PRIO>), grid, block, 0, 0, p);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((vnp_gemm_kernel<BM, BN, BK, AKC, BKC, FAST>), grid, block, 0, 0, p);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / iters;
@@ -48,14 +49,9 @@ int main()
         printf("%-16s M=%d N=%d K=%d\n", s.name, s.M, s.N, s.K);
         for (int round = 0; round < 2; ++round) {
             float t;
-            t = run<192, 128, 32, true, true, false, false>(p, it); printf("  r%d 192x128x32 sbuf       %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<192, 128, 32, true, true, false, true>(p, it);  printf("  r%d 192x128x32 sbuf prio  %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<192, 128, 16, true, true, true, false>(p, it);  printf("  r%d 192x128x16 dbuf       %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<192, 128, 16, true, true, true, true>(p, it);   printf("  r%d 192x128x16 dbuf prio  %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<192, 128, 16, true, true, false, false>(p, it); printf("  r%d 192x128x16 sbuf       %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<128, 128, 32, true, true, false, false>(p, it); printf("  r%d 128x128x32 sbuf       %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<128, 128, 32, true, true, true, false>(p, it);  printf("  r%d 128x128x32 dbuf       %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
-            t = run<192, 256, 16, true, true, true, false>(p, it);  printf("  r%d 192x256x16 dbuf       %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
+            t = run<192, 128, 32, true, true, true, 2>(p, it);  printf("  r%d 192x128x32 fast  2/CU %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
+            t = run<192, 128, 32, true, true, false, 2>(p, it); printf("  r%d 192x128x32 gen   2/CU %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
+            t = run<128, 128, 32, true, true, true, 3>(p, it);  printf("  r%d 128x128x32 fast  3/CU %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
         }
     }
     return 0;

@@ -92,3 +92,27 @@ def test_cpu_tensor_raises(lib_built):
     from vn_pointcloudcompletion_amd import _lib
     with pytest.raises(_lib.VnpError):
         _fwd(torch.rand(1, 4, 3), torch.rand(1, 5, 3))
+
+
+def test_dcd_and_fscore_match_oracle(lib_built):
+    """calc_dcd (metrics/loss.py:77-118) and fscore (ChamferDistancePytorch/fscore.py) vs the oracle restatement, incl. grads."""
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd import loss, metric
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(3, 200, 3, generator=g) - 0.5)
+    gt = (torch.rand(3, 500, 3, generator=g) - 0.5)
+    xr = x.cuda().requires_grad_(True)
+    l, cd_p, cd_t = loss.calc_dcd(xr, gt.cuda(), alpha=200, n_lambda=0.5)
+    xo = x.clone().requires_grad_(True)
+    lo, po, to = O.calc_dcd_oracle(xo, gt, alpha=200, n_lambda=0.5)
+    assert (l.cpu() - lo).abs().max().item() < 1e-5 and (cd_p.cpu() - po).abs().max().item() < 1e-6
+    assert (cd_t.cpu() - to).abs().max().item() < 1e-6
+    l.mean().backward()
+    lo.mean().backward()
+    assert (xr.grad.cpu() - xo.grad).abs().max().item() < 1e-5 * max(1.0, xo.grad.abs().max().item())
+    d1, d2, _, _ = O.chamfer_torch(x, gt)
+    f, p1, p2 = metric.fscore(d1.cuda(), d2.cuda(), 0.01)
+    fo, _, _ = O.fscore_oracle(d1, d2, 0.01)
+    assert (f.cpu() - fo).abs().max().item() < 1e-6
+    assert abs(metric.f_score(x[0].numpy(), gt[0].numpy(), th=0.1) - 2 * ((d2[0] < 0.01).float().mean() * (d1[0] < 0.01).float().mean()
+               / ((d2[0] < 0.01).float().mean() + (d1[0] < 0.01).float().mean())).item()) < 1e-6

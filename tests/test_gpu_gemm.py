@@ -48,14 +48,10 @@ def test_splitk_large_k():
     assert relerr(C, A.double().t() @ B.double()) < 2e-5
 
 
-def test_dual_bias_strided_accumulate():
+def test_bias_strided_accumulate():
     from vn_pointcloudcompletion_amd import ops
-    M, N, K1, K2 = 2 * 10 * 3, 70, 40, 24          # 2 samples x 10 points
-    A1, A2 = _mk(M, K1, seed=8), _mk(M, K2, seed=9)
-    W1, W2 = _mk(K1, N, seed=10), _mk(K2, N, seed=11)
-    C = ops.gemm(A1, W1, op_b=1, A2=A2, B2=W2)
-    ref = A1.double() @ W1.double() + A2.double() @ W2.double()
-    assert relerr(C, ref) < 2e-5
+    M, N, K1 = 2 * 10 * 3, 70, 40          # 2 samples x 10 points
+    A1 = _mk(M, K1, seed=8)
     # per-sample VN bias and a strided (column-slice) weight / output
     Wfull = _mk(N, K1 + 16, seed=12)
     bias = _mk(2 * 3, N, seed=13)
@@ -68,6 +64,25 @@ def test_dual_bias_strided_accumulate():
     prev = out[:, N:].clone()
     ops.gemm(A1, Wfull[:, 16:], out=out[:, N:], accumulate=True, nsplit=1)
     assert relerr(out[:, N:], prev.double() + A1.double() @ Wfull[:, 16:].double().t()) < 2e-5
+    # aligned fast path with a per-sample bias whose groups are larger / smaller than the 192-row tile
+    for rpg in (384, 96, 576):
+        M2, N2, K2 = 1152, 256, 64
+        A2, W2, b2 = _mk(M2, K2, seed=20), _mk(N2, K2, seed=21), _mk(M2 // rpg * 3, N2, seed=22)
+        got = ops.gemm(A2, W2, bias=b2, rows_per_group=rpg)
+        r2 = torch.arange(M2, device="cuda")
+        assert relerr(got, A2.double() @ W2.double().t() + b2.double()[(r2 // rpg) * 3 + r2 % 3]) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(192 * 700, 128, 64), (192 * 3, 128 * 5, 32 * 40), (128 * 9, 128 * 3, 32 * 3)])
+def test_persistent_walk_covers_every_tile(M, N, K):
+    """More work items than resident workgroups: every output tile must be visited exactly once (NT, NN, TN)."""
+    from vn_pointcloudcompletion_amd import ops
+    A, B = _mk(M, K, seed=31), _mk(N, K, seed=32)
+    assert relerr(ops.gemm(A, B), A.double() @ B.double().t()) < 2e-5
+    Bn = _mk(K, N, seed=33)
+    assert relerr(ops.gemm(A, Bn, op_b=1), A.double() @ Bn.double()) < 2e-5
+    At = _mk(K, M, seed=34)
+    assert relerr(ops.gemm(At, Bn, op_a=1, op_b=1, nsplit=1), At.double().t() @ Bn.double()) < 2e-5
 
 
 def test_bad_arguments_raise():

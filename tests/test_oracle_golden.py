@@ -153,3 +153,62 @@ def test_chamfer_c_oracle_vs_golden():
     t1, t2, k1, k2 = O.chamfer_torch(a, b, chunk=64)
     c1, c2, l1, l2 = CO.chamfer_forward(a.numpy(), b.numpy())
     assert np.abs(t1.numpy() - c1).max() < 1e-6 and np.array_equal(k1.numpy(), l1) and np.array_equal(k2.numpy(), l2)
+
+
+# ------------------------------------------------------------------ configs 3-5: oracle vs the reference captures
+def _seeded_state(builder, seed, prefix=""):
+    torch.manual_seed(seed)
+    m = builder()
+    return {prefix + k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_dgcnn_oracle_vs_golden():
+    from vn_pointcloudcompletion_amd.dgcnn import VN_DGCNN_fps          # parameter container only
+    D = load_golden("dgcnn_small.npz")
+    sd = _seeded_state(lambda: VN_DGCNN_fps(SimpleNamespace(num_coarse=32)), int(D["seed"]), "encoder.")
+    x = T(D["x"])
+    assert np.array_equal(O.knn_torch(x, x, 16).numpy(), D["knn_idx"])
+    assert np.array_equal(O.fps_torch(x, 512).numpy(), D["fps_idx"])
+    with torch.no_grad():
+        co, go = O.vn_dgcnn_fps_forward(sd, x, True)
+    assert relerr(co, D["coarse"]) < 1e-4 and relerr(go, D["global"]) < 1e-4
+
+
+def test_attention_decoder_oracle_vs_golden():
+    from vn_pointcloudcompletion_amd.attention_decoder import Attention_VN_FoldingNet
+    A = load_golden("attention_small.npz")
+    sd = _seeded_state(lambda: Attention_VN_FoldingNet(SimpleNamespace(num_coarse=128, latent_dim=2048)), int(A["seed"]), "decoder.")
+    with torch.no_grad():
+        b0 = O.vn_block(sd, "decoder.transformer.0", T(A["tok_in"]), 8, 1, True)
+        b1 = O.vn_block(sd, "decoder.transformer.1", T(A["blk0_out"]), 8, 1, True)
+        fine = O.attention_vn_foldingnet_forward(sd, T(A["coarse"]), T(A["fg"]), True)
+    assert relerr(b0, A["blk0_out"]) < 1e-4 and relerr(b1, A["blk1_out"]) < 1e-4
+    gap = np.abs(A["fine"].astype(np.float64) - A["fine64"]).max()
+    assert (fine.double() - T(A["fine64"])).abs().max().item() < max(10 * gap, 5e-3)
+
+
+def test_pointr_oracle_stages_vs_golden():
+    from vn_pointcloudcompletion_amd.vn_pointr import VN_PCTransformer
+    P = load_golden("pointr_small.npz")
+    sd = _seeded_state(lambda: VN_PCTransformer(in_chans=3, embed_dim=384, depth=[6, 8], drop_rate=0., num_query=224, knn_layer=1,
+                                                dgcnn="vn_dgcnn", trans="vn_trans", memory_profile=False, only_coarse=True),
+                       int(P["seed"]), "encoder.")
+    with torch.no_grad():
+        b0 = O.pointr_vn_block(sd, "encoder.encoder.0", T(P["t_in"]) + T(P["t_pos"]), T(P["t_knn"]).long(), True)
+        b1 = O.pointr_vn_block(sd, "encoder.encoder.1", T(P["t_blk0"]) + T(P["t_pos"]), None, True)
+        e4 = O.mean_pool(O._lin_leaky(sd, "encoder.grouper.conv4", O.vn_graph_feature(T(P["g_fq1"]), T(P["g_i4"]).long()), True, None))
+    assert relerr(b0, P["t_blk0"]) < 1e-4 and relerr(b1, P["t_blk1"]) < 1e-4 and relerr(e4, P["g_f4"]) < 1e-4
+    assert np.array_equal(O.fps_torch(T(P["x"]), 512).numpy(), P["g_fps1"].astype(np.int64))
+
+
+def test_emd_oracle_properties():
+    """EMD is PARITY UNPINNED (no reference test / CPU equivalent): check the restatement's invariants instead."""
+    rng = np.random.default_rng(0)
+    a, b = rng.random((2, 96, 3), dtype=np.float32), rng.random((2, 96, 3), dtype=np.float32)
+    m = CO.emd_approxmatch(a, b)
+    assert m.shape == (2, 96, 96) and (m >= 0).all()
+    assert np.abs(m.sum(1) - 1).max() < 1e-3 and np.abs(m.sum(2) - 1).max() < 1e-3       # n == m: doubly stochastic
+    assert CO.emd_matchcost(a, a, CO.emd_approxmatch(a, a)).max() < 1e-4               # identical clouds
+    # n != m: integer multipliers (emd_kernel.cu:29-35): rows of the larger side carry weight 1, the smaller n/m each
+    m2 = CO.emd_approxmatch(a[:, :32], b)                                              # n = 32 < m = 96 -> multiL = 3
+    assert np.abs(m2.sum(1) - 3).max() < 1e-2 and np.abs(m2.sum(2) - 1).max() < 1e-2

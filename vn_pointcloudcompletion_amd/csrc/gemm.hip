@@ -15,6 +15,20 @@
 // four consecutive K values come from ONE 16-byte LDS read.
 #include "gemm_kernel.h"
 
+static int vnp_num_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 // out[r][c] (+)= sum_z ws[z][r][c]; ws slabs are dense [M, N]
 __global__ void vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit, long long slab, float* __restrict__ C,
                                         int M, int N, int ldc, int accumulate)
@@ -35,51 +49,52 @@ __global__ void vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit
 // nsplit > 1: split-K; `ws` must hold nsplit * M * N floats; the result is reduced into C afterwards.
 static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
                          const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                         const float* A2, int lda2, const float* B2, int ldb2, int K2,
                          const float* bias, int ldbias, int rows_per_group,
                          int accumulate, int nsplit, float* ws,
                          int nbatch, long long bsa, long long bsb, long long bsc)
 {
     if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return VNP_EINVAL;
-    if (K2 > 0 && (!A2 || !B2)) return VNP_EINVAL;
     if (bias && rows_per_group <= 0) return VNP_EINVAL;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1 && !ws) return VNP_EINVAL;
-    if (nbatch < 1 || (nbatch > 1 && (nsplit > 1 || K2 > 0))) return VNP_EINVAL;
+    if (nbatch < 1 || (nbatch > 1 && nsplit > 1)) return VNP_EINVAL;
     constexpr int BK = 32;
     VnpGemmArgs p;
-    p.A = A; p.B = B; p.A2 = A2; p.B2 = B2; p.bias = bias;
-    p.M = M; p.N = N; p.K = K; p.K2 = K2 > 0 ? K2 : 0;
-    p.lda = lda; p.ldb = ldb; p.lda2 = lda2; p.ldb2 = ldb2; p.ldbias = ldbias;
+    p.A = A; p.B = B; p.bias = bias;
+    p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldbias = ldbias;
     p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
     p.bsa = bsa; p.bsb = bsb; p.bsc = bsc;
-    const int nk = vnp_cdiv(K, BK) + (p.K2 ? vnp_cdiv(p.K2, BK) : 0);
-    if (nsplit > nk) nsplit = nk > 0 ? nk : 1;
-    p.tiles_per_split = vnp_cdiv(nk > 0 ? nk : 1, nsplit);
-    nsplit = vnp_cdiv(nk > 0 ? nk : 1, p.tiles_per_split);
+    const int nk = vnp_cdiv(K, BK) > 0 ? vnp_cdiv(K, BK) : 1;
+    if (nsplit > nk) nsplit = nk;
+    p.tiles_per_split = vnp_cdiv(nk, nsplit);
+    nsplit = vnp_cdiv(nk, p.tiles_per_split);
     if (nsplit > 1) {
         if (bias) return VNP_EINVAL;
         p.C = ws; p.ldc = N; p.slab = (long long)M * N; p.accumulate = 0;
     } else {
         p.C = C; p.ldc = ldc; p.slab = 0; p.accumulate = accumulate;
     }
-    p.nsplit = nsplit;
-    const int gy = nsplit * nbatch;
-    if (gy > 65535) return VNP_EINVAL;
-    dim3 block(256);
-    if (op_a == 0 && op_b == 0) {
-        dim3 grid(vnp_cdiv(M, 192) * vnp_cdiv(N, 128), gy);
-        hipLaunchKernelGGL((vnp_gemm_kernel<192, 128, BK, true, true>), grid, block, 0, stream, p);
-    } else if (op_a == 0 && op_b == 1) {
-        dim3 grid(vnp_cdiv(M, 192) * vnp_cdiv(N, 128), gy);
-        hipLaunchKernelGGL((vnp_gemm_kernel<192, 128, BK, true, false>), grid, block, 0, stream, p);
-    } else if (op_a == 1 && op_b == 1) {
-        dim3 grid(vnp_cdiv(M, 128) * vnp_cdiv(N, 128), gy);
-        hipLaunchKernelGGL((vnp_gemm_kernel<128, 128, BK, false, false>), grid, block, 0, stream, p);
-    } else {
-        dim3 grid(vnp_cdiv(M, 128) * vnp_cdiv(N, 128), gy);
-        hipLaunchKernelGGL((vnp_gemm_kernel<128, 128, BK, false, true>), grid, block, 0, stream, p);
-    }
+    p.nsplit = nsplit; p.nbatch = nbatch;
+    const int bm = op_a == 0 ? 192 : 128;
+    const long long items = (long long)vnp_cdiv(M, bm) * vnp_cdiv(N, 128) * nsplit * nbatch;
+    if (items > 2147483647LL) return VNP_EINVAL;
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
+                         (bsa % 4 == 0) && (bsb % 4 == 0);
+    const bool fast = aligned && (M % bm == 0) && (N % 128 == 0) && (K % BK == 0) && K > 0;
+    // resident workgroups per CU: 2 for the 192-row tiles (~240 VGPRs), 3 for the aligned 128-row weight-gradient kernel (151)
+    const long long cap = (long long)vnp_num_cus() * ((bm == 128 && fast && op_b == 1) ? 3 : 2);
+    dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
+#define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                              \
+    do {                                                                                                          \
+        if (fast) hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, true>), grid, block, 0, stream, p);  \
+        else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p); \
+    } while (0)
+    if (op_a == 0 && op_b == 0)      VNP_LAUNCH(192, true, true);
+    else if (op_a == 0 && op_b == 1) VNP_LAUNCH(192, true, false);
+    else if (op_a == 1 && op_b == 1) VNP_LAUNCH(128, false, false);
+    else                             VNP_LAUNCH(128, false, true);
+#undef VNP_LAUNCH
     int rc = vnp_last_error();
     if (rc) return rc;
     if (nsplit > 1) {
@@ -95,11 +110,10 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
 
 extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
                         const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                        const float* A2, int lda2, const float* B2, int ldb2, int K2,
                         const float* bias, int ldbias, int rows_per_group,
                         int accumulate, int nsplit, float* ws)
 {
-    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, A2, lda2, B2, ldb2, K2, bias, ldbias, rows_per_group,
+    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias, ldbias, rows_per_group,
                          accumulate, nsplit, ws, 1, 0, 0, 0);
 }
 
@@ -108,6 +122,6 @@ extern "C" int vnp_gemm_batched(hipStream_t stream, int op_a, int op_b, int M, i
                                 const float* A, int lda, long long bsa, const float* B, int ldb, long long bsb,
                                 float* C, int ldc, long long bsc, int nbatch, int accumulate)
 {
-    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0,
+    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, 0,
                          accumulate, 1, nullptr, nbatch, bsa, bsb, bsc);
 }

@@ -4,15 +4,14 @@
 
 struct VnpGemmArgs {
     const float* A; const float* B; float* C;
-    const float* A2; const float* B2;   // optional second product accumulated into the same tile (K2 > 0)
     const float* bias;                   // optional: C[r][c] += bias[(r / rows_per_group) * 3 + r % 3][c]
-    int M, N, K, K2;
-    int lda, ldb, ldc, lda2, ldb2, ldbias;
+    int M, N, K;
+    int lda, ldb, ldc, ldbias;
     int rows_per_group;
     int accumulate;                      // C += result instead of C = result
     int tiles_per_split;                 // K-tiles handled by one blockIdx.y
     long long slab;                      // elements between the output slabs of consecutive splits
-    int nsplit;                          // gridDim.y = nsplit * nbatch: blockIdx.y = batch * nsplit + split
+    int nsplit, nbatch;                  // work items = tiles x nsplit x nbatch, walked persistently
     long long bsa, bsb, bsc;             // batch strides (elements) of A, B, C (batched GEMM: attention heads)
 };
 
@@ -82,7 +81,13 @@ __device__ __forceinline__ void vnp_store_tile(const vnp_f4 (&reg)[NV], float* S
     }
 }
 
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool DBUF = false, bool PRIO = false>
+// Persistent kernel: gridDim.x <= (resident blocks per CU) x 256 workgroups walk the work items (output tile x K-split
+// x batch) with a fixed stride.  While a tile's last K-step runs its MFMAs and its epilogue stores drain, the first
+// K-tile of the block's NEXT work item is already in flight (global -> registers), so block start-up latency and the
+// epilogue are paid once per workgroup instead of once per tile.
+// FAST: every tile is full and 16-byte aligned (M % BM == 0, N % BN == 0, K % BK == 0, ld % 4 == 0): no bounds logic at
+// all in the loop or the epilogue; the generic instantiation handles ragged shapes.
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool FAST>
 __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
 {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
     constexpr int ASZ = AKC ? BM * LDAS : BK * LDAS;
     constexpr int BSZ = BKC ? BN * LDBS : BK * LDBS;
     constexpr int AV = BM * BK / 4 / 256, BV = BN * BK / 4 / 256;
-    __shared__ __attribute__((aligned(16))) float smem[(ASZ + BSZ) * (DBUF ? 2 : 1)];
+    __shared__ __attribute__((aligned(16))) float smem[ASZ + BSZ];
     float* As = smem;
     float* Bs = smem + ASZ;
 
@@ -100,70 +105,47 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a
-    // contiguous run of tiles (column tile fastest) -> the co-resident blocks of one L2 share A/B panels.
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-    const int nwg = nbm * nbn;
-    int wg;
-    {
-        const int id = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
-    }
-    const int m0 = (wg / nbn) * BM, n0 = (wg % nbn) * BN;
+    const int nwg = nbm * nbn;                            // output tiles
+    const int total = nwg * p.nsplit * p.nbatch;          // work items
+    const int nk = (p.K + BK - 1) / BK;
 
-    const int nk1 = (p.K + BK - 1) / BK;
-    const int nk2 = p.K2 > 0 ? (p.K2 + BK - 1) / BK : 0;
-    const int nk = nk1 + nk2;
-    const int split = blockIdx.y % p.nsplit, batch = blockIdx.y / p.nsplit;
-    const int kt0 = split * p.tiles_per_split;
-    const int kt1 = min(nk, kt0 + p.tiles_per_split);
+    const bool va = FAST || (((p.lda & 3) == 0) && ((((uintptr_t)p.A) & 15) == 0) && ((p.bsa & 3) == 0));
+    const bool vb = FAST || (((p.ldb & 3) == 0) && ((((uintptr_t)p.B) & 15) == 0) && ((p.bsb & 3) == 0));
+    int oa, sa, ob, sb;
+    vnp_tile_offsets<BM, BK, AKC>(oa, sa, p.lda, tid);
+    vnp_tile_offsets<BN, BK, BKC>(ob, sb, p.ldb, tid);
 
-    const bool va1 = ((p.lda & 3) == 0) && ((((uintptr_t)p.A) & 15) == 0);
-    const bool vb1 = ((p.ldb & 3) == 0) && ((((uintptr_t)p.B) & 15) == 0);
-    const bool va2 = nk2 && ((p.lda2 & 3) == 0) && ((((uintptr_t)p.A2) & 15) == 0);
-    const bool vb2 = nk2 && ((p.ldb2 & 3) == 0) && ((((uintptr_t)p.B2) & 15) == 0);
+    // work item w -> (m0, n0, K-tile range, split, batch).  XCD-aware order: workgroups b and b+8 share an XCD (round-robin
+    // dispatch); XCD x walks the contiguous run of output tiles [x*nwg/8, (x+1)*nwg/8) (column tile fastest) so that
+    // co-resident blocks share A/B panels in its L2.
+    int m0, n0, kt0, kt1, split, batch;
+    auto set_item = [&](int w) {
+        const int sbi = w / nwg, t = w - sbi * nwg;
+        const int q = nwg >> 3, r = nwg & 7, x = t & 7;
+        const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+        m0 = (wg / nbn) * BM; n0 = (wg % nbn) * BN;
+        split = sbi % p.nsplit; batch = sbi / p.nsplit;
+        kt0 = split * p.tiles_per_split;
+        kt1 = min(nk, kt0 + p.tiles_per_split);
+    };
 
     vnp_f4 ra[AV], rb[BV];
-    vnp_f16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // fast path: tile rows fully in range, operands 16-byte aligned with ld % 4 == 0 (K-tail tiles fall back)
-    const bool fa1 = va1 && (m0 + BM <= p.M), fb1 = vb1 && (n0 + BN <= p.N);
-    const bool fa2 = va2 && (m0 + BM <= p.M), fb2 = vb2 && (n0 + BN <= p.N);
-    int oa1, sa1, ob1, sb1, oa2 = 0, sa2 = 0, ob2 = 0, sb2 = 0;
-    vnp_tile_offsets<BM, BK, AKC>(oa1, sa1, p.lda, tid);
-    vnp_tile_offsets<BN, BK, BKC>(ob1, sb1, p.ldb, tid);
-    if (nk2) {
-        vnp_tile_offsets<BM, BK, AKC>(oa2, sa2, p.lda2, tid);
-        vnp_tile_offsets<BN, BK, BKC>(ob2, sb2, p.ldb2, tid);
-    }
-    const float* pA = p.A + (size_t)batch * p.bsa;
-    const float* pB = p.B + (size_t)batch * p.bsb;
-    const float* bA1 = AKC ? pA + (size_t)m0 * p.lda : pA + m0;
-    const float* bB1 = BKC ? pB + (size_t)n0 * p.ldb : pB + n0;
-    const float* bA2 = nk2 ? (AKC ? p.A2 + (size_t)m0 * p.lda2 : p.A2 + m0) : nullptr;
-    const float* bB2 = nk2 ? (BKC ? p.B2 + (size_t)n0 * p.ldb2 : p.B2 + n0) : nullptr;
-
-    auto fetch = [&](int kt) {
-        if (kt < nk1) {
-            const int k0 = kt * BK;
-            const bool full = k0 + BK <= p.K;
-            if (fa1 && full) vnp_load_tile_fast<AV>(ra, AKC ? bA1 + k0 : bA1 + (size_t)k0 * p.lda, oa1, sa1);
-            else vnp_load_tile<BM, BK, AKC, AV>(ra, pA, p.lda, m0, p.M, k0, p.K, va1, tid);
-            if (fb1 && full) vnp_load_tile_fast<BV>(rb, BKC ? bB1 + k0 : bB1 + (size_t)k0 * p.ldb, ob1, sb1);
-            else vnp_load_tile<BN, BK, BKC, BV>(rb, pB, p.ldb, n0, p.N, k0, p.K, vb1, tid);
+    auto fetch = [&](int fm0, int fn0, int fbatch, int kt) {
+        const float* pA = p.A + (size_t)fbatch * p.bsa;
+        const float* pB = p.B + (size_t)fbatch * p.bsb;
+        const int k0 = kt * BK;
+        if (FAST) {
+            vnp_load_tile_fast<AV>(ra, AKC ? pA + (size_t)fm0 * p.lda + k0 : pA + fm0 + (size_t)k0 * p.lda, oa, sa);
+            vnp_load_tile_fast<BV>(rb, BKC ? pB + (size_t)fn0 * p.ldb + k0 : pB + fn0 + (size_t)k0 * p.ldb, ob, sb);
         } else {
-            const int k0 = (kt - nk1) * BK;
-            const bool full = k0 + BK <= p.K2;
-            if (fa2 && full) vnp_load_tile_fast<AV>(ra, AKC ? bA2 + k0 : bA2 + (size_t)k0 * p.lda2, oa2, sa2);
-            else vnp_load_tile<BM, BK, AKC, AV>(ra, p.A2, p.lda2, m0, p.M, k0, p.K2, va2, tid);
-            if (fb2 && full) vnp_load_tile_fast<BV>(rb, BKC ? bB2 + k0 : bB2 + (size_t)k0 * p.ldb2, ob2, sb2);
-            else vnp_load_tile<BN, BK, BKC, BV>(rb, p.B2, p.ldb2, n0, p.N, k0, p.K2, vb2, tid);
+            const bool full = k0 + BK <= p.K;
+            if (va && full && fm0 + BM <= p.M)
+                vnp_load_tile_fast<AV>(ra, AKC ? pA + (size_t)fm0 * p.lda + k0 : pA + fm0 + (size_t)k0 * p.lda, oa, sa);
+            else vnp_load_tile<BM, BK, AKC, AV>(ra, pA, p.lda, fm0, p.M, k0, p.K, va, tid);
+            if (vb && full && fn0 + BN <= p.N)
+                vnp_load_tile_fast<BV>(rb, BKC ? pB + (size_t)fn0 * p.ldb + k0 : pB + fn0 + (size_t)k0 * p.ldb, ob, sb);
+            else vnp_load_tile<BN, BK, BKC, BV>(rb, pB, p.ldb, fn0, p.N, k0, p.K, vb, tid);
         }
     };
     auto stage = [&]() {
@@ -171,94 +153,115 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
         vnp_store_tile<BN, BK, BKC, BV, LDBS>(rb, Bs, tid);
     };
 
-    auto compute = [&](const float* As_, const float* Bs_) {
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            float a[TM][4], b[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / 2) + i * 32 + li;
-                if (AKC) {
-                    const vnp_f4 v = *(const vnp_f4*)&As_[row * LDAS + 8 * q + 4 * lh];
-                    a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) a[i][s] = As_[(8 * q + 4 * lh + s) * LDAS + row];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * (BN / 2) + j * 32 + li;
-                if (BKC) {
-                    const vnp_f4 v = *(const vnp_f4*)&Bs_[col * LDBS + 8 * q + 4 * lh];
-                    b[j][0] = v[0]; b[j][1] = v[1]; b[j][2] = v[2]; b[j][3] = v[3];
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b[j][s] = Bs_[(8 * q + 4 * lh + s) * LDBS + col];
-                }
-            }
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-        }
-    };
+    int w = blockIdx.x;
+    if (w >= total) return;
+    set_item(w);
+    fetch(m0, n0, batch, kt0);
+    stage();
+    __syncthreads();
 
-    if (kt0 < kt1) {
-        fetch(kt0);
-        stage();
-        __syncthreads();
-    }
-    if (DBUF) {
-        // two LDS buffers: the next tile is written while the other buffer may still be read by slower waves;
-        // one barrier per K-tile
-        int cur = 0;
+    while (true) {
+        vnp_f16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        const int wnext = w + gridDim.x;                     // this block's next work item
+        const bool more = wnext < total;
+
         for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) fetch(kt + 1);
-            compute(As + cur * (ASZ + BSZ), Bs + cur * (ASZ + BSZ));
-            if (kt + 1 < kt1) {
-                vnp_store_tile<BM, BK, AKC, AV, LDAS>(ra, As + (cur ^ 1) * (ASZ + BSZ), tid);
-                vnp_store_tile<BN, BK, BKC, BV, LDBS>(rb, Bs + (cur ^ 1) * (ASZ + BSZ), tid);
+            if (kt + 1 < kt1) fetch(m0, n0, batch, kt + 1);
+            else if (more) {
+                // cross-item prefetch: the next item's first K-tile loads overlap the last MFMAs and the epilogue
+                const int cm0 = m0, cn0 = n0, ck0 = kt0, ck1 = kt1, cs = split, cb = batch;
+                set_item(wnext);
+                fetch(m0, n0, batch, kt0);
+                m0 = cm0; n0 = cn0; kt0 = ck0; kt1 = ck1; split = cs; batch = cb;
             }
-            __syncthreads();
-            cur ^= 1;
-        }
-    } else {
-        for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) fetch(kt + 1);
-            compute(As, Bs);
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                float a[TM][4], b[TN][4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = wm * (BM / 2) + i * 32 + li;
+                    if (AKC) {
+                        const vnp_f4 v = *(const vnp_f4*)&As[row * LDAS + 8 * q + 4 * lh];
+                        a[i][0] = v[0]; a[i][1] = v[1]; a[i][2] = v[2]; a[i][3] = v[3];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) a[i][s] = As[(8 * q + 4 * lh + s) * LDAS + row];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = wn * (BN / 2) + j * 32 + li;
+                    if (BKC) {
+                        const vnp_f4 v = *(const vnp_f4*)&Bs[col * LDBS + 8 * q + 4 * lh];
+                        b[j][0] = v[0]; b[j][1] = v[1]; b[j][2] = v[2]; b[j][3] = v[3];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) b[j][s] = Bs[(8 * q + 4 * lh + s) * LDBS + col];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            }
             __syncthreads();
             if (kt + 1 < kt1) {
                 stage();
                 __syncthreads();
             }
         }
-    }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* Cz = p.C + (size_t)split * p.slab + (size_t)batch * p.bsc;
+        // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        {
+            float* Cz = p.C + (size_t)split * p.slab + (size_t)batch * p.bsc;
+            const bool full = FAST || ((m0 + BM <= p.M) && (n0 + BN <= p.N));
+            // per-sample VN bias row = (row / rows_per_group)*3 + row%3 without a division per element: the tile's first
+            // row fixes the group; a tile spans at most one group boundary when rows_per_group >= BM
+            int g0 = 0, r0 = 0;
+            const bool bias_fast = p.bias && p.rows_per_group >= BM;
+            if (p.bias) { g0 = m0 / p.rows_per_group; r0 = m0 - g0 * p.rows_per_group; }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + li;
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int row = m0 + lr;
+                    if (!full && row >= p.M) continue;
+                    const float* brow = nullptr;
+                    if (p.bias) {
+                        int grp;
+                        if (bias_fast) grp = g0 + ((r0 + lr) >= p.rows_per_group ? 1 : 0);
+                        else grp = row / p.rows_per_group;
+                        brow = p.bias + (size_t)(grp * 3 + row % 3) * p.ldbias;
+                    }
+                    float* drow = Cz + (size_t)row * p.ldc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (row < p.M && col < p.N) {
-                    float v = acc[i][j][e];
-                    if (p.bias) v += p.bias[(size_t)((row / p.rows_per_group) * 3 + row % 3) * p.ldbias + col];
-                    float* dst = Cz + (size_t)row * p.ldc + col;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = n0 + wn * (BN / 2) + j * 32 + li;
+                        if (!full && col >= p.N) continue;
+                        float v = acc[i][j][e];
+                        if (brow) v += brow[col];
+                        if (p.accumulate) v += drow[col];
+                        drow[col] = v;
+                    }
                 }
             }
         }
+
+        if (!more) break;
+        w = wnext;
+        set_item(w);
+        stage();                 // the next item's first K-tile (fetched before the last MFMAs) -> LDS
+        __syncthreads();
     }
 }
-

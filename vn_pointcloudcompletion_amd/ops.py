@@ -17,6 +17,11 @@ from ._lib import call, ptr
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# VNMaxPool direction d = Wd (W x): evaluate as (Wd W) x when the pooled tensor is the output of a VNLinear (see
+# VNLinearMaxPoolFn).  Set VNP_POOL_AS_WRITTEN=1 to keep the reference's evaluation order.
+import os as _os
+POOL_DIRECTION_REASSOCIATE = _os.environ.get("VNP_POOL_AS_WRITTEN", "0") != "1"
+
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (variant, flops, start_event, end_event)
 GEMM_PROFILE = None
@@ -44,18 +49,13 @@ def _nchunk(P: int) -> int:
     return (P + c - 1) // c
 
 
-def gemm(A, B, *, op_a=0, op_b=0, out=None, A2=None, B2=None, bias=None, rows_per_group=0,
-         accumulate=False, nsplit=None):
-    """C = op(A) op(B) (+ op(A2) op(B2)) (+ per-sample bias).  See vnp_gemm in include/vnpcc.h."""
+def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumulate=False, nsplit=None):
+    """C = op(A) op(B) (+ per-sample bias).  See vnp_gemm in include/vnpcc.h."""
     A, B = _rows(A), _rows(B)
     M, K = (A.shape[0], A.shape[1]) if op_a == 0 else (A.shape[1], A.shape[0])
     N, Kb = (B.shape[0], B.shape[1]) if op_b == 0 else (B.shape[1], B.shape[0])
     if K != Kb:
         raise _lib.VnpError(f"gemm: inner dimensions differ ({K} vs {Kb})")
-    K2 = 0
-    if A2 is not None:
-        A2, B2 = _rows(A2), _rows(B2)
-        K2 = A2.shape[1] if op_a == 0 else A2.shape[0]
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     elif out.shape != (M, N) or out.stride(1) != 1:
@@ -67,7 +67,7 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, A2=None, B2=None, bias=None, rows_pe
         if bias is None:
             bm = 192 if op_a == 0 else 128
             tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
-            nk = (K + 31) // 32 + ((K2 + 31) // 32 if K2 else 0)
+            nk = (K + 31) // 32
             if tiles < 256 and nk >= 8:
                 nsplit = max(1, min(nk // 4, 1024 // tiles))
     ws = None
@@ -78,12 +78,11 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, A2=None, B2=None, bias=None, rows_pe
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
-         ptr(A2), _ld(A2) if A2 is not None else 0, ptr(B2), _ld(B2) if B2 is not None else 0, K2,
          ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))
     if prof is not None:
         e1.record()
         prof.append(("NT" if (op_a, op_b) == (0, 0) else "NN" if (op_a, op_b) == (0, 1) else "TN" if (op_a, op_b) == (1, 1) else "TT",
-                     2.0 * M * N * (K + K2), nsplit, (M, N, K + K2), e0, e1))
+                     2.0 * M * N * K, nsplit, (M, N, K), e0, e1))
     return out
 
 
@@ -258,27 +257,28 @@ class VNLinearLeakyFn(Function):
         R = x.shape[0]
         C = Wf.shape[0]
         pd = torch.empty((R, 2 * C), device=x.device, dtype=torch.float32)
-        bf = bd = None
         if bias is not None:
             bias = _rows(bias)
-            bf, bd = bias[:, :C], bias[:, C:]
-        gemm(x, Wf, out=pd[:, :C], bias=bf, rows_per_group=rows_per_group, nsplit=1)
-        gemm(x, Wd, out=pd[:, C:], bias=bd, rows_per_group=rows_per_group, nsplit=1)
+        # one GEMM for both halves: [Wf; Wd] is copied into a [2C, Cin] matrix (a few MB at most) so that x is streamed
+        # once and the launch has twice the columns
+        Wcat = torch.cat([Wf, Wd], dim=0)
+        gemm(x, Wcat, out=pd, bias=bias, rows_per_group=rows_per_group, nsplit=1)
         out, mean, rstd = _bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, running_mean, running_var, training, ns)
-        ctx.save_for_backward(x, Wf, Wd, gamma, beta, pd, mean, rstd)
+        ctx.save_for_backward(x, Wcat, gamma, beta, pd, mean, rstd)
         ctx.cfg = (C, rows_per_group, training, ns, bias is not None)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, go):
-        x, Wf, Wd, gamma, beta, pd, mean, rstd = ctx.saved_tensors
+        x, Wcat, gamma, beta, pd, mean, rstd = ctx.saved_tensors
         C, rpg, training, ns, has_bias = ctx.cfg
         gpd, ggamma, gbeta = _bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, ns)
-        gp, gd = gpd[:, :C], gpd[:, C:]
-        gx = gemm(gp, Wf, op_b=1, A2=gd, B2=Wd) if ctx.needs_input_grad[0] else None
-        gWf = _wgrad(gp, x) if ctx.needs_input_grad[1] else None
-        gWd = _wgrad(gd, x) if ctx.needs_input_grad[2] else None
+        gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None          # dX = [dP | dD] [Wf; Wd]
+        gWf = gWd = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gW = _wgrad(gpd, x)                                                     # [2C, Cin] in one split-K launch
+            gWf, gWd = gW[:C], gW[C:]
         gb = _per_sample_colsum(gpd, rpg) if (has_bias and ctx.needs_input_grad[7]) else None
         return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None
 
@@ -334,10 +334,15 @@ class VNMaxPoolFn(Function):
     (the arg-max detaches it in the reference as well)."""
 
     @staticmethod
-    def forward(ctx, x, Wd, G, gs):
+    def forward(ctx, x, Wd, G, gs, x_prev=None, W_prev=None):
+        """``x_prev``, ``W_prev``: when x = x_prev W_prev^T was produced by a VNLinear, the direction d = Wd x can be evaluated
+        as (Wd W_prev) x_prev (contraction over the producer's input channels; see POOL_DIRECTION_REASSOCIATE)."""
         x = _rows(x)
         C = x.shape[1]
-        d = gemm(x, Wd, nsplit=1)
+        if x_prev is not None and POOL_DIRECTION_REASSOCIATE:
+            d = gemm(_rows(x_prev), gemm(Wd, W_prev, op_b=1), nsplit=1)
+        else:
+            d = gemm(x, Wd, nsplit=1)
         nch = _nchunk(gs)
         ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
         ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
@@ -357,7 +362,7 @@ class VNMaxPoolFn(Function):
         gout = _rows(gout)
         gx = torch.empty((G * gs * 3, C), device=gout.device, dtype=torch.float32)
         call("vnp_vn_pool_bwd", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(gx), C)
-        return gx, None, None, None
+        return gx, None, None, None, None, None
 
 
 class VNLinearMaxPoolFn(Function):
@@ -371,7 +376,13 @@ class VNLinearMaxPoolFn(Function):
         x = _rows(x)
         y = gemm(x, W, nsplit=1)
         C = y.shape[1]
-        d = gemm(y, Wd, nsplit=1)
+        if POOL_DIRECTION_REASSOCIATE:
+            # d = Wd (W x) = (Wd W) x: the product of the two weight matrices is formed once per step (8.6 GFLOP for
+            # 2048x2048x1024) and the per-point direction GEMM contracts over Cin instead of Cout (half the FLOPs here).
+            # Same arithmetic up to fp32 re-association.
+            d = gemm(x, gemm(Wd, W, op_b=1), nsplit=1)
+        else:
+            d = gemm(y, Wd, nsplit=1)
         nch = _nchunk(gs)
         ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
         ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)

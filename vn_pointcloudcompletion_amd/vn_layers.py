@@ -182,8 +182,11 @@ class VNMaxPool(nn.Module):
         super().__init__()
         self.map_to_dir = nn.Linear(in_channels, in_channels, bias=False)
 
-    def forward_rows(self, rows, groups, group_size, return_index=False):
-        out, idx = ops.VNMaxPoolFn.apply(rows, self.map_to_dir.weight.detach(), groups, group_size)
+    def forward_rows(self, rows, groups, group_size, return_index=False, producer=None):
+        """``producer`` = (x_prev, VNLinear) when ``rows`` is that layer's output: lets the direction GEMM contract over the
+        producer's input channels (ops.POOL_DIRECTION_REASSOCIATE)."""
+        xp, wp = (producer[0].detach(), producer[1].map_to_feat.weight.detach()) if producer is not None else (None, None)
+        out, idx = ops.VNMaxPoolFn.apply(rows, self.map_to_dir.weight.detach(), groups, group_size, xp, wp)
         return (out, idx) if return_index else out
 
     def forward(self, x):
