@@ -148,6 +148,20 @@ int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* s
 int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr,
                         long long P, int k, int W, float* out, int ldo);
 
+/* Fused FoldingNet layer 0 (rank-2 expansion + BatchNorm + leaky projection) that never writes the [P*3, 2C] (p | d)
+ * tensor: p and d are recomputed from bias / wseed / wcoarse / seed / coarse in every pass.
+ *   mode 0: partial [nchunk][C][2] = (mean, M2) of |p|+eps           (then vnp_vn_bn_finalize)
+ *   mode 1: out [P*3][ldo] = leaky(bn(p), d)
+ *   mode 2: partial [nchunk][C][2] = (sum g_nhat, sum g_nhat*xhat) from the upstream gradient go
+ *   mode 3: part5 [nchunk][5][2C] = per-chunk sums for dbias (rows 0-2), dwseed (3), dwcoarse (4); gcoarse [B*Mc][3]
+ *           (zero-filled here, accumulated atomically); sums [C][2] = reduced mode-2 partials (NULL: eval-mode BatchNorm)
+ * nchunk = ceil(B*Mc*S / vnp_chunk_points()); S must divide vnp_chunk_points(). */
+int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* wseed, const float* wcoarse,
+                   const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int C,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                   float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
+                   float* part5, float* gcoarse);
+
 /* ---- small reductions -------------------------------------------------------------------------------------- */
 /* out[r] = sum_c X[r][c]*w[c] (+ add[((r/3)/add_group)*3 + r%3]) : final VNLinear(C->1) + point_feat (pcn.py:387) */
 int vnp_rowdot(hipStream_t st, const float* X, int ldx, const float* w, long long R, int C,

@@ -592,6 +592,193 @@ extern "C" int vnp_pool_lin_bwd(hipStream_t st, const float* gout, int ldgo, con
     return vnp_last_error();
 }
 
+
+// ------------------------------------------------------------------------------------------------ fused folding layer
+// FoldingNet layer 0 end to end WITHOUT its [P*3, 2C] pre-activation tensor (3.2 GB at B = 32): p and d are recomputed
+// from the per-sample bias and the rank-2 per-point term wherever they are needed
+//   p[t][j] = bias[b*3+t][j]   + wseed[j]  *seed[(b)][s][t] + wcoarse[j]  *coarse[b][mc][t]        (j <  C)
+//   d[t][j] = bias[b*3+t][C+j] + wseed[C+j]*seed[(b)][s][t] + wcoarse[C+j]*coarse[b][mc][t]
+// MODE 0: Welford statistics of |p|+eps per chunk (-> vnp_vn_bn_finalize)          reads nothing big, writes nothing big
+// MODE 1: out = leaky(bn(p), d)                                                     writes out
+// MODE 2: backward sums S1 = sum g_nhat, S2 = sum g_nhat*xhat per chunk             reads go
+// MODE 3: backward: gp, gd on the fly -> partial sums for dbias / dwseed / dwcoarse per chunk and dcoarse (atomics)
+// block = 64 columns x 4 coarse-point lanes; a chunk = VNP_CHUNK points = VNP_CHUNK/S coarse points.
+struct VnpFoldArgs {
+    const float* bias; int ldb;
+    const float* wseed; const float* wcoarse; const float* seed; int seed_batched;
+    const float* coarse; int Mc, S, C; long long ncoarse;      // ncoarse = B*Mc
+    const float* mean; const float* rstd; const float* gamma; const float* beta; float ns;
+    float* out; int ldo;                  // MODE 1
+    const float* go; int ldgo;            // MODE 2, 3
+    float2* partial;                      // MODE 0: (mean, M2); MODE 2: (S1, S2)   [nchunk][C]
+    const float* sums; float inv_count;   // MODE 3: reduced sums [C][2] (nullptr in eval mode)
+    float* part5;                         // MODE 3: [nchunk][5][2C]
+    float* gcoarse;                       // MODE 3: [B*Mc][3], zero-filled, atomically accumulated
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a)
+{
+    __shared__ float red[4][5][2][64];
+    __shared__ int cnt[4];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cx;
+    const bool live = j < a.C;
+    const int C = a.C, S = a.S;
+    const int cpc = VNP_CHUNK / S;                                 // coarse points per chunk
+    const long long cp0 = (long long)blockIdx.y * cpc;
+    const long long cp1 = min(a.ncoarse, cp0 + cpc);
+    float wsf = 0, wcf = 0, wsd = 0, wcd = 0, mu = 0, rs = 0, ga = 0, be = 0;
+    if (live) {
+        wsf = a.wseed[j]; wcf = a.wcoarse[j]; wsd = a.wseed[C + j]; wcd = a.wcoarse[C + j];
+        if (a.mean) { mu = a.mean[j]; rs = a.rstd[j]; ga = a.gamma[j]; be = a.beta[j]; }
+    }
+    const float m1 = (MODE == 3 && a.sums) ? a.sums[2 * (live ? j : 0)] * a.inv_count : 0.f;
+    const float m2 = (MODE == 3 && a.sums) ? a.sums[2 * (live ? j : 0) + 1] * a.inv_count : 0.f;
+    float wmean = 0.f, wm2 = 0.f; int wk = 0;                      // MODE 0
+    float s1 = 0.f, s2 = 0.f;                                      // MODE 2
+    float acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};          // MODE 3: [feat|dir][bias t0..2, seed, coarse]
+    for (long long cp = cp0 + py; cp < cp1; cp += 4) {
+        const int b = (int)(cp / a.Mc);
+        const float c0 = a.coarse[cp * 3], c1 = a.coarse[cp * 3 + 1], c2 = a.coarse[cp * 3 + 2];
+        float pf[3] = {0, 0, 0}, pdv[3] = {0, 0, 0};
+        if (live) {
+            const float* bb = a.bias + (size_t)b * 3 * a.ldb;
+            pf[0] = bb[j] + wcf * c0; pf[1] = bb[a.ldb + j] + wcf * c1; pf[2] = bb[2 * a.ldb + j] + wcf * c2;
+            pdv[0] = bb[C + j] + wcd * c0; pdv[1] = bb[a.ldb + C + j] + wcd * c1; pdv[2] = bb[2 * a.ldb + C + j] + wcd * c2;
+        }
+        const float* sd = a.seed + (a.seed_batched ? (size_t)b * S * 3 : 0);
+        float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;                     // MODE 3: dcoarse contributions of this column
+        for (int s = 0; s < S; ++s) {
+            const float e0 = sd[s * 3], e1 = sd[s * 3 + 1], e2 = sd[s * 3 + 2];
+            const float x0 = pf[0] + wsf * e0, x1 = pf[1] + wsf * e1, x2 = pf[2] + wsf * e2;
+            const float pn = sqrtf(vnp_sq3(x0, x1, x2)), n = pn + VNP_EPS;
+            if (MODE == 0) {
+                if (live) { ++wk; const float dl = n - wmean; wmean += dl / (float)wk; wm2 += dl * (n - wmean); }
+                continue;
+            }
+            const float xh = (n - mu) * rs, nh = xh * ga + be, sc = nh / n;
+            const float q0 = x0 * sc, q1 = x1 * sc, q2 = x2 * sc;
+            const float d0 = pdv[0] + wsd * e0, d1 = pdv[1] + wsd * e1, d2 = pdv[2] + wsd * e2;
+            const float dot = q0 * d0 + q1 * d1 + q2 * d2;
+            const size_t row = ((size_t)cp * S + s) * 3;
+            if (MODE == 1) {
+                float o0 = q0, o1 = q1, o2 = q2;
+                if (dot < 0.f) {
+                    const float al = (1.f - a.ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                    o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
+                }
+                if (live) { a.out[row * a.ldo + j] = o0; a.out[(row + 1) * a.ldo + j] = o1; a.out[(row + 2) * a.ldo + j] = o2; }
+                continue;
+            }
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (live) { g0 = a.go[row * a.ldgo + j]; g1 = a.go[(row + 1) * a.ldgo + j]; g2 = a.go[(row + 2) * a.ldgo + j]; }
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f;                    // dL/dd
+            if (dot < 0.f) {
+                const float cc = 1.f - a.ns;
+                const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                const float al = dot * inv;
+                const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
+                const float k1 = cc * gdd * inv;
+                h0 = -cc * (al * g0 + gdd * (q0 * inv - 2.f * al * inv * d0));
+                h1 = -cc * (al * g1 + gdd * (q1 * inv - 2.f * al * inv * d1));
+                h2 = -cc * (al * g2 + gdd * (q2 * inv - 2.f * al * inv * d2));
+                g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;       // now dL/dq
+            }
+            const float gs = g0 * x0 + g1 * x1 + g2 * x2;
+            const float gnh = gs / n;
+            if (MODE == 2) { s1 += gnh; s2 += gnh * xh; continue; }
+            // MODE 3: dL/dp = sc*gq + gn * p/|p|
+            const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
+            const float kk = pn > 0.f ? gn / pn : 0.f;
+            const float r0 = sc * g0 + kk * x0, r1 = sc * g1 + kk * x1, r2 = sc * g2 + kk * x2;
+            acc[0][0] += r0; acc[0][1] += r1; acc[0][2] += r2;
+            acc[0][3] += r0 * e0 + r1 * e1 + r2 * e2;
+            acc[0][4] += r0 * c0 + r1 * c1 + r2 * c2;
+            acc[1][0] += h0; acc[1][1] += h1; acc[1][2] += h2;
+            acc[1][3] += h0 * e0 + h1 * e1 + h2 * e2;
+            acc[1][4] += h0 * c0 + h1 * c1 + h2 * c2;
+            gc0 += r0 * wcf + h0 * wcd; gc1 += r1 * wcf + h1 * wcd; gc2 += r2 * wcf + h2 * wcd;
+        }
+        if (MODE == 3) {
+            // dcoarse[cp][t] = sum over columns (this wave's 64, then the other column tiles through atomics)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gc0 += __shfl_xor(gc0, o); gc1 += __shfl_xor(gc1, o); gc2 += __shfl_xor(gc2, o); }
+            if (cx == 0) {
+                atomicAdd(&a.gcoarse[cp * 3], gc0); atomicAdd(&a.gcoarse[cp * 3 + 1], gc1); atomicAdd(&a.gcoarse[cp * 3 + 2], gc2);
+            }
+        }
+    }
+    if (MODE == 0) {
+        red[py][0][0][cx] = wmean; red[py][1][0][cx] = wm2;
+        if (cx == 0) cnt[py] = (int)((cp1 - cp0 - py + 3) / 4 > 0 ? ((cp1 - cp0 - py + 3) / 4) * S : 0);
+        __syncthreads();
+        if (py == 0 && live) {
+            double na = cnt[0], ma = red[0][0][0][cx], Ma = red[0][1][0][cx];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) vnp_chan_merge(na, ma, Ma, (double)cnt[q], (double)red[q][0][0][cx], (double)red[q][1][0][cx]);
+            a.partial[(size_t)blockIdx.y * C + j] = make_float2((float)ma, (float)Ma);
+        }
+    } else if (MODE == 2) {
+        red[py][0][0][cx] = s1; red[py][1][0][cx] = s2;
+        __syncthreads();
+        if (py == 0 && live)
+            a.partial[(size_t)blockIdx.y * C + j] = make_float2((red[0][0][0][cx] + red[1][0][0][cx]) + (red[2][0][0][cx] + red[3][0][0][cx]),
+                                                                (red[0][1][0][cx] + red[1][1][0][cx]) + (red[2][1][0][cx] + red[3][1][0][cx]));
+    } else if (MODE == 3) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) red[py][r][h][cx] = acc[h][r];
+        __syncthreads();
+        if (py == 0 && live) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 5; ++r)
+                    a.part5[((size_t)blockIdx.y * 5 + r) * 2 * C + h * C + j] =
+                        (red[0][r][h][cx] + red[1][r][h][cx]) + (red[2][r][h][cx] + red[3][r][h][cx]);
+        }
+    }
+}
+
+// mode 0: statistics partials; 1: forward; 2: backward sums; 3: backward gradients (see ops.FoldBnLeakyFn).
+// partial: [nchunk][C][2]; part5: [nchunk][5][2C]; gcoarse [B*Mc][3] is zero-filled here in mode 3.  S must divide
+// vnp_chunk_points().
+extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* wseed, const float* wcoarse,
+                              const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int C,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                              float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
+                              float* part5, float* gcoarse)
+{
+    if (!bias || !wseed || !wcoarse || !seed || !coarse || B <= 0 || Mc <= 0 || S <= 0 || C <= 0 || VNP_CHUNK % S) return VNP_EINVAL;
+    if (mode < 0 || mode > 3) return VNP_EINVAL;
+    if (mode > 0 && (!mean || !rstd || !gamma || !beta)) return VNP_EINVAL;
+    if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
+    if (mode == 1 && !out) return VNP_EINVAL;
+    if (mode >= 2 && !go) return VNP_EINVAL;
+    if (mode == 3 && (!part5 || !gcoarse)) return VNP_EINVAL;
+    VnpFoldArgs a;
+    a.bias = bias; a.ldb = ldb; a.wseed = wseed; a.wcoarse = wcoarse; a.seed = seed; a.seed_batched = seed_batched;
+    a.coarse = coarse; a.Mc = Mc; a.S = S; a.C = C; a.ncoarse = (long long)B * Mc;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
+    a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo; a.partial = (float2*)partial;
+    a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f; a.part5 = part5; a.gcoarse = gcoarse;
+    const long long P = (long long)B * Mc * S;
+    const int nchunk = vnp_cdiv(P, VNP_CHUNK);
+    if (nchunk > 65535) return VNP_EINVAL;
+    dim3 grid(vnp_cdiv(C, 64), nchunk), block(256);
+    if (mode == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<0>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((vnp_fold_fused_kernel<1>), grid, block, 0, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((vnp_fold_fused_kernel<2>), grid, block, 0, st, a);
+    else {
+        hipError_t e = hipMemsetAsync(gcoarse, 0, (size_t)B * Mc * 3 * 4, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((vnp_fold_fused_kernel<3>), grid, block, 0, st, a);
+    }
+    return vnp_last_error();
+}
+
 // ================================================================================================ C-ABI
 static inline dim3 vnp_grid_pc(long long P, int C) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, VNP_CHUNK)); }
 

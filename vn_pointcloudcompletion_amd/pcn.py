@@ -127,11 +127,18 @@ class VN_FoldingNet(nn.Module):
         wseed = torch.cat([Wf[:, latent], Wd[:, latent]])
         wcoarse = torch.cat([Wf[:, latent + 1], Wd[:, latent + 1]])
         coarse = coarse.contiguous().float()
-        pd = ops.FoldFn.apply(bias, wseed, wcoarse, seed, coarse)               # [B*Md*3, 512] = (p | d) of layer 0
         bn = l0.batchnorm.bn
         l0.batchnorm._tick()
-        f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
-                                  l0.negative_slope)
+        from . import _lib
+        chunk = _lib.chunk_points()
+        if (Mc * S) % chunk == 0 and chunk % S == 0:
+            # fused layer 0: the (p | d) pre-activations are recomputed inside every pass instead of being stored
+            f = ops.FoldBnLeakyFn.apply(bias, wseed, wcoarse, seed, coarse, bn.weight, bn.bias, bn.running_mean,
+                                        bn.running_var, self.training, l0.negative_slope)
+        else:
+            pd = ops.FoldFn.apply(bias, wseed, wcoarse, seed, coarse)           # [B*Md*3, 512] = (p | d) of layer 0
+            f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
+                                      l0.negative_slope)
         f = self.final_conv[1].forward_rows(f)
         fine = ops.LinOutFn.apply(f, self.final_conv[2].map_to_feat.weight, coarse, S)          # [B*Md*3]
         return fine.reshape(B, Mc * S, 3)
