@@ -9,13 +9,19 @@
 // its result into a packed 64-bit word per query with atomicMin:  (float bits of d) << 32 | index.  d >= 0, so the
 // unsigned order of the bits is the order of the floats, and among equal distances the smaller index wins —
 // exactly the reference's strict '<' scan.  A second tiny kernel unpacks (dist, idx).
-// This is VALU-bound (about 10 lane-ops per pair), not HBM-bound: ~12 B per point are read once per block.
+// This is VALU-bound (~9.5 lane-op-equivalents per pair), not HBM-bound: ~12 B per point are read once per block.
 #include "vnp_common.h"
 
 #define CH_THREADS 256
 #define CH_QPT 4                 // queries per thread
 #define CH_TILE 1024             // reference points staged per LDS tile (16 KB)
 
+// Measured notes on the inner loop (kept for the next reader): (1) packing the arithmetic (v_pk_add/mul/fma_f32) halves the
+// instruction count but not the time — on gfx950 a wave64 v_pk_*_f32 issues in 4 cycles, the bound is 32 lane-ops / clk /
+// SIMD either way, and the extra v_mov splats made it 8 % slower; (2) tracking only chunk minima (v_min3) and re-scanning
+// a chunk when some lane improved was slower too: with 256 queries per wave some lane improves in 40-60 % of 8-reference
+// chunks.  The plain form below — 3 sub, 1 mul, 2 fma, 1 cmp, 2 select per pair, 4 queries per thread sharing each LDS
+// broadcast read — runs 18.3 G pairs/step in ~3.1 ms = ~70 % of the VALU issue bound.
 __global__ void __launch_bounds__(CH_THREADS) vnp_chamfer_nn_kernel(const float* __restrict__ q, int n, const float* __restrict__ r, int m,
                                                                    int slice, unsigned long long* __restrict__ packed)
 {
