@@ -97,7 +97,13 @@ int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, const float*
                          const float* p, int ldp, const float* d, int ldd,
                          float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
                          const float* mean, const float* rstd, const float* gamma, const float* beta,
-                         float negative_slope, float* partial);
+                         float negative_slope, float* partial, float* gw_partial);
+/* gw_partial (rank-1 mode only, nullable) [nchunk][C]: per-chunk sums of go_row . out, i.e. dL/dw of a final VNLinear(C->1)
+ * whose input (this layer's output) was never stored.
+ * Forward of that fusion: fine[pt*3+t] = sum_c leaky(bn(p),d)[pt,t,c]*w[c] + add[(pt/add_group)*3+t] (models/pcn.py:341-346,387) */
+int vnp_vn_bn_leaky_rowdot_fwd(hipStream_t st, const float* p, int ldp, const float* d, int ldd, long long P, int C,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               float negative_slope, const float* w, const float* add, int add_group, float* out);
 /* backward phase 2: g (dL/dbn(p)) -> dL/dp in place; S [C][2] reduced partial sums (NULL: eval-mode BatchNorm) */
 int vnp_vn_bn_bwd2(hipStream_t st, float* g, int ldg, const float* p, int ldp, long long P, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta,

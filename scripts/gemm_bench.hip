@@ -1,6 +1,7 @@
 // Tuning harness (dev tool, not part of the library): times variants of vnp_gemm_kernel in one process, interleaved.
 //   hipcc --offload-arch=gfx950 -O3 -I vn_pointcloudcompletion_amd/csrc scripts/gemm_bench.hip -o gpurun_out/gemm_bench
 #include "gemm_kernel.h"
+#include "gemm_wave_private.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -20,6 +21,22 @@ float run(const VnpGemmArgs& p0, int iters)
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((vnp_gemm_kernel<BM, BN, BK, AKC, BKC, FAST>), grid, block, 0, 0, p);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
+template <int BK>
+float run_wp(const VnpGemmArgs& p0, int iters)
+{
+    VnpGemmArgs p = p0;
+    int items = (p.M / 192) * (p.N / 128);
+    dim3 grid(items < 512 ? items : 512), block(256);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((vnp_gemm_wp_kernel<BK>), grid, block, 0, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((vnp_gemm_wp_kernel<BK>), grid, block, 0, 0, p);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / iters;
@@ -50,6 +67,7 @@ int main()
         for (int round = 0; round < 2; ++round) {
             float t;
             t = run<192, 128, 32, true, true, true, 2>(p, it);  printf("  r%d 192x128x32 fast  2/CU %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
+            t = run_wp<16>(p, it); printf("  r%d wave-private BK16    %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
             t = run<192, 128, 32, true, true, false, 2>(p, it); printf("  r%d 192x128x32 gen   2/CU %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
             t = run<128, 128, 32, true, true, true, 3>(p, it);  printf("  r%d 128x128x32 fast  3/CU %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
         }

@@ -151,14 +151,15 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                                                                long long P, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float ns,
-                                                               float2* __restrict__ partial)
+                                                               float2* __restrict__ partial, float* __restrict__ gw_partial)
 {
     __shared__ float2 red[4][64];
+    __shared__ float red3[4][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
     const long long p1 = min(P, p0 + VNP_CHUNK);
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
         float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, gc = 0.f;
         if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
@@ -185,6 +186,16 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                 const float d0 = rd[0], d1 = rd[ldd], d2 = rd[2 * ldd];
                 const float dot = q0 * d0 + q1 * d1 + q2 * d2;
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+                if (gw_partial) {
+                    // layer output (q or its projection) against the upstream gradient: d(loss)/d(w_out) of the fused
+                    // final VNLinear(C -> 1)
+                    float o0 = q0, o1 = q1, o2 = q2;
+                    if (dot < 0.f) {
+                        const float al = (1.f - ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                        o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
+                    }
+                    s3 += go_row[pt * 3] * o0 + go_row[pt * 3 + 1] * o1 + go_row[pt * 3 + 2] * o2;
+                }
                 if (dot < 0.f) {
                     const float cc = 1.f - ns;
                     const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
@@ -208,13 +219,52 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
             }
         }
     }
-    if (partial) {
+    if (partial || gw_partial) {
         red[py][cx] = make_float2(s1, s2);
+        red3[py][cx] = s3;
         __syncthreads();
         if (py == 0 && c < C) {
             float2 a = red[0][cx], b = red[1][cx], e = red[2][cx], f = red[3][cx];
-            partial[(size_t)blockIdx.y * C + c] = make_float2((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y));
+            if (partial) partial[(size_t)blockIdx.y * C + c] = make_float2((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y));
+            if (gw_partial) gw_partial[(size_t)blockIdx.y * C + c] = (red3[0][cx] + red3[1][cx]) + (red3[2][cx] + red3[3][cx]);
         }
+    }
+}
+
+// fine[pt*3+t] = sum_c leaky(bn(p), d)[pt,t,c] * w[c] + add[((pt / add_group))*3 + t]: the last VNLinearLeakyReLU of the
+// decoder fused with the final VNLinear(C -> 1) and the residual point_feat (models/pcn.py:341-346,387): the [P*3, C]
+// layer output is never written.  One wave per point (4 points per block), lanes stride over the channels.
+__global__ void __launch_bounds__(256) vnp_bn_leaky_rowdot_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ d, int ldd,
+                                                                 long long P, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float ns,
+                                                                 const float* __restrict__ w, const float* __restrict__ add, int add_group,
+                                                                 float* __restrict__ out)
+{
+    const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (pt >= P) return;
+    const float* rp = p + (size_t)pt * 3 * ldp;
+    const float* rd = d + (size_t)pt * 3 * ldd;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float q0 = rp[c], q1 = rp[ldp + c], q2 = rp[2 * ldp + c];
+        const float n = sqrtf(vnp_sq3(q0, q1, q2)) + VNP_EPS;
+        const float s = ((n - mean[c]) * rstd[c] * gamma[c] + beta[c]) / n;
+        q0 *= s; q1 *= s; q2 *= s;
+        const float d0 = rd[c], d1 = rd[ldd + c], d2 = rd[2 * ldd + c];
+        const float dot = q0 * d0 + q1 * d1 + q2 * d2;
+        if (dot < 0.f) {
+            const float al = (1.f - ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+            q0 -= al * d0; q1 -= al * d1; q2 -= al * d2;
+        }
+        const float wc = w[c];
+        a0 += q0 * wc; a1 += q1 * wc; a2 += q2 * wc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+    if (lane == 0) {
+        const float* ad = add ? add + (pt / add_group) * 3 : nullptr;
+        out[pt * 3] = a0 + (ad ? ad[0] : 0.f); out[pt * 3 + 1] = a1 + (ad ? ad[1] : 0.f); out[pt * 3 + 2] = a2 + (ad ? ad[2] : 0.f);
     }
 }
 
@@ -820,14 +870,26 @@ extern "C" int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, c
                                     const float* p, int ldp, const float* d, int ldd,
                                     float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                    float negative_slope, float* partial)
+                                    float negative_slope, float* partial, float* gw_partial)
 {
     if (!p || !gq || P <= 0 || C <= 0) return VNP_EINVAL;
+    if (gw_partial && (go || !d)) return VNP_EINVAL;
     if (!go && (!go_row || !go_col)) return VNP_EINVAL;
     if (d && !gd) return VNP_EINVAL;
     if (mean && (!rstd || !gamma || !beta || !partial)) return VNP_EINVAL;
     hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
-                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial);
+                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_vn_bn_leaky_rowdot_fwd(hipStream_t st, const float* p, int ldp, const float* d, int ldd, long long P, int C,
+                                          const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                          float negative_slope, const float* w, const float* add, int add_group, float* out)
+{
+    if (!p || !d || !mean || !rstd || !gamma || !beta || !w || !out || P <= 0 || C <= 0) return VNP_EINVAL;
+    if (add && add_group <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_bn_leaky_rowdot_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), 0, st, p, ldp, d, ldd, P, C, mean, rstd, gamma, beta,
+                       negative_slope, w, add, add_group > 0 ? add_group : 1, out);
     return vnp_last_error();
 }
 

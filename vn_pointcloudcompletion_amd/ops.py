@@ -142,8 +142,10 @@ def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training,
     return out, mean, rstd
 
 
-def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_bn=True, go_row=None, go_col=None):
-    """Returns (gpd [R, 2C or C] with dL/dp in [:, :C] and dL/dd in [:, C:], ggamma, gbeta)."""
+def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_bn=True, go_row=None, go_col=None,
+                       want_gw=False):
+    """Returns (gpd [R, 2C or C] with dL/dp in [:, :C] and dL/dd in [:, C:], ggamma, gbeta[, gw]).
+    Rank-1 upstream gradient: go=None, go[r, c] = go_row[r] * go_col[c]; want_gw adds dL/d(go_col) = sum_r go_row[r]*out[r, :]."""
     R = p.shape[0]
     P = R // 3
     dev = p.device
@@ -154,12 +156,16 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
     gd = gpd[:, C:] if has_d else None
     nch = _nchunk(P)
     part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32) if use_bn else None
+    nch_pad = (nch + 255) // 256 * 256 if nch > 1024 else nch
+    gw_part = None
+    if want_gw:
+        gw_part = (torch.zeros if nch_pad != nch else torch.empty)((nch_pad, C), device=dev, dtype=torch.float32)
     if go is not None:
         go = _rows(go)
     call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
          ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0, ptr(gq), ldg, ptr(gd), ldg, P, C,
          ptr(mean) if use_bn else None, ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None,
-         ns, ptr(part))
+         ns, ptr(part), ptr(gw_part))
     ggamma = gbeta = None
     if use_bn:
         S = torch.empty((C, 2), device=dev, dtype=torch.float32)
@@ -167,6 +173,8 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
         call("vnp_vn_bn_bwd2", ptr(gq), ldg, ptr(p), _ld(p), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
              ptr(S) if training else None, P)
         gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
+    if want_gw:
+        return gpd, ggamma, gbeta, reduce_rows(gw_part, 1, nch_pad, C)
     return gpd, ggamma, gbeta
 
 
@@ -281,6 +289,58 @@ class VNLinearLeakyFn(Function):
             gWf, gWd = gW[:C], gW[C:]
         gb = _per_sample_colsum(gpd, rpg) if (has_bias and ctx.needs_input_grad[7]) else None
         return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None
+
+
+class VNLinearLeakyOutFn(Function):
+    """Last two layers of VN_FoldingNet fused (models/pcn.py:341-346,387): VNLinearLeakyReLU(C_in -> C) followed by
+    VNLinear(C -> 1) and the residual point_feat.  The [P*3, C] activation between them is never written (forward) nor
+    its gradient (backward: rank-1 upstream gradient g_fine[r] * w_out[c] generated inside the BatchNorm/leaky backward).
+    Returns fine [P*3]."""
+
+    @staticmethod
+    def forward(ctx, x, Wf, Wd, gamma, beta, running_mean, running_var, w_out, coarse, S, training, ns):
+        x = _rows(x)
+        R = x.shape[0]
+        P = R // 3
+        C = Wf.shape[0]
+        dev = x.device
+        Wcat = torch.cat([Wf, Wd], dim=0)
+        pd = gemm(x, Wcat, nsplit=1)                                           # [R, 2C]
+        p, d = pd[:, :C], pd[:, C:]
+        if training:
+            nch = _nchunk(P)
+            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                 BN_MOMENTUM, BN_EPS)
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+        w = w_out.reshape(-1).contiguous()
+        coarse = coarse.contiguous()
+        fine = torch.empty(R, device=dev, dtype=torch.float32)
+        call("vnp_vn_bn_leaky_rowdot_fwd", ptr(p), _ld(p), ptr(d), _ld(d), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             ptr(w), ptr(coarse), S, ptr(fine))
+        ctx.save_for_backward(x, Wcat, gamma, beta, pd, mean, rstd, w)
+        ctx.cfg = (C, S, tuple(coarse.shape), training, ns)
+        return fine
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, Wcat, gamma, beta, pd, mean, rstd, w = ctx.saved_tensors
+        C, S, cshape, training, ns = ctx.cfg
+        g = g.contiguous()
+        gpd, ggamma, gbeta, gw = _bn_leaky_backward(None, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, ns,
+                                                    go_row=g, go_col=w, want_gw=True)
+        gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None
+        gW = _wgrad(gpd, x)
+        gcoarse = torch.empty(cshape, device=g.device, dtype=torch.float32)
+        call("vnp_group_sum3", ptr(g), g.numel() // 3 // S, S, ptr(gcoarse), 0)
+        return gx, gW[:C], gW[C:], ggamma, gbeta, None, None, gw.reshape(1, C), gcoarse, None, None, None
 
 
 class VNBnLeakyFn(Function):

@@ -139,6 +139,11 @@ class VN_FoldingNet(nn.Module):
             pd = ops.FoldFn.apply(bias, wseed, wcoarse, seed, coarse)           # [B*Md*3, 512] = (p | d) of layer 0
             f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training,
                                       l0.negative_slope)
-        f = self.final_conv[1].forward_rows(f)
-        fine = ops.LinOutFn.apply(f, self.final_conv[2].map_to_feat.weight, coarse, S)          # [B*Md*3]
+        l1 = self.final_conv[1]
+        bn1 = l1.batchnorm.bn
+        l1.batchnorm._tick()
+        # final_conv[1] + final_conv[2] + point_feat fused: the 256-channel activation between them is never stored
+        fine = ops.VNLinearLeakyOutFn.apply(f, l1.map_to_feat.weight, l1.map_to_dir.weight, bn1.weight, bn1.bias, bn1.running_mean,
+                                            bn1.running_var, self.final_conv[2].map_to_feat.weight, coarse, S, self.training,
+                                            l1.negative_slope)                                   # [B*Md*3]
         return fine.reshape(B, Mc * S, 3)
