@@ -212,6 +212,15 @@ def main():
                         "ln_gx": xr.grad, "ln_ggamma": m.layer_norm.weight.grad, "ln_gbeta": m.layer_norm.bias.grad})
             check(O.vn_layer_norm(x, m.layer_norm.weight.detach(), m.layer_norm.bias.detach()), y, "vn_layer_norm")
         out[f"x_{tag}"] = x
+    # VNStdFeature (unused by PCNNet; kept for layer-library completeness): C = 8 -> 4 -> 2 -> 3 frame vectors
+    for nf in (False, True):
+        m = vl.VNStdFeature(8, dim=4, normalize_frame=nf)
+        O.closed_form_fill(m.state_dict())
+        m.train()
+        xs = torch.randn(2, 8, 3, 16, generator=torch.Generator().manual_seed(99))      # own stream: later sections keep theirs
+        ys, zs = m(xs)
+        tagf = "std_nf" if nf else "std"
+        out.update({f"{tagf}_x": xs, f"{tagf}_y": ys, f"{tagf}_z": zs})
     npz("layers.npz", **out)
 
     # ------------------------------------------------------- 2. small VN_FoldingNet

@@ -141,3 +141,15 @@ def test_mean_pool(lib_built):
     g = torch.randn_like(y)
     y.backward(g)
     assert relerr(x.grad, (g / 4).unsqueeze(-1).expand_as(x)) < 1e-6
+
+
+@pytest.mark.parametrize("nf", [False, True])
+def test_vnstdfeature(G, nf):
+    from oracle.vn_oracle import closed_form_fill
+    from vn_pointcloudcompletion_amd.vn_layers import VNStdFeature
+    tag = "std_nf" if nf else "std"
+    m = VNStdFeature(8, dim=4, normalize_frame=nf)
+    closed_form_fill(m.state_dict())
+    m = m.cuda().train()
+    y, z = m(t(G[f"{tag}_x"]))
+    assert relerr(y, G[f"{tag}_y"]) < 1e-4 and relerr(z, G[f"{tag}_z"]) < 1e-4

@@ -129,11 +129,11 @@ class VNLinearLeakyReLU(nn.Module):
         """``global_rows`` [G*3, Cg]: per-group features standing for Cg of the input channels, i.e. the layer acts on
         cat([global.expand(n), x], dim=1) (``global_first``, models/pcn.py:172) or cat([x, global.expand(n)], dim=1)
         (models/pcn.py:486,488) without materialising the broadcast; a group is ``rows_per_group``/3 consecutive points."""
-        if self.share_nonlinearity:
-            raise NotImplementedError("share_nonlinearity=True is not used on the PCNNet paths")
         bn = self.batchnorm.bn
         self.batchnorm._tick()
         Wf, Wd = self.map_to_feat.weight, self.map_to_dir.weight
+        if self.share_nonlinearity:
+            Wd = Wd.expand(Wf.shape[0], -1)              # one shared direction (vn_layers.py:56-57): same row for every channel
         bias = None
         if global_rows is not None:
             cg = global_rows.shape[1]
@@ -208,3 +208,41 @@ def mean_pool(x, dim=-1, keepdim=False):
         y = ops.FromRowsFn.apply(out, B, G // B)
         return y.reshape(B, rows.shape[1], 3, *tail[:-1])
     return x.mean(dim=dim, keepdim=keepdim)
+
+
+class VNStdFeature(nn.Module):
+    """models/vn_layers.py:174-220: a learned, rotation-equivariant frame z0 and the invariant features x_std = x . z0.
+    Not used by any PCNNet path; the two VN layers run on libvnpcc, the 3x3 frame algebra (a few
+    floats per point) stays in torch."""
+
+    def __init__(self, in_channels, dim=4, normalize_frame=False, share_nonlinearity=False, negative_slope=0.2):
+        super().__init__()
+        self.dim = dim
+        self.normalize_frame = normalize_frame
+        self.vn1 = VNLinearLeakyReLU(in_channels, in_channels // 2, dim=dim, share_nonlinearity=share_nonlinearity,
+                                     negative_slope=negative_slope)
+        self.vn2 = VNLinearLeakyReLU(in_channels // 2, in_channels // 4, dim=dim, share_nonlinearity=share_nonlinearity,
+                                     negative_slope=negative_slope)
+        self.vn_lin = nn.Linear(in_channels // 4, 2 if normalize_frame else 3, bias=False)
+
+    def forward(self, x):
+        rows, meta = to_rows(x)
+        z = self.vn2.forward_rows(self.vn1.forward_rows(rows))
+        z0 = from_rows(ops.VNLinearFn.apply(z, self.vn_lin.weight, None, 0), meta)          # [B, 2|3, 3, N, ...]
+        if self.normalize_frame:
+            v1 = z0[:, 0, :]
+            u1 = v1 / (torch.sqrt((v1 * v1).sum(1, keepdims=True)) + EPS)
+            v2 = z0[:, 1, :]
+            v2 = v2 - (v2 * u1).sum(1, keepdims=True) * u1
+            u2 = v2 / (torch.sqrt((v2 * v2).sum(1, keepdims=True)) + EPS)
+            u3 = torch.cross(u1, u2, dim=1)
+            z0 = torch.stack([u1, u2, u3], dim=1).transpose(1, 2)
+        else:
+            z0 = z0.transpose(1, 2)
+        if self.dim == 4:
+            x_std = torch.einsum("bijm,bjkm->bikm", x, z0)
+        elif self.dim == 3:
+            x_std = torch.einsum("bij,bjk->bik", x, z0)
+        else:
+            x_std = torch.einsum("bijmn,bjkmn->bikmn", x, z0)
+        return x_std, z0
