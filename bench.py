@@ -5,8 +5,14 @@ of vn_pointnet + vn_foldingnet on synthetic (B,2048,3) -> (B,16384,3) clouds, fp
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the dominant kernel, the fp32-MFMA GEMM,
-timed per launch with HIP events on its launch stream) and `cpu_baseline` (the torch-CPU oracle on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the dominant kernel, the GEMM, timed per
+launch with HIP events on its launch stream) and `cpu_baseline` (the torch-CPU oracle on a bounded sample).
+
+GEMM arithmetic: fp32 operands and fp32 results; by default each operand is split EXACTLY into three bf16
+terms and six bf16 MFMA products are accumulated in fp32 (error vs fp64 at or below the fp32-input MFMA's — asserted by
+tests/test_gpu_gemm.py::test_split_is_fp32_grade).  The roofline is priced on the bf16 pipe actually used: peak = 2500/6
+TFLOP/s of fp32-equivalent work.  At N = 1 the same step is also timed with the fp32-input MFMA kernels
+(VNP_GEMM_MODE=fp32) and reported beside it as `fp32_mfma_mode`.
 """
 import argparse
 import json
@@ -22,6 +28,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: bf16 dense
+SPLIT_PRODUCTS = 6                     # bf16 MFMA products per fp32 product in the split kernel
 METRIC = "completed points/sec/GPU + Chamfer-L1, 2048→16384, B=32, 1/2/4/8 MI355X"
 
 
@@ -110,10 +118,34 @@ def main():
     ops.GEMM_PROFILE = None
     elapsed = D.allreduce_scalar_max(elapsed)
 
+    # the same step on the fp32-input MFMA kernels, outside the timed region (single GPU only; a comparison, not `value`)
+    fp32_mode = None
+    gemm_mode = _lib.get_gemm_mode()
+    if world == 1 and gemm_mode == "split":
+        _lib.set_gemm_mode("fp32")
+        train_step(cfg, model, opt, p, c)
+        torch.cuda.synchronize()
+        prof32 = []
+        ops.GEMM_PROFILE = prof32
+        t1 = time.perf_counter()
+        n32 = max(2, min(5, args.steps))
+        for _ in range(n32):
+            train_step(cfg, model, opt, p, c)
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t1
+        ops.GEMM_PROFILE = None
+        _lib.set_gemm_mode("split")
+        f32 = sum(x[1] for x in prof32)
+        t32 = sum(x[4].elapsed_time(x[5]) for x in prof32) * 1e-3
+        fp32_mode = {"ms_per_step": dt32 / n32 * 1e3, "value": B * Md * n32 / dt32, "steps": n32,
+                     "roofline": {"bound": "mfma", "kernel": "vnp_gemm_kernel<*> (v_mfma_f32_32x32x2_f32)",
+                                  "achieved": round(f32 / t32 / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(f32 / t32 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * Md * args.steps / elapsed
-        # dominant kernel: vnp_gemm_kernel (fp32 MFMA); per-variant algorithmic FLOP / s from the per-launch HIP events
+        # dominant kernel: the GEMM; per-variant algorithmic FLOP / s from the per-launch HIP events
         agg = {}
         for variant, flops, nsplit, shape, e0, e1 in prof:
             a = agg.setdefault(variant, [0.0, 0.0, 0])
@@ -139,30 +171,44 @@ def main():
             import glob
             summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")))[-1]
             tr = json.load(open(summ)).get("traffic", {})
-            num = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items() if "vnp_gemm_kernel" in k)
-            den = sum(v["launches"] for k, v in tr.items() if "vnp_gemm_kernel" in k)
+            kname = "vnp_gemm_split_kernel" if gemm_mode == "split" else "vnp_gemm_kernel"
+            num = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items() if kname in k)
+            den = sum(v["launches"] for k, v in tr.items() if kname in k)
             if den:
                 traffic, traffic_src = num / den, os.path.relpath(summ, ROOT)
         except Exception:
             pass
         alg_bytes = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in prof) / max(nlaunch, 1)
-        roofline = {"bound": "mfma", "kernel": "vnp_gemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        if gemm_mode == "split":
+            kernel = ("vnp_gemm_split_kernel<*> (fp32 operands split exactly into 3 bf16 terms; 6 x v_mfma_f32_32x32x16_bf16 "
+                      "per fp32 product block, fp32 accumulate)")
+            peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        else:
+            kernel, peak = "vnp_gemm_kernel<*> (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
+        roofline = {"bound": "mfma", "kernel": kernel,
+                    "achieved": round(achieved, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                     "launches_per_step": nlaunch // max(args.steps, 1),
                     "flop_per_launch": tot_f / max(nlaunch, 1), "avg_launch_ms": tot_t / max(nlaunch, 1) * 1e3,
                     "gemm_ms_per_step": tot_t / args.steps * 1e3,
+                    "note": ("achieved = algorithmic 2MNK fp32 flops / launch time; in split mode peak = bf16 dense MFMA peak "
+                             f"({PEAK_BF16_MFMA_TFLOPS:.0f}) / {SPLIT_PRODUCTS} products, i.e. executed bf16 rate = "
+                             f"{achieved * SPLIT_PRODUCTS:.0f} TFLOP/s; fp32-input MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
+                            if gemm_mode == "split" else "achieved = algorithmic 2MNK flops / launch time",
                     "by_variant": {k: {"tflops": round(a[0] / a[1] / 1e12, 2), "ms_per_step": round(a[1] / args.steps * 1e3, 3),
                                        "launches_per_step": a[2] // max(args.steps, 1)} for k, a in agg.items() if a[1] > 0}}
         out = {"metric": METRIC, "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"vn_pointnet+vn_foldingnet train step (fwd+2xCD-L1+bwd+allreduce+Adam), B={B}/GPU, "
-                                      f"{N}->{Mc}->{Md} pts, fp32", "global_batch": B * world, "parallelism": f"dp{world}"},
+                                      f"{N}->{Mc}->{Md} pts, fp32 (GEMM mode: {gemm_mode})", "global_batch": B * world,
+                          "parallelism": f"dp{world}"},
                "points_per_s_per_gpu": value / world,
                "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
                "roofline": roofline}
+        if fp32_mode is not None:
+            out["fp32_mfma_mode"] = fp32_mode
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))      # the GPU box gives 16 cores per GPU

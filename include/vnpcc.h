@@ -53,6 +53,10 @@ int vnp_emd_matchcost_bwd(hipStream_t st, int B, int n, int m, const float* grad
  *   op_a = 0: A is [M,K] row-major; 1: A is [K,M] row-major.   op_b = 0: B is [N,K] row-major; 1: B is [K,N].
  *   bias: optional [groups*3, ldbias]; row r gets bias[(r / rows_per_group)*3 + r%3] (per-sample VN bias).
  *   accumulate != 0: C += result.   nsplit > 1: split-K through ws (nsplit*M*N floats), bias not allowed. */
+/* GEMM arithmetic: 0 (default) = every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products with fp32
+ * accumulation (error vs fp64 at or below mode 1's); 1 = fp32-input MFMA.  Process-wide; returns 0 or VNP_EINVAL. */
+int vnp_gemm_set_mode(int mode);
+int vnp_gemm_get_mode(void);
 int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, int ldbias, int rows_per_group,

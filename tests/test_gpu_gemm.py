@@ -1,5 +1,7 @@
-"""fp32-MFMA GEMM (vnp_gemm) against a float64 torch reference.  Tolerance: an fp32 fmaf chain of length K has
-error <= ~K * 6e-8 * sum|a||b|; we assert 2e-5 relative to max|C| for K <= 4096."""
+"""vnp_gemm against a float64 torch reference, in both arithmetic modes: 'split' (default: operands split exactly into
+three bf16 terms, six bf16 MFMA products, fp32 accumulation) and 'fp32' (fp32-input MFMA).  Tolerance: an fp32 fmaf chain
+of length K has error <= ~K * 6e-8 * sum|a||b|; we assert 2e-5 relative to max|C| for K <= 4096 in BOTH modes, and
+test_split_is_fp32_grade pins the split kernel's error to the fp32 kernel's on the same operands."""
 import pytest
 import torch
 
@@ -8,9 +10,13 @@ from conftest import relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _lib(lib_built):
-    pass
+@pytest.fixture(autouse=True, params=["split", "fp32"])
+def _mode(lib_built, request):
+    from vn_pointcloudcompletion_amd import _lib
+    before = _lib.get_gemm_mode()
+    _lib.set_gemm_mode(request.param)
+    yield request.param
+    _lib.set_gemm_mode(before)
 
 
 def _mk(*shape, seed=0):
@@ -91,3 +97,55 @@ def test_bad_arguments_raise():
         ops.gemm(_mk(4, 5), _mk(4, 6))
     with pytest.raises(_lib.VnpError):
         ops.gemm(torch.zeros(4, 5), torch.zeros(4, 5))          # CPU tensors: no fallback
+
+
+def _err_vs_fp64(C, ref, A, B, op_a, op_b):
+    """max |C - ref| / (|A| |B|)  — the error normalised by what a rounding-error bound is proportional to."""
+    Aa, Ba = A.double().abs(), B.double().abs()
+    mag = (Aa.t() if op_a else Aa) @ (Ba if op_b else Ba.t())
+    return ((C.double() - ref).abs() / mag.clamp_min(1e-300)).max().item()
+
+
+_DISTRIBUTIONS = {
+    "uniform": lambda g, *s: torch.rand(*s, generator=g) * 2 - 1,
+    "positive": lambda g, *s: torch.rand(*s, generator=g) + 0.5,                       # sums grow linearly: exposes biased rounding
+    "wide": lambda g, *s: (torch.rand(*s, generator=g) * 2 - 1) * torch.exp2(torch.randint(-20, 21, s, generator=g).float()),
+    "tiny": lambda g, *s: (torch.rand(*s, generator=g) * 2 - 1) * 1e-18,
+    "huge": lambda g, *s: (torch.rand(*s, generator=g) * 2 - 1) * 1e15,
+    "normal_act": lambda g, *s: torch.nn.functional.leaky_relu(torch.randn(*s, generator=g), 0.2),
+}
+
+
+@pytest.mark.parametrize("dist", sorted(_DISTRIBUTIONS))
+@pytest.mark.parametrize("layout,M,N,K", [("nt", 384, 256, 2048), ("nn", 384, 256, 1024), ("tn", 256, 128, 24576),
+                                          ("nt", 200, 100, 333)])
+def test_split_is_fp32_grade(dist, layout, M, N, K):
+    """Error against fp64 of the bf16x3-split kernel vs the fp32-MFMA kernel on identical operands: the split kernel must be
+    within 1.5x of the fp32 kernel's worst error (it is usually below it), for zero-mean, one-signed, wide-range, tiny and huge
+    data, in every operand layout (K-contiguous and transposed staging paths)."""
+    from vn_pointcloudcompletion_amd import ops, _lib
+    g = torch.Generator().manual_seed(sum(map(ord, dist + layout)))
+    f = _DISTRIBUTIONS[dist]
+    op_a, op_b = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[layout]
+    A = f(g, *((K, M) if op_a else (M, K))).cuda()
+    B = f(g, *((K, N) if op_b else (N, K))).cuda()
+    ref = (A.double().t() if op_a else A.double()) @ (B.double() if op_b else B.double().t())
+    errs = {}
+    for mode in ("fp32", "split"):
+        _lib.set_gemm_mode(mode)
+        errs[mode] = _err_vs_fp64(ops.gemm(A, B, op_a=op_a, op_b=op_b), ref, A, B, op_a, op_b)
+    assert errs["fp32"] < 5e-6, errs                     # sanity: the yardstick itself is fp32-accurate
+    assert errs["split"] <= 1.5 * errs["fp32"] + 1e-8, errs
+
+
+def test_split_planes_reconstruct_exactly():
+    """x = h + m + l exactly: with B = identity the split product must return A bit for bit (each output is one non-zero
+    term h*1 + m*1 + l*1 accumulated in fp32), including values whose low planes are 16 binades below the high one."""
+    from vn_pointcloudcompletion_amd import ops, _lib
+    _lib.set_gemm_mode("split")
+    g = torch.Generator().manual_seed(5)
+    A = ((torch.rand(384, 128, generator=g) * 2 - 1) * torch.exp2(torch.randint(-30, 31, (384, 128), generator=g).float())).cuda()
+    eye_n, eye_m = torch.eye(128, device="cuda"), torch.eye(384, device="cuda")
+    assert torch.equal(ops.gemm(A, eye_n), A)                                   # A K-contiguous
+    assert torch.equal(ops.gemm(eye_m, A, op_b=1), A)                           # B row-contiguous (transposed staging)
+    assert torch.equal(ops.gemm(A, eye_m, op_a=1, op_b=1, nsplit=1), A.t())     # A row-contiguous

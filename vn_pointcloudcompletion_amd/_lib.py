@@ -102,7 +102,7 @@ _SIGNATURES = {
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
-_NO_STREAM = {"vnp_chunk_points": []}
+_NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": []}
 
 
 def exported_symbols():
@@ -126,7 +126,24 @@ def lib():
             fn.argtypes = args
             fn.restype = _i
         _LIB = L
+        mode = os.environ.get("VNP_GEMM_MODE", "split").lower()
+        if mode not in ("split", "fp32"):
+            raise VnpError(f"VNP_GEMM_MODE must be 'split' or 'fp32', got {mode!r}")
+        L.vnp_gemm_set_mode(1 if mode == "fp32" else 0)
     return _LIB
+
+
+def set_gemm_mode(mode: str) -> None:
+    """'split' (default): fp32 operands split exactly into three bf16 terms, six bf16 MFMA products, fp32 accumulation;
+    'fp32': fp32-input MFMA.  Same results to fp32 rounding (tests/test_gpu_gemm.py); process-wide."""
+    if mode not in ("split", "fp32"):
+        raise VnpError(f"gemm mode must be 'split' or 'fp32', got {mode!r}")
+    if lib().vnp_gemm_set_mode(1 if mode == "fp32" else 0) != 0:
+        raise VnpError("vnp_gemm_set_mode failed")
+
+
+def get_gemm_mode() -> str:
+    return "fp32" if lib().vnp_gemm_get_mode() == 1 else "split"
 
 
 def chunk_points() -> int:

@@ -1,4 +1,8 @@
-// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains, 157 TF/s peak).
+// fp32 GEMM on the CDNA4 matrix cores.  Two kernels with the same tiling, arguments and results to fp32 rounding:
+//   * gemm_split_kernel.h (default): every operand is split exactly into three bf16 terms on its way into LDS and six
+//     v_mfma_f32_32x32x16_bf16 products are accumulated in fp32 — error vs fp64 at or below the fp32 kernel's
+//     (tests/test_gpu_gemm.py), 1.45-1.75x its speed;
+//   * gemm_kernel.h (vnp_gemm_set_mode(1) / VNP_GEMM_MODE=fp32): v_mfma_f32_32x32x2_f32, 157 TF/s peak.
 //
 // Every Vector-Neuron linear map of the reference (models/vn_layers.py:21,36,65,69,162: x.transpose(1,-1) ->
 // nn.Linear -> transpose back) is, in the rows layout of vnp_common.h, one plain row-major GEMM
@@ -13,7 +17,18 @@
 // (one LDS buffer, two barriers per K-tile; the co-resident block covers the barrier gaps).
 // K order inside an MFMA pair is permuted identically for A and B (lane half h takes k = 8q+4h+s), so a lane's
 // four consecutive K values come from ONE 16-byte LDS read.
-#include "gemm_kernel.h"
+#include "gemm_split_kernel.h"
+
+static int g_vnp_gemm_mode = 0;          // 0 = bf16x3 split (fp32-grade), 1 = fp32 MFMA
+
+extern "C" int vnp_gemm_set_mode(int mode)
+{
+    if (mode != 0 && mode != 1) return VNP_EINVAL;
+    g_vnp_gemm_mode = mode;
+    return 0;
+}
+
+extern "C" int vnp_gemm_get_mode(void) { return g_vnp_gemm_mode; }
 
 static int vnp_num_cus()
 {
@@ -83,12 +98,18 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
                          (bsa % 4 == 0) && (bsb % 4 == 0);
     const bool fast = aligned && (M % bm == 0) && (N % 128 == 0) && (K % BK == 0) && K > 0;
     // resident workgroups per CU: 2 for the 192-row tiles (~240 VGPRs), 3 for the aligned 128-row weight-gradient kernel (151)
-    const long long cap = (long long)vnp_num_cus() * ((bm == 128 && fast && op_b == 1) ? 3 : 2);
+    const bool split = g_vnp_gemm_mode == 0;
+    const long long cap = (long long)vnp_num_cus() * ((!split && bm == 128 && fast && op_b == 1) ? 3 : 2);
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
-#define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                              \
-    do {                                                                                                          \
-        if (fast) hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, true>), grid, block, 0, stream, p);  \
-        else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p); \
+#define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                                    \
+    do {                                                                                                                \
+        if (split) {                                                                                                    \
+            if (fast) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true>), grid, block, 0, stream, p);  \
+            else      hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, false>), grid, block, 0, stream, p); \
+        } else {                                                                                                        \
+            if (fast) hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, true>), grid, block, 0, stream, p);    \
+            else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p);   \
+        }                                                                                                               \
     } while (0)
     if (op_a == 0 && op_b == 0)      VNP_LAUNCH(192, true, true);
     else if (op_a == 0 && op_b == 1) VNP_LAUNCH(192, true, false);

@@ -1,0 +1,300 @@
+// fp32 GEMM on the bf16 matrix pipe by exact operand splitting (shared by gemm.hip and scripts/gemm_bench.hip).
+//
+// Every fp32 value is x = h + m + l exactly, with h, m, l bf16 (8 significant bits each, round-to-nearest at each
+// level: 24 = 3 x 8 bits, and bf16 has fp32's exponent range, so no scaling is needed).  A product of two bf16 values is
+// exact in fp32, so   x*y = hh + (hm + mh) + (hl + lh + mm) + (ml + lm) + ll .  The kernel issues the first SIX terms as
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (smallest first); the dropped terms are bounded by
+// |ml + lm + ll| <= 2^-26 |x*y| — four times below the rounding of ONE fp32 multiply-add — so the result is fp32-grade
+// (tests/test_gpu_gemm.py measures both kernels against fp64).  Six bf16 MFMAs per 32x32x16 block do the work of eight
+// v_mfma_f32_32x32x2_f32 in 6*32 instead of 8*64 cycles: 2.67 x the fp32-MFMA roof.
+//
+// Structure = vnp_gemm_kernel's: persistent 256-thread workgroups (4 waves, 2(M) x 2(N)), 192x128x32 or 128x128x32
+// tiles, global -> registers -> LDS with the next K-tile in flight during the MFMAs.  The split happens once per loaded
+// element on the way into LDS (11 VALU ops per pair of elements); LDS holds the three bf16 planes of both operands as
+// [row][32 k] rows of 64 bytes, 16-byte slots XOR-swizzled so that the ds_read_b128 fragment reads of 16 consecutive
+// rows and the ds_write_b64 of the staging pass are both conflict-free (vnp_split_row_off).
+// Operands that are not K-contiguous in memory (the weight-gradient form A[K,M], B[K,N]) are loaded as 4(k) x 4(m)
+// register blocks and transposed in registers, so LDS always holds K-contiguous rows; their staging pass writes rows
+// 4 apart, so that layout also permutes the rows (row -> (row & 3) * R/4 + row / 4) to keep both sides conflict-free.
+#pragma once
+#include "gemm_kernel.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 vnp_bf8;
+typedef __attribute__((ext_vector_type(4))) unsigned vnp_u4;
+typedef __attribute__((ext_vector_type(2))) unsigned vnp_u2;
+
+__device__ __forceinline__ unsigned vnp_cvt_pk_bf16(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// (x0, x1) -> packed bf16 pairs H, M, L with x = h + m + l exactly (x0 in the low half-word: the lower k)
+__device__ __forceinline__ void vnp_split_pair(float x0, float x1, unsigned& H, unsigned& M, unsigned& L)
+{
+    H = vnp_cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(H << 16);
+    const float r1 = x1 - __uint_as_float(H & 0xffff0000u);
+    M = vnp_cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(M << 16);
+    const float s1 = r1 - __uint_as_float(M & 0xffff0000u);
+    L = vnp_cvt_pk_bf16(s0, s1);
+}
+
+// byte offset of (row, 16-byte slot q) inside one plane of R rows.  A 16-lane group covers all 64 banks when its 16-byte
+// slot numbers 4 * (physical row & 3) + (q ^ g) are distinct:
+//   KC layout: physical row = row, g = (row >> 2) & 3          (readers: 16 consecutive rows; writers: 8 whole rows)
+//   T  layout: physical row = (row & 3) * R/4 + (row >> 2), g = (row & 3) ^ ((row >> 4) & 3)
+//              (readers: 16 consecutive rows; writers: rows 4 m + e for 16 consecutive m)
+template <int R, bool KC>
+__device__ __forceinline__ int vnp_split_row_off(int row, int q)
+{
+    if (KC) return row * 64 + ((q ^ ((row >> 2) & 3)) << 4);
+    return ((row & 3) * (R / 4) + (row >> 2)) * 64 + ((q ^ (row & 3) ^ ((row >> 4) & 3)) << 4);
+}
+
+// thread -> tile element maps.  KC (K-contiguous operand): float4 j of thread tid is row tid/8 + 32 j, k = 4 (tid % 8).
+// !KC (row-contiguous operand, R = 128 rows): float4 j is k = 4 kq + j, rows 4 m4 .. 4 m4 + 3, where a wave covers
+// 16 m4 x 4 kq (256-byte runs in memory; 64 distinct 8-byte LDS units per ds_write_b64).
+__device__ __forceinline__ int vnp_split_m4(int tid) { return (tid & 15) + 16 * ((tid >> 6) & 1); }
+__device__ __forceinline__ int vnp_split_kq(int tid) { return ((tid >> 4) & 3) + 4 * (tid >> 7); }
+
+template <int R, bool KC>
+__device__ __forceinline__ void vnp_split_offsets(int& voff0, int& step, int ld, int tid)
+{
+    static_assert(KC || R == 128, "row-contiguous operands use 128-row tiles");
+    if (KC) { voff0 = (tid >> 3) * ld + (tid & 7) * 4; step = 32 * ld; }
+    else    { voff0 = vnp_split_kq(tid) * 4 * ld + vnp_split_m4(tid) * 4; step = ld; }
+}
+
+template <int R, bool KC, int NV>
+__device__ __forceinline__ void vnp_split_load_generic(vnp_f4 (&reg)[NV], const float* __restrict__ G, int ld,
+                                                       int r0, int rmax, int k0, int kmax, bool vec_ok, int tid)
+{
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        int r, k;
+        if (KC) { r = (tid >> 3) + 32 * j; k = (tid & 7) * 4; }
+        else    { k = vnp_split_kq(tid) * 4 + j;  r = vnp_split_m4(tid) * 4; }
+        const int gr = r0 + r, gk = k0 + k;
+        vnp_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < rmax && gk < kmax) {
+            if (KC) {
+                const float* src = G + (size_t)gr * ld + gk;
+                if (vec_ok && gk + 3 < kmax) v = *(const vnp_f4*)src;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gk + e < kmax) v[e] = src[e];
+                }
+            } else {
+                const float* src = G + (size_t)gk * ld + gr;
+                if (vec_ok && gr + 3 < rmax) v = *(const vnp_f4*)src;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gr + e < rmax) v[e] = src[e];
+                }
+            }
+        }
+        reg[j] = v;
+    }
+}
+
+// registers -> three bf16 planes in LDS.  plane stride = R * 64 bytes.
+template <int R, bool KC, int NV>
+__device__ __forceinline__ void vnp_split_stage(const vnp_f4 (&reg)[NV], char* S, int tid)
+{
+    if (KC) {
+        const int r = tid >> 3, kc = tid & 7;
+        const int base = vnp_split_row_off<R, true>(r, kc >> 1) + (kc & 1) * 8;      // rows r + 32 j share the swizzle
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            vnp_split_pair(reg[j][0], reg[j][1], h0, m0, l0);
+            vnp_split_pair(reg[j][2], reg[j][3], h1, m1, l1);
+            char* d = S + base + j * 32 * 64;
+            *(vnp_u2*)(d)              = vnp_u2{h0, h1};
+            *(vnp_u2*)(d + R * 64)     = vnp_u2{m0, m1};
+            *(vnp_u2*)(d + 2 * R * 64) = vnp_u2{l0, l1};
+        }
+    } else {
+        static_assert(KC || NV == 4, "row-contiguous operands: 4 k-rows x 4 rows per thread");
+        const int kq = vnp_split_kq(tid), r4 = vnp_split_m4(tid) * 4;       // k = 4 kq .. 4 kq + 3 -> slot kq >> 1, half kq & 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            vnp_split_pair(reg[0][e], reg[1][e], h0, m0, l0);
+            vnp_split_pair(reg[2][e], reg[3][e], h1, m1, l1);
+            char* d = S + vnp_split_row_off<R, false>(r4 + e, kq >> 1) + (kq & 1) * 8;
+            *(vnp_u2*)(d)              = vnp_u2{h0, h1};
+            *(vnp_u2*)(d + R * 64)     = vnp_u2{m0, m1};
+            *(vnp_u2*)(d + 2 * R * 64) = vnp_u2{l0, l1};
+        }
+    }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int EXP = 0>
+__global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArgs p)
+{
+    constexpr int BK = 32;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AV = BM * BK / 4 / 256, BV = BN * BK / 4 / 256;
+    constexpr int APL = BM * 64, BPL = BN * 64;                 // bytes per plane
+    __shared__ __attribute__((aligned(16))) char smem[3 * APL + 3 * BPL];
+    char* As = smem;
+    char* Bs = smem + 3 * APL;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int nwg = nbm * nbn;
+    const int total = nwg * p.nsplit * p.nbatch;
+    const int nk = (p.K + BK - 1) / BK;
+
+    const bool va = FAST || (((p.lda & 3) == 0) && ((((uintptr_t)p.A) & 15) == 0) && ((p.bsa & 3) == 0));
+    const bool vb = FAST || (((p.ldb & 3) == 0) && ((((uintptr_t)p.B) & 15) == 0) && ((p.bsb & 3) == 0));
+    int oa, sa, ob, sb;
+    vnp_split_offsets<BM, AKC>(oa, sa, p.lda, tid);
+    vnp_split_offsets<BN, BKC>(ob, sb, p.ldb, tid);
+
+    int m0, n0, kt0, kt1, split, batch;
+    auto set_item = [&](int w) {                            // same XCD-aware walk as vnp_gemm_kernel
+        const int sbi = w / nwg, t = w - sbi * nwg;
+        const int q = nwg >> 3, r = nwg & 7, x = t & 7;
+        const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+        m0 = (wg / nbn) * BM; n0 = (wg % nbn) * BN;
+        split = sbi % p.nsplit; batch = sbi / p.nsplit;
+        kt0 = split * p.tiles_per_split;
+        kt1 = min(nk, kt0 + p.tiles_per_split);
+    };
+
+    vnp_f4 ra[AV], rb[BV];
+    auto fetch = [&](int fm0, int fn0, int fbatch, int kt) {
+        const float* pA = p.A + (size_t)fbatch * p.bsa;
+        const float* pB = p.B + (size_t)fbatch * p.bsb;
+        const int k0 = kt * BK;
+        const bool full = FAST || (k0 + BK <= p.K);
+        if (FAST || (va && full && fm0 + BM <= p.M))
+            vnp_load_tile_fast<AV>(ra, AKC ? pA + (size_t)fm0 * p.lda + k0 : pA + fm0 + (size_t)k0 * p.lda, oa, sa);
+        else vnp_split_load_generic<BM, AKC, AV>(ra, pA, p.lda, fm0, p.M, k0, p.K, va, tid);
+        if (FAST || (vb && full && fn0 + BN <= p.N))
+            vnp_load_tile_fast<BV>(rb, BKC ? pB + (size_t)fn0 * p.ldb + k0 : pB + fn0 + (size_t)k0 * p.ldb, ob, sb);
+        else vnp_split_load_generic<BN, BKC, BV>(rb, pB, p.ldb, fn0, p.N, k0, p.K, vb, tid);
+    };
+    auto stage = [&]() {
+        vnp_split_stage<BM, AKC, AV>(ra, As, tid);
+        vnp_split_stage<BN, BKC, BV>(rb, Bs, tid);
+    };
+
+    // fragment read offsets: lane (li, lh) reads row base + li, slot 2 s + lh of K16-step s.  The slot enters the address
+    // as (slot ^ g) << 4, so K16-step 1 is step 0's address ^ 32.
+    int a_rd[TM], b_rd[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_rd[i] = vnp_split_row_off<BM, AKC>(wm * (BM / 2) + i * 32 + li, lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_rd[j] = vnp_split_row_off<BN, BKC>(wn * (BN / 2) + j * 32 + li, lh);
+
+    int w = blockIdx.x;
+    if (w >= total) return;
+    set_item(w);
+    fetch(m0, n0, batch, kt0);
+    stage();
+    __syncthreads();
+
+    while (true) {
+        vnp_f16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        const int wnext = w + gridDim.x;
+        const bool more = wnext < total;
+
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (EXP == 1) { asm volatile("" ::: "memory"); }
+            else if (kt + 1 < kt1) fetch(m0, n0, batch, kt + 1);
+            else if (more) {
+                const int cm0 = m0, cn0 = n0, ck0 = kt0, ck1 = kt1, cs = split, cb = batch;
+                set_item(wnext);
+                fetch(m0, n0, batch, kt0);
+                m0 = cm0; n0 = cn0; kt0 = ck0; kt1 = ck1; split = cs; batch = cb;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                vnp_bf8 a[TM][3], b[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        a[i][pl] = __builtin_bit_cast(vnp_bf8, *(const vnp_u4*)(As + pl * APL + (a_rd[i] ^ (s << 5))));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        b[j][pl] = __builtin_bit_cast(vnp_bf8, *(const vnp_u4*)(Bs + pl * BPL + (b_rd[j] ^ (s << 5))));
+                // six products, smallest first: l*h, h*l, m*m, m*h, h*m, h*h   (planes: 0 = h, 1 = m, 2 = l)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (kt + 1 < kt1) {
+                stage();
+                __syncthreads();
+            }
+        }
+
+        // epilogue (identical to vnp_gemm_kernel's): C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        {
+            float* Cz = p.C + (size_t)split * p.slab + (size_t)batch * p.bsc;
+            const bool full = FAST || ((m0 + BM <= p.M) && (n0 + BN <= p.N));
+            int g0 = 0, r0 = 0;
+            const bool bias_fast = p.bias && p.rows_per_group >= BM;
+            if (p.bias) { g0 = m0 / p.rows_per_group; r0 = m0 - g0 * p.rows_per_group; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int lr = wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int row = m0 + lr;
+                    if (!full && row >= p.M) continue;
+                    const float* brow = nullptr;
+                    if (p.bias) {
+                        int grp;
+                        if (bias_fast) grp = g0 + ((r0 + lr) >= p.rows_per_group ? 1 : 0);
+                        else grp = row / p.rows_per_group;
+                        brow = p.bias + (size_t)(grp * 3 + row % 3) * p.ldbias;
+                    }
+                    float* drow = Cz + (size_t)row * p.ldc;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = n0 + wn * (BN / 2) + j * 32 + li;
+                        if (!full && col >= p.N) continue;
+                        float v = acc[i][j][e];
+                        if (brow) v += brow[col];
+                        if (p.accumulate) v += drow[col];
+                        drow[col] = v;
+                    }
+                }
+            }
+        }
+
+        if (!more) break;
+        w = wnext;
+        set_item(w);
+        stage();
+        __syncthreads();
+    }
+}
