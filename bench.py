@@ -180,7 +180,7 @@ def main():
             pass
         alg_bytes = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in prof) / max(nlaunch, 1)
         if gemm_mode == "split":
-            kernel = ("vnp_gemm_split_kernel<*> (fp32 operands split exactly into 3 bf16 terms; 6 x v_mfma_f32_32x32x16_bf16 "
+            kernel = ("vnp_gemm_split_kernel<*> (fp32 operands split exactly into 3 bf16 terms; 6 x v_mfma_f32_16x16x32_bf16 "
                       "per fp32 product block, fp32 accumulate)")
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         else:

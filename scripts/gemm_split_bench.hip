@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -42,6 +43,21 @@ void run_case(const char* name, int M, int N, int K, int nsplit, const float* A,
         printf("  r%d fp32 mfma    %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
         t = time_it([&] { hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true>), grid, block, 0, 0, p2); }, 5);
         printf("  r%d bf16x3 split %8.3f ms %7.1f TF-equiv\n", round, t, fl / t * 1e-9);
+    }
+    {   // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): d(s_memtime) / d(s_memrealtime) x 100 MHz
+        unsigned long long* dbg;
+        CK(hipMalloc(&dbg, 1024 * 16));
+        VnpGemmArgs p3 = p2; p3.bias = (const float*)dbg;
+        for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true, 8>), grid, block, 0, 0, p3);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(2 * grid.x);
+        CK(hipMemcpy(h.data(), dbg, grid.x * 16, hipMemcpyDeviceToHost));
+        std::vector<double> mhz;
+        for (unsigned i = 0; i < grid.x; ++i) if (h[2 * i + 1]) mhz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+        std::sort(mhz.begin(), mhz.end());
+        if (!mhz.empty()) printf("  in-kernel clock after 200 launches: median %.0f MHz (min %.0f, max %.0f), block life %.3f ms\n",
+                                 mhz[mhz.size() / 2], mhz.front(), mhz.back(), h[1] / 100e3);
+        CK(hipFree(dbg));
     }
     const int NS = 1000;
     double e1 = 0, e2 = 0, ref2 = 0, m1 = 0, m2 = 0;
