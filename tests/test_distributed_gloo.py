@@ -44,6 +44,39 @@ def _worker(rank, world, port, q):
     expect = sum(gathered) / world
     ok = torch.allclose(fb.flat_grad, expect, atol=1e-6) and fb.view(fb.flat_grad, 1).abs().sum().item() == 0.0
     mx = D.allreduce_scalar_max(float(rank + 1))
+
+    # bucketed, backward-overlapped averaging: several buckets (tiny bucket size), one never-used parameter, three steps
+    # (step 1 learns which parameters receive gradients; later steps launch buckets from inside backward)
+    class Holder2:
+        flat_buffers = [fb]
+        grad_reducers = [D.OverlappedGradReducer(fb, bucket_bytes=8)]
+    red = Holder2.grad_reducers[0]
+    ok = ok and len(red.buckets) == 3 and red.buckets[0][3] == fb.numel and red.buckets[-1][2] == 0
+    for step in range(3):
+        fb.zero_grad()
+        torch.manual_seed(20 + step)
+        xs = torch.randn(8, 6)[lo:hi]
+        model[2](model[0](xs)).pow(2).sum().backward()
+        launched_in_backward = red.launched
+        local = fb.flat_grad.clone() if step == 0 else None      # later steps: slices are being reduced already
+        # expected value from an independent computation of both ranks' local gradients
+        exp = torch.zeros_like(fb.flat_grad)
+        for rr in range(world):
+            m2 = torch.nn.Sequential(torch.nn.Linear(6, 4, bias=False), torch.nn.Linear(4, 4, bias=False), torch.nn.Linear(4, 1, bias=False))
+            m2.load_state_dict(model.state_dict())
+            torch.manual_seed(20 + step)
+            m2[2](m2[0](torch.randn(8, 6)[rr * 4:rr * 4 + 4])).pow(2).sum().backward()
+            off = 0
+            for prm, o in zip(m2.parameters(), fb.offsets):
+                if prm.grad is not None:
+                    exp[o:o + prm.numel()] += prm.grad.reshape(-1) / world
+        D.allreduce_gradients(Holder2)
+        ok = ok and torch.allclose(fb.flat_grad, exp, atol=1e-6) and fb.view(fb.flat_grad, 1).abs().sum().item() == 0.0
+        if step == 0:
+            ok = ok and launched_in_backward == 0 and red.live is not None and len(red.live) == 2
+        else:
+            ok = ok and launched_in_backward >= 1                   # model[2]'s bucket left during backward
+    red.remove()
     q.put((rank, ok, w0.sum().item(), mx))
     D.barrier()
     dist.destroy_process_group()

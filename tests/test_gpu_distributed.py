@@ -1,0 +1,138 @@
+"""Two ranks on ONE MI355X (RCCL refuses two ranks on one device): the real model, FusedAdam and the backward-overlapped
+bucketed gradient averaging (distributed.OverlappedGradReducer: hooks on the autograd device thread, bucket order, never-
+used parameters) against a single-process run that computes each shard's gradients separately and averages them by hand.
+The transport is injected: each bucket is staged through the host and averaged with a CPU gloo all-reduce (this build's
+gloo hangs on repeated device-tensor collectives, and RCCL itself cannot be exercised on a one-GPU box).  Everything else
+is exactly what `bench.py --gpus N` runs."""
+import os
+import socket
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cfg():
+    return SimpleNamespace(num_coarse=64, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cuda:0",
+                           coarse_loss="cd", dcd_opts={"alpha": 200, "lambda": 0.5})
+
+
+def _data():
+    g = torch.Generator().manual_seed(5)
+    return (torch.rand(4, 128, 3, generator=g) - 0.5), (torch.rand(4, 1024, 3, generator=g) - 0.5)
+
+
+def _model(cfg):
+    from vn_pointcloudcompletion_amd.model import PCNNet
+    torch.manual_seed(3)
+    m = PCNNet(cfg, "vn_pointnet", "vn_foldingnet")
+    m.decoder.num_dense = cfg.num_coarse * 16
+    m.train()
+    return m
+
+
+def _worker(rank, world, port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)                  # a stuck rank reports where and dies instead of hanging the box
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        from vn_pointcloudcompletion_amd import distributed as D
+        from vn_pointcloudcompletion_amd.optim import FusedAdam
+        from vn_pointcloudcompletion_amd.train import train_step
+        torch.cuda.set_device(0)
+        D.init_from_env(backend="gloo")
+        cfg = _cfg()
+        model = _model(cfg)
+        # same seed -> identical replicas (no device-tensor broadcast over gloo)
+
+        def host_staged_average(flat):
+            h = flat.detach().cpu()
+            dist.all_reduce(h)
+            flat.copy_((h / world).to(flat.device))
+            return None
+        opt = FusedAdam(model.parameters(), lr=0.0)      # lr 0: every step sees the same weights -> the same gradients
+        red = opt.enable_overlapped_allreduce(bucket_bytes=16 << 20, transport=host_staged_average)[0]
+        p, c = _data()
+        lo, hi = D.shard_batch(4)
+        p, c = p[lo:hi].cuda(), c[lo:hi].cuda()
+        launched, grads = [], []
+        for _ in range(3):
+            opt.zero_grad()
+            from vn_pointcloudcompletion_amd.train import compute_losses
+            coarse, fine = model(p)
+            loss, _, _ = compute_losses(cfg, coarse, fine, c)
+            loss.backward()
+            launched.append(red.launched)
+            D.allreduce_gradients(opt)
+            grads.append(opt.flat_buffers[0].flat_grad.cpu().clone())
+            opt.step()
+        torch.cuda.synchronize()
+        q.put((rank, "ok", grads, launched, len(red.buckets)))
+        D.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                            # report instead of hanging the parent
+        import traceback
+        q.put((rank, "error", f"{type(e).__name__}: {e}\n{traceback.format_exc()}", None, None))
+
+
+def test_two_ranks_overlapped_allreduce_matches_manual_average(lib_built):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < world and time.time() - t0 < 90:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            if not any(pr.is_alive() for pr in procs) and q.empty():
+                break
+    for pr in procs:
+        pr.join(10)
+        if pr.is_alive():
+            pr.terminate()
+    assert len(out) == world, f"only {len(out)} of {world} ranks reported (exit codes {[pr.exitcode for pr in procs]})"
+    out.sort(key=lambda o: o[0])
+    errs = [o for o in out if o[1] != "ok"]
+    if errs and "gloo" in errs[0][2].lower() and "cuda" in errs[0][2].lower():
+        pytest.skip("this gloo build has no device-tensor support: " + errs[0][2].splitlines()[0])
+    assert not errs, errs[0][2]
+    assert all(pr.exitcode == 0 for pr in procs)
+    for g0, g1 in zip(out[0][2], out[1][2]):
+        assert torch.equal(g0, g1)                                    # both replicas hold the same averaged gradient
+    assert out[0][4] >= 3                                             # several buckets at this bucket size
+    assert out[0][3][0] == 0 and all(n >= 1 for n in out[0][3][1:])   # from step 2 on, buckets leave during backward
+
+    # single-process reference: per-shard gradients (per-replica BatchNorm statistics), averaged by hand
+    from vn_pointcloudcompletion_amd.optim import FusedAdam
+    from vn_pointcloudcompletion_amd.train import compute_losses
+    cfg = _cfg()
+    model = _model(cfg)
+    opt = FusedAdam(model.parameters(), lr=0.0)
+    fb = opt.flat_buffers[0]
+    p, c = _data()
+    acc = torch.zeros_like(fb.flat_grad)
+    for r in range(world):
+        opt.zero_grad()
+        coarse, fine = model(p[2 * r:2 * r + 2].cuda())
+        loss, _, _ = compute_losses(cfg, coarse, fine, c[2 * r:2 * r + 2].cuda())
+        loss.backward()
+        acc += fb.flat_grad / world
+    ref = acc.cpu()
+    scale = ref.abs().max().item()
+    for g in out[0][2]:
+        assert (g - ref).abs().max().item() < 1e-5 * scale, ((g - ref).abs().max().item(), scale)

@@ -3,10 +3,13 @@
 
   * every rank holds a full replica and processes its own shard of the batch (samples are independent; train-mode
     BatchNorm statistics stay per replica, i.e. the single-GPU semantics at the per-GPU batch size);
-  * once per step the flat gradient buffer of ``FusedAdam`` (optim.py) is averaged with ONE all-reduce
-    (22.5 M fp32 = 90 MB for vn_pointnet+vn_foldingnet).  Parameters that never get a gradient
-    (``maxpool*.map_to_dir``) live in the same buffer as zeros, so every rank reduces the same static layout and
-    nothing like DDP's ``find_unused_parameters`` is needed;
+  * once per step the flat gradient buffer of ``FusedAdam`` (optim.py) is averaged (22.5 M fp32 = 90 MB for
+    vn_pointnet+vn_foldingnet): either with ONE all-reduce after backward, or — ``OverlappedGradReducer`` — as a few large
+    contiguous buckets of that buffer, each all-reduced asynchronously as soon as backward has produced its last
+    gradient, so that the exchange of the decoder / coarse-head gradients (60 % of the bytes) runs over xGMI while the
+    encoder's backward GEMMs are still computing.  xGMI rings are per-link bound, so buckets are few and large
+    (default 32 MB).  Parameters that never get a gradient (``maxpool*.map_to_dir``) live in the same buffer as zeros, so
+    every rank reduces the same static layout and nothing like DDP's ``find_unused_parameters`` is needed;
   * rank 0's initial weights are broadcast so replicas start identical.
 """
 from __future__ import annotations
@@ -85,9 +88,125 @@ def allreduce_mean_(flat: torch.Tensor):
     return flat
 
 
+class OverlappedGradReducer:
+    """Bucketed, backward-overlapped averaging of one FlatBuffers gradient buffer.
+
+    Buckets are contiguous element ranges of the flat buffer, cut from its END (parameters are registered in forward
+    order, so backward completes them roughly from the end) at >= ``bucket_bytes`` each.  Every parameter carries a
+    post-accumulate-grad hook; when the last live parameter of a bucket has its gradient, and every later bucket has
+    already been launched (collectives are issued in the same fixed order on every rank), the bucket's slice is
+    all-reduced with ``async_op=True``: RCCL's stream waits for the compute queued so far, later compute does not wait
+    for RCCL.  ``finish()`` launches whatever is left (first step; buckets holding never-used parameters) and waits.
+    Parameters whose hook did not fire in the first backward are treated as never receiving a gradient from then on (the
+    set is static for this model family); if one of them later does fire after its bucket was sent, ``finish`` raises.
+    """
+
+    def __init__(self, fb, bucket_bytes=32 << 20, transport=None):
+        """``transport(flat_slice) -> work-or-None`` replaces the default asynchronous all-reduce (tests: a host-staged
+        collective); it must leave the AVERAGE in ``flat_slice`` once the returned work (if any) has been waited for."""
+        self.fb = fb
+        self.transport = transport
+        n = len(fb.params)
+        ends = list(fb.offsets[1:]) + [fb.numel]
+        self.buckets = []                      # (first param index, last+1, element lo, element hi), launch order
+        hi_i = n
+        while hi_i > 0:
+            lo_i = hi_i - 1
+            while lo_i > 0 and (ends[hi_i - 1] - fb.offsets[lo_i]) * 4 < bucket_bytes:
+                lo_i -= 1
+            self.buckets.append((lo_i, hi_i, fb.offsets[lo_i], ends[hi_i - 1]))
+            hi_i = lo_i
+        self.bucket_of = {}
+        for b, (lo_i, hi_i, _, _) in enumerate(self.buckets):
+            for i in range(lo_i, hi_i):
+                self.bucket_of[id(fb.params[i])] = b
+        self.live = None                        # set of id(param) that fired in the first backward
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in fb.params]
+        self._begin()
+
+    def _begin(self):
+        self.fired = set()
+        self.launched = 0                       # buckets [0, launched) are in flight
+        self.works = []
+        self.late = False
+        if self.live is None:
+            self.pending = None
+        else:
+            self.pending = [sum(1 for i in range(lo_i, hi_i) if id(self.fb.params[i]) in self.live)
+                            for lo_i, hi_i, _, _ in self.buckets]
+
+    def _launch_ready(self):
+        while self.launched < len(self.buckets) and self.pending is not None and self.pending[self.launched] == 0:
+            self._launch(self.launched)
+
+    def _launch(self, b):
+        _, _, lo, hi = self.buckets[b]
+        flat = self.fb.flat_grad[lo:hi]
+        if self.transport is not None:
+            self.works.append((self.transport(flat), None))
+        elif dist.get_backend() == "nccl":
+            self.works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None))
+        else:
+            self.works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
+        self.launched = b + 1
+
+    def _hook(self, p):
+        if world_size() == 1:
+            return
+        b = self.bucket_of[id(p)]
+        if id(p) in self.fired:
+            return                                           # a second accumulation into the same parameter
+        self.fired.add(id(p))
+        if p.grad is not None and p.grad.data_ptr() != self.fb.flat_grad.data_ptr() + self.fb.offsets[self._index(p)] * 4:
+            self.fb.view(self.fb.flat_grad, self._index(p)).copy_(p.grad)        # autograd replaced the view: re-home it
+            p.grad = self.fb.view(self.fb.flat_grad, self._index(p))
+        if b < self.launched:
+            self.late = True                                 # its bucket is already on the wire
+            return
+        if self.pending is not None and id(p) in self.live:
+            self.pending[b] -= 1
+            self._launch_ready()
+
+    def _index(self, p):
+        if not hasattr(self, "_idx"):
+            self._idx = {id(q): i for i, q in enumerate(self.fb.params)}
+        return self._idx[id(p)]
+
+    def finish(self):
+        """Call after backward: send the remaining buckets, wait for all of them, re-arm for the next step."""
+        if world_size() > 1:
+            if self.late:
+                self._begin()
+                raise RuntimeError("a parameter received its gradient after its bucket had been all-reduced: the set of "
+                                   "parameters that receive gradients changed; build a new OverlappedGradReducer")
+            self.fb.check_views()
+            while self.launched < len(self.buckets):
+                self._launch(self.launched)
+            w = world_size()
+            for work, flat in self.works:
+                if work is not None:
+                    work.wait()
+                if flat is not None:
+                    flat.mul_(1.0 / w)
+            if self.live is None:
+                self.live = set(self.fired)
+        self._begin()
+
+    def remove(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
 def allreduce_gradients(optimizer_or_params):
-    """Average gradients across ranks: one collective per flat buffer when given a FusedAdam, else per parameter
-    (skipping ``grad is None`` consistently — the set is static for this model family)."""
+    """Average gradients across ranks: the optimizer's OverlappedGradReducer when it has one (already running since
+    backward), else one collective per flat buffer when given a FusedAdam, else per parameter (skipping ``grad is None``
+    consistently — the set is static for this model family)."""
+    reducers = getattr(optimizer_or_params, "grad_reducers", None)
+    if reducers:
+        for r in reducers:
+            r.finish()
+        return
     if world_size() == 1:
         return
     flats = getattr(optimizer_or_params, "flat_buffers", None)

@@ -80,6 +80,14 @@ class FusedAdam(torch.optim.Optimizer):
     def flat_buffers(self):
         return self._flat
 
+    def enable_overlapped_allreduce(self, bucket_bytes=32 << 20, transport=None):
+        """Data parallel: average gradients in large buckets while backward is still running (distributed.py)."""
+        from .distributed import OverlappedGradReducer
+        for r in getattr(self, "grad_reducers", []):
+            r.remove()
+        self.grad_reducers = [OverlappedGradReducer(fb, bucket_bytes, transport) for fb in self._flat]
+        return self.grad_reducers
+
     def zero_grad(self, set_to_none: bool = True):
         for fb in self._flat:
             fb.zero_grad()
