@@ -1,0 +1,18 @@
+#!/bin/bash
+# dev: default bench, then the same under rocprofv3 kernel trace; args: <tag>
+set -e
+tag=${1:-x}
+export TMPDIR=/tmp
+timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/b_$tag.log 2> gpurun_out/b_$tag.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline --steps 5 > gpurun_out/bp_$tag.log 2>&1
+python3 - <<PY
+import json, glob, csv
+d = json.loads(open("gpurun_out/b_$tag.log").read().strip().splitlines()[-1])
+print("ms/step", round(d["ms_per_step"], 3), "points/s", round(d["value"]), "gemm ms", round(d["roofline"]["gemm_ms_per_step"], 2),
+      "fp32 mode ms", round(d.get("fp32_mfma_mode", {}).get("ms_per_step", 0), 2))
+f = glob.glob("gpurun_out/prof_$tag/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+steps = 5 + 3 + 6   # timed + warmup + fp32-mode steps (1 warm + 5)
+for r in rows[:22]:
+    print("%-70s calls %5s  total %8.3f ms  avg %8.1f us  %5s%%" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+PY

@@ -116,3 +116,96 @@ def test_dcd_and_fscore_match_oracle(lib_built):
     assert (f.cpu() - fo).abs().max().item() < 1e-6
     assert abs(metric.f_score(x[0].numpy(), gt[0].numpy(), th=0.1) - 2 * ((d2[0] < 0.01).float().mean() * (d1[0] < 0.01).float().mean()
                / ((d2[0] < 0.01).float().mean() + (d1[0] < 0.01).float().mean())).item()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------- pruned search (dense clouds)
+def _both_paths(a, b):
+    """(brute-force kernel outputs, pruned kernel outputs) through the C ABI, same inputs."""
+    from vn_pointcloudcompletion_amd import _lib
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    B, n, _ = a.shape
+    m = b.shape[1]
+    outs = []
+    for pruned in (False, True):
+        d1 = torch.empty(B, n, device="cuda"); d2 = torch.empty(B, m, device="cuda")
+        i1 = torch.empty(B, n, device="cuda", dtype=torch.int32); i2 = torch.empty(B, m, device="cuda", dtype=torch.int32)
+        if pruned:
+            nb = _lib.lib().vnp_chamfer_pruned_ws_bytes(B, n, m)
+            assert nb > 0
+            ws = torch.empty((nb + 7) // 8, device="cuda", dtype=torch.int64)
+            call("vnp_chamfer_fwd_pruned", B, n, ptr(a), m, ptr(b), ptr(d1), ptr(i1), ptr(d2), ptr(i2), ptr(ws))
+        else:
+            ws = torch.empty(B * max(n, m), device="cuda", dtype=torch.int64)
+            call("vnp_chamfer_fwd", B, n, ptr(a), m, ptr(b), ptr(d1), ptr(i1), ptr(d2), ptr(i2), ptr(ws))
+        outs.append((d1, d2, i1, i2))
+    return outs
+
+
+def _assert_same_bits(x, y):
+    for u, v in zip(x, y):
+        if u.dtype == torch.float32:
+            assert torch.equal(u.view(torch.int32), v.view(torch.int32))         # bit pattern, so NaN == NaN too
+        else:
+            assert torch.equal(u, v)
+
+
+def _surface(g, B, n):
+    """points on a bumpy sphere: what completed shapes look like (empty interior, thin shell)."""
+    v = torch.randn(B, n, 3, generator=g)
+    v = v / v.norm(dim=-1, keepdim=True)
+    return v * (0.4 + 0.05 * torch.sin(9 * v[..., :1]))
+
+
+_CLOUDS = {
+    "uniform": lambda g, B, n: torch.rand(B, n, 3, generator=g) - 0.5,
+    "surface": _surface,
+    "blob": lambda g, B, n: 0.01 * torch.randn(B, n, 3, generator=g) + 0.3,                 # compact, far from the other cloud
+    "lattice": lambda g, B, n: torch.randint(0, 12, (B, n, 3), generator=g).float() * 0.125,  # many exactly equal distances
+    "line": lambda g, B, n: torch.cat([torch.rand(B, n, 1, generator=g), torch.zeros(B, n, 2)], -1),   # degenerate extent
+    "huge": lambda g, B, n: (torch.rand(B, n, 3, generator=g) - 0.5) * 1e18,
+}
+
+
+@pytest.mark.parametrize("qa,qb", [("uniform", "uniform"), ("surface", "surface"), ("blob", "uniform"), ("uniform", "blob"),
+                                   ("lattice", "lattice"), ("line", "surface"), ("huge", "huge"), ("blob", "blob")])
+@pytest.mark.parametrize("B,n,m", [(2, 4096, 4096), (1, 16384, 14336), (3, 5000, 4097)])
+def test_pruned_equals_brute_force_bits(lib_built, qa, qb, B, n, m):
+    g = torch.Generator().manual_seed(n + m + len(qa) * 7 + len(qb))
+    a, b = _CLOUDS[qa](g, B, n).cuda().contiguous(), _CLOUDS[qb](g, B, m).cuda().contiguous()
+    brute, pruned = _both_paths(a, b)
+    _assert_same_bits(brute, pruned)
+
+
+def test_pruned_ties_duplicates_and_oracle(lib_built):
+    """Every point present 4 times (up-sampling by repetition) and queries that coincide with references: the lowest
+    original index must win although chunks are visited out of index order; also checked against the C oracle."""
+    from oracle import chamfer_oracle as CO
+    g = torch.Generator().manual_seed(11)
+    base = torch.rand(2, 1100, 3, generator=g) - 0.5
+    b = base.repeat(1, 4, 1)[:, torch.randperm(4400, generator=g)]                # 4400 refs, duplicates scattered
+    a = torch.cat([base[:, :600], base.repeat(1, 4, 1)[:, :3600] + 1e-4], 1)       # 4200 queries, 600 exactly on a reference
+    brute, pruned = _both_paths(a.cuda().contiguous(), b.cuda().contiguous())
+    _assert_same_bits(brute, pruned)
+    o1, o2, j1, j2 = CO.chamfer_forward(a.numpy(), b.contiguous().numpy())
+    assert np.array_equal(pruned[0].cpu().numpy(), o1) and np.array_equal(pruned[1].cpu().numpy(), o2)
+    assert np.array_equal(pruned[2].cpu().numpy(), j1) and np.array_equal(pruned[3].cpu().numpy(), j2)
+
+
+def test_pruned_non_finite_inputs_match_brute_force(lib_built):
+    g = torch.Generator().manual_seed(12)
+    a = torch.rand(1, 4096, 3, generator=g) - 0.5
+    b = torch.rand(1, 4096, 3, generator=g) - 0.5
+    a[0, 17, 1] = float("nan"); a[0, 900, 0] = float("inf"); b[0, 5, 2] = float("nan"); b[0, 4000, 0] = -float("inf")
+    brute, pruned = _both_paths(a.cuda(), b.cuda())
+    _assert_same_bits(brute, pruned)
+
+
+def test_pruned_is_the_path_dense_clouds_take(lib_built):
+    """ops.ChamferFn routes clouds of >= 4096 points through the pruned kernels (and says how to opt out)."""
+    from vn_pointcloudcompletion_amd import ops
+    assert ops.CHAMFER_PRUNED_MIN_POINTS == 4096
+    g = torch.Generator().manual_seed(13)
+    a, b = (torch.rand(2, 4096, 3, generator=g) - 0.5).cuda(), (torch.rand(2, 8192, 3, generator=g) - 0.5).cuda()
+    d1, d2, i1, i2 = _fwd(a.clone().requires_grad_(True), b)
+    brute, _ = _both_paths(a, b)
+    _assert_same_bits(brute, (d1.detach(), d2.detach(), i1, i2))

@@ -61,6 +61,7 @@ _vp, _i, _ll, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_fl
 _SIGNATURES = {
     "vnp_chamfer_fwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_chamfer_bwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "vnp_chamfer_fwd_pruned": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "vnp_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vnp_emd_matchcost_bwd": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -102,7 +103,8 @@ _SIGNATURES = {
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
-_NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": []}
+_NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i]}
+_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll}
 
 
 def exported_symbols():
@@ -124,7 +126,7 @@ def lib():
         for name, args in _NO_STREAM.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = _i
+            fn.restype = _RESTYPE.get(name, _i)
         _LIB = L
         mode = os.environ.get("VNP_GEMM_MODE", "split").lower()
         if mode not in ("split", "fp32"):

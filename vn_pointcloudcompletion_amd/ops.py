@@ -7,6 +7,8 @@ is done by the HIP kernels.  No function in this file has a CPU / PyTorch fallba
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -652,6 +654,11 @@ class LinOutFn(Function):
         return gx, gw, gcoarse, None
 
 
+# both clouds at least this large -> vnp_chamfer_fwd_pruned (below it the brute-force kernel's slicing fills the chip better);
+# VNP_CHAMFER_BRUTE=1 forces the brute-force kernel everywhere
+CHAMFER_PRUNED_MIN_POINTS = (1 << 30) if os.environ.get("VNP_CHAMFER_BRUTE") == "1" else 4096
+
+
 class ChamferFn(Function):
     """chamfer_3DFunction (extensions/chamfer_distance/chamfer_distance.py:29-71) on libvnpcc."""
 
@@ -666,8 +673,14 @@ class ChamferFn(Function):
         dist2 = torch.empty((B, m), device=dev, dtype=torch.float32)
         idx1 = torch.empty((B, n), device=dev, dtype=torch.int32)
         idx2 = torch.empty((B, m), device=dev, dtype=torch.int32)
-        ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
-        call("vnp_chamfer_fwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
+        nbytes = _lib.lib().vnp_chamfer_pruned_ws_bytes(B, n, m) if min(n, m) >= CHAMFER_PRUNED_MIN_POINTS else 0
+        if nbytes > 0:
+            # dense clouds: pruned exact search (same bits as the brute-force kernel; tests/test_gpu_chamfer.py)
+            ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
+            call("vnp_chamfer_fwd_pruned", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
+        else:
+            ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
+            call("vnp_chamfer_fwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
         return dist1, dist2, idx1, idx2
