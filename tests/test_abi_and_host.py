@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol(lib_built):
     from vn_pointcloudcompletion_amd import _lib
     header = open(os.path.join(ROOT, "include", "vnpcc.h")).read()
-    declared = sorted(set(re.findall(r"^\s*int\s+(vnp_\w+)\s*\(", header, flags=re.M)))
+    declared = sorted(set(re.findall(r"^\s*(?:int|long long)\s+(vnp_\w+)\s*\(", header, flags=re.M)))
     assert len(declared) >= 25
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
