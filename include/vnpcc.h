@@ -125,6 +125,13 @@ int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long long batch_str
 /* ---- pooling ----------------------------------------------------------------------------------------------
  * VNMaxPool (models/vn_layers.py:153-167) over groups of gs consecutive points; idx [G][C] = local arg-max (first max).
  * ws_val / ws_idx: G*ceil(gs/vnp_chunk_points())*C elements. */
+/* VNLinear followed by VNMaxPool in ONE pass (models/pcn.py:173-174): the pooled x = W f and the direction d = W' f
+ * (W' = Wd W) are produced by one split-GEMM whose epilogue forms <x, d> and the arg-max in registers; neither matrix is
+ * written.  Wcat [2C, K]: per 32 channels, 32 rows of W then 32 rows of W'.  ws: vnp_linear_pool_ws_bytes(G, gs, C).
+ * VNP_EINVAL unless split GEMM mode, (G*gs*3) % 192 == 0, gs % 32 == 0, C % 64 == 0, K % 32 == 0 and 16-byte alignment. */
+long long vnp_linear_pool_ws_bytes(long long G, int gs, int C);
+int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
+                        int K, int* idx, float* out, int ldo, void* ws);
 int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int ldd, long long G, int gs, int C,
                     int* idx, float* out, int ldo, float* ws_val, int* ws_idx);
 int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,

@@ -153,3 +153,33 @@ def test_vnstdfeature(G, nf):
     m = m.cuda().train()
     y, z = m(t(G[f"{tag}_x"]))
     assert relerr(y, G[f"{tag}_y"]) < 1e-4 and relerr(z, G[f"{tag}_z"]) < 1e-4
+
+
+@pytest.mark.parametrize("G,gs,C,K", [(3, 64, 128, 64), (2, 2048, 256, 96), (1, 96, 64, 32), (5, 32, 192, 160)])
+def test_linear_pool_fused_epilogue_equals_unfused(lib_built, G, gs, C, K):
+    """VNLinear -> VNMaxPool with the pool in the GEMM epilogue (vnp_linear_pool_fwd: x and d never written) against the
+    two-GEMM + pool-kernel path: same arg-max indices and pooled vectors, bit for bit, including exact ties (duplicated
+    points: the lowest index wins) — and the same gradients, since backward only needs the indices."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(G * 100 + gs + C + K)
+    f = torch.randn(G * gs * 3, K, generator=g)
+    f[3 * (gs // 2):3 * (gs // 2) + 3] = f[0:3]                  # point gs/2 duplicates point 0 (group 0): exact ties
+    f[3 * (gs - 1):3 * gs] = f[3:6]                              # and the last point duplicates point 1
+    W = (torch.randn(C, K, generator=g) / K ** 0.5)
+    Wd = (torch.randn(C, C, generator=g) / C ** 0.5)
+    res = {}
+    for fused in (True, False):
+        ops.POOL_FUSED_EPILOGUE = fused
+        try:
+            fx, Wx = f.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+            out, idx = ops.VNLinearMaxPoolFn.apply(fx, Wx, Wd.cuda(), G, gs)
+            (out * torch.arange(out.numel(), device="cuda").reshape(out.shape).cos()).sum().backward()
+            res[fused] = (out.detach(), idx, fx.grad, Wx.grad)
+        finally:
+            ops.POOL_FUSED_EPILOGUE = True
+    assert torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+    # the ties really occurred and were resolved to the lower index
+    i0 = res[True][1][0]
+    assert (i0 != gs // 2).all() and (i0 != gs - 1).all()

@@ -129,6 +129,65 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     return rc;
 }
 
+// ---- VNLinear + VNMaxPool in one pass (models/pcn.py:173-174: second_conv[1] -> maxpool2) -------------------------------
+// Stage 2 of the fused pool: reduce the per-32-point partials of a group (ascending order keeps the first maximum).
+__global__ void vnp_pool_fused_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, const float* __restrict__ px,
+                                            int nparts, int C, int* __restrict__ idx, float* __restrict__ out, int ldo)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y;
+    size_t slot = (size_t)g * nparts * C + c;
+    float best = pval[slot];
+    size_t bs = slot;
+    for (int k = 1; k < nparts; ++k) {
+        slot += C;
+        const float v = pval[slot];
+        if (v > best) { best = v; bs = slot; }
+    }
+    idx[(size_t)g * C + c] = pidx[bs];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) out[((size_t)g * 3 + t) * ldo + c] = px[3 * bs + t];
+}
+
+extern "C" long long vnp_linear_pool_ws_bytes(long long G, int gs, int C)
+{
+    if (G <= 0 || gs <= 0 || C <= 0 || gs % 32) return 0;
+    return G * (gs / 32) * (long long)C * 20;
+}
+
+// out[g*3+t][c] = (W f)[(g*gs + n*)*3 + t][c] with n* = argmax_n <W f, W' f>(n, c) over the gs points of group g, idx[g][c] = n*.
+// x [G*gs*3, K] rows layout; Wcat [2C, K]: per 32 channels, 32 rows of W then 32 rows of W' (W' = Wd W for VNMaxPool's
+// direction map); ws: vnp_linear_pool_ws_bytes(G, gs, C).  Requirements (else VNP_EINVAL, callers fall back to
+// vnp_gemm + vnp_vn_pool_fwd): split GEMM mode, (G*gs*3) % 192 == 0, gs % 32 == 0, C % 64 == 0, K % 32 == 0, 16-byte aligned.
+extern "C" int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
+                                   int K, int* idx, float* out, int ldo, void* ws)
+{
+    if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0) return VNP_EINVAL;
+    const long long M = G * gs * 3;
+    if (g_vnp_gemm_mode != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || M > 2147483647LL ||
+        (uintptr_t)x % 16 || (uintptr_t)Wcat % 16 || G > 65535)
+        return VNP_EINVAL;
+    const long long nslot = G * (gs / 32) * (long long)C;
+    VnpGemmArgs p{};
+    p.A = x; p.B = Wcat; p.C = nullptr; p.bias = nullptr;
+    p.M = (int)M; p.N = 2 * C; p.K = K;
+    p.lda = ldx; p.ldb = ldw; p.ldc = 0; p.rows_per_group = 1;
+    p.tiles_per_split = K / 32; p.nsplit = 1; p.nbatch = 1;
+    p.pool_val = (float*)ws;
+    p.pool_idx = (int*)((char*)ws + nslot * 4);
+    p.pool_x = (float*)((char*)ws + nslot * 8);
+    p.pool_gs = gs;
+    const long long items = (M / 192) * (2LL * C / 128);
+    if (items > 2147483647LL) return VNP_EINVAL;
+    const long long cap = (long long)vnp_num_cus() * 2;
+    dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
+    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 1>), grid, block, 0, st, p);
+    hipLaunchKernelGGL(vnp_pool_fused_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
+                       (const float*)p.pool_val, (const int*)p.pool_idx, (const float*)p.pool_x, gs / 32, C, idx, out, ldo);
+    return vnp_last_error();
+}
+
 extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
                         const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                         const float* bias, int ldbias, int rows_per_group,

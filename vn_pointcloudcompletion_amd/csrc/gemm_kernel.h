@@ -13,6 +13,9 @@ struct VnpGemmArgs {
     long long slab;                      // elements between the output slabs of consecutive splits
     int nsplit, nbatch;                  // work items = tiles x nsplit x nbatch, walked persistently
     long long bsa, bsb, bsc;             // batch strides (elements) of A, B, C (batched GEMM: attention heads)
+    // VN max-pool epilogue of vnp_gemm_split_kernel<.., EPI = 1> (C is not written): per 32-point wave block and channel,
+    // the best <x, d>, its point index inside the group of pool_gs points, and the winning x vector
+    float* pool_val; int* pool_idx; float* pool_x; int pool_gs;
 };
 
 template <int R, int BK, bool KC, int NV>

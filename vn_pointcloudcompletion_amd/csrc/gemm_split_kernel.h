@@ -149,8 +149,13 @@ __device__ __forceinline__ void vnp_split_write(const vnp_u2 (&pl)[NV][3], char*
     }
 }
 
-// VAR & 8: diagnostic build (clock stamps, scripts/gemm_split_bench.hip); the library instantiates VAR = 0 only
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int VAR = 0>
+// VAR & 8: diagnostic build (clock stamps, scripts/gemm_split_bench.hip); the library instantiates VAR = 0 only.
+// EPI = 1 (192x128 NT FAST only): Vector-Neuron arg-max pool fused into the epilogue.  A's rows are (point, t) triples and B's
+// rows are interleaved per 32 channels as [32 rows of W | 32 rows of W'] (x = W f, d = W' f), so a wave's 64 columns are
+// 32 channels of x and the same 32 channels of d.  The A tile is loaded under a row permutation that puts component t of
+// point (16 i3 + r) into MFMA row-tile 3 i3 + t, row r: every lane then holds whole 3-vectors of x and d for 8 points x 2
+// channels, forms <x, d> in registers and reduces the arg-max over the wave's 32 points.  Neither x nor d is ever written.
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int VAR = 0, int EPI = 0>
 __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArgs p)
 {
     constexpr int BK = 32;
@@ -175,6 +180,15 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     int oa, sa, ob, sb;
     vnp_split_offsets<BM, AKC>(oa, sa, p.lda, tid);
     vnp_split_offsets<BN, BKC>(ob, sb, p.ldb, tid);
+    static_assert(EPI == 0 || (BM == 192 && BN == 128 && AKC && BKC && FAST), "the pool epilogue needs the aligned 192x128 NT kernel");
+    int perm_off[AV];                       // EPI == 1: element offset of the global row that LDS row tid/8 + 32 j holds
+    if (EPI == 1) {
+#pragma unroll
+        for (int j = 0; j < AV; ++j) {
+            const int rho = (tid >> 3) + 32 * j, half = rho / 96, within = rho % 96, i = within >> 4, r16 = within & 15;
+            perm_off[j] = (half * 96 + ((i / 3) * 16 + r16) * 3 + i % 3) * p.lda + (tid & 7) * 4;
+        }
+    }
 
     int m0, n0, kt0, kt1, split, batch;
     auto set_item = [&](int w) {                            // same XCD-aware walk as vnp_gemm_kernel
@@ -193,7 +207,11 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
         const float* pB = p.B + (size_t)fbatch * p.bsb;
         const int k0 = kt * BK;
         const bool full = FAST || (k0 + BK <= p.K);
-        if (FAST || (va && full && fm0 + BM <= p.M))
+        if (EPI == 1) {
+            const float* blk = pA + (size_t)fm0 * p.lda + k0;
+#pragma unroll
+            for (int j = 0; j < AV; ++j) ra[j] = *(const vnp_f4*)(blk + perm_off[j]);
+        } else if (FAST || (va && full && fm0 + BM <= p.M))
             vnp_load_tile_fast<AV>(ra, AKC ? pA + (size_t)fm0 * p.lda + k0 : pA + fm0 + (size_t)k0 * p.lda, oa, sa);
         else vnp_split_load_generic<BM, AKC, AV>(ra, pA, p.lda, fm0, p.M, k0, p.K, va, tid);
         if (FAST || (vb && full && fn0 + BN <= p.N))
@@ -279,6 +297,40 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
             }
         }
 
+        if (EPI == 1) {
+            // acc[3 i3 + t][j][e]: component t of wave-local point 16 i3 + 4 lq + e; j = 0, 1: x channels, j = 2, 3: d channels
+            const int pt0 = m0 / 3 + wm * 32;                         // first point of this wave (global point index)
+            const int grp = pt0 / 32;                                  // partial slot: one per 32 points
+            const int loc0 = pt0 % p.pool_gs;                          // its index inside the pooling group
+            const int Cch = p.N >> 1;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                float bv = 0.f, bx0 = 0.f, bx1 = 0.f, bx2 = 0.f;
+                int bi = 0;
+#pragma unroll
+                for (int i3 = 0; i3 < 2; ++i3)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = acc[3 * i3][jj][e], x1 = acc[3 * i3 + 1][jj][e], x2 = acc[3 * i3 + 2][jj][e];
+                        const float d0 = acc[3 * i3][jj + 2][e], d1 = acc[3 * i3 + 1][jj + 2][e], d2 = acc[3 * i3 + 2][jj + 2][e];
+                        const float dot = fmaf(x2, d2, fmaf(x1, d1, x0 * d0));
+                        if ((i3 == 0 && e == 0) || dot > bv) { bv = dot; bi = 16 * i3 + 4 * lq + e; bx0 = x0; bx1 = x1; bx2 = x2; }
+                    }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {                    // the other lane groups hold the other points
+                    const float ov = __shfl_xor(bv, o), o0 = __shfl_xor(bx0, o), o1 = __shfl_xor(bx1, o), o2 = __shfl_xor(bx2, o);
+                    const int oi = __shfl_xor(bi, o);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bx0 = o0; bx1 = o1; bx2 = o2; }
+                }
+                if (lq == 0) {
+                    const int ch = (n0 >> 1) + wn * 32 + jj * 16 + l16;
+                    const size_t slot = (size_t)grp * Cch + ch;
+                    p.pool_val[slot] = bv;
+                    p.pool_idx[slot] = loc0 + bi;
+                    p.pool_x[3 * slot + 0] = bx0; p.pool_x[3 * slot + 1] = bx1; p.pool_x[3 * slot + 2] = bx2;
+                }
+            }
+        } else
         // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
         {
             float* Cz = p.C + (size_t)split * p.slab + (size_t)batch * p.bsc;

@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) vnp_pool_partial_kernel(const float* __re
             const size_t row = ((size_t)g * gs + n) * 3;
             const float* rx = x + row * ldx + c;
             const float* rd = d + row * ldd + c;
-            const float dot = rx[0] * rd[0] + rx[ldx] * rd[ldd] + rx[2 * ldx] * rd[2 * ldd];
+            const float dot = fmaf(rx[2 * ldx], rd[2 * ldd], fmaf(rx[ldx], rd[ldd], rx[0] * rd[0]));   // same form as the fused epilogue
             if (dot > best || bi == 0x7fffffff) { best = dot; bi = n; }
         }
     }

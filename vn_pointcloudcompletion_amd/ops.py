@@ -23,6 +23,9 @@ BN_MOMENTUM = 0.1
 # VNLinearMaxPoolFn).  Set VNP_POOL_AS_WRITTEN=1 to keep the reference's evaluation order.
 import os as _os
 POOL_DIRECTION_REASSOCIATE = _os.environ.get("VNP_POOL_AS_WRITTEN", "0") != "1"
+# VNLinear -> VNMaxPool: fuse the pool into the GEMM epilogue (vnp_linear_pool_fwd) when shapes allow; VNP_POOL_UNFUSED=1 keeps
+# the two GEMMs + pool kernels
+POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (variant, flops, start_event, end_event)
@@ -436,21 +439,38 @@ class VNLinearMaxPoolFn(Function):
     @staticmethod
     def forward(ctx, x, W, Wd, G, gs):
         x = _rows(x)
-        y = gemm(x, W, nsplit=1)
-        C = y.shape[1]
-        if POOL_DIRECTION_REASSOCIATE:
-            # d = Wd (W x) = (Wd W) x: the product of the two weight matrices is formed once per step (8.6 GFLOP for
-            # 2048x2048x1024) and the per-point direction GEMM contracts over Cin instead of Cout (half the FLOPs here).
-            # Same arithmetic up to fp32 re-association.
-            d = gemm(x, gemm(Wd, W, op_b=1), nsplit=1)
-        else:
-            d = gemm(y, Wd, nsplit=1)
-        nch = _nchunk(gs)
-        ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
-        ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
+        C, K = W.shape
         idx = torch.empty((G, C), device=x.device, dtype=torch.int32)
         out = torch.empty((G * 3, C), device=x.device, dtype=torch.float32)
-        call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        fused = (POOL_DIRECTION_REASSOCIATE and POOL_FUSED_EPILOGUE and _lib.get_gemm_mode() == "split" and (G * gs * 3) % 192 == 0
+                 and gs % 32 == 0 and C % 64 == 0 and K % 32 == 0 and G <= 65535 and _ld(x) % 4 == 0 and x.data_ptr() % 16 == 0)
+        if fused:
+            # one GEMM over the interleaved [W ; Wd W] rows whose epilogue does the arg-max pool: y and d are never written
+            Wp = gemm(Wd, W, op_b=1)
+            Wcat = torch.stack([_rows(W).view(C // 32, 32, K), Wp.view(C // 32, 32, K)], dim=1).reshape(2 * C, K)
+            nb = _lib.lib().vnp_linear_pool_ws_bytes(G, gs, C)
+            ws = torch.empty((nb + 7) // 8, device=x.device, dtype=torch.int64)
+            prof = GEMM_PROFILE
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            call("vnp_linear_pool_fwd", ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
+            if prof is not None:
+                e1.record()
+                prof.append(("NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
+        else:
+            y = gemm(x, W, nsplit=1)
+            if POOL_DIRECTION_REASSOCIATE:
+                # d = Wd (W x) = (Wd W) x: the product of the two weight matrices is formed once per step (8.6 GFLOP for
+                # 2048x2048x1024) and the per-point direction GEMM contracts over Cin instead of Cout (half the FLOPs here).
+                # Same arithmetic up to fp32 re-association.
+                d = gemm(x, gemm(Wd, W, op_b=1), nsplit=1)
+            else:
+                d = gemm(y, Wd, nsplit=1)
+            nch = _nchunk(gs)
+            ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
+            ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
+            call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
