@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--num-coarse", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-input-MFMA comparison steps (clean profiles)")
     args = ap.parse_args()
 
     from vn_pointcloudcompletion_amd import _lib, ops
@@ -124,7 +125,7 @@ def main():
     # the same step on the fp32-input MFMA kernels, outside the timed region (single GPU only; a comparison, not `value`)
     fp32_mode = None
     gemm_mode = _lib.get_gemm_mode()
-    if world == 1 and gemm_mode == "split":
+    if world == 1 and gemm_mode == "split" and not args.no_fp32_mode:
         _lib.set_gemm_mode("fp32")
         train_step(cfg, model, opt, p, c)
         torch.cuda.synchronize()
