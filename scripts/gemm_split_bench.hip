@@ -43,6 +43,12 @@ void run_case(const char* name, int M, int N, int K, int nsplit, const float* A,
         printf("  r%d fp32 mfma    %8.3f ms %7.1f TF\n", round, t, fl / t * 1e-9);
         t = time_it([&] { hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true>), grid, block, 0, 0, p2); }, 5);
         printf("  r%d bf16x3 split %8.3f ms %7.1f TF-equiv\n", round, t, fl / t * 1e-9);
+        for (int cgv : {4, 8, 16}) {
+            if (cgv >= N / 128) continue;
+            VnpGemmArgs p4 = p2; p4.col_group = cgv;
+            t = time_it([&] { hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true>), grid, block, 0, 0, p4); }, 5);
+            printf("  r%d   col_group %2d %8.3f ms %7.1f TF-equiv\n", round, cgv, t, fl / t * 1e-9);
+        }
     }
     {   // in-kernel clock (MI355X_MICROARCH.md, DVFS give-back item 6): d(s_memtime) / d(s_memrealtime) x 100 MHz
         unsigned long long* dbg;
@@ -85,7 +91,7 @@ void run_case(const char* name, int M, int N, int K, int nsplit, const float* A,
 
 int main(int argc, char** argv)
 {
-    const size_t maxA = (size_t)1572864 * 512, maxB = (size_t)1572864 * 512, maxC = (size_t)1572864 * 512;
+    const size_t maxA = (size_t)1572864 * 512, maxB = (size_t)1572864 * 512, maxC = (size_t)196608 * 4096;
     float *A, *B, *C1, *C2;
     CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&B, maxB * 4)); CK(hipMalloc(&C1, maxC * 4)); CK(hipMalloc(&C2, maxC * 4));
     std::vector<float> hA(maxA), hB(maxB);
@@ -97,6 +103,7 @@ int main(int argc, char** argv)
     CK(hipMemcpy(A, hA.data(), maxA * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, hB.data(), maxB * 4, hipMemcpyHostToDevice));
     run_case<192, true, true>("enc 1024->2048", 196608, 2048, 1024, 1, A, B, C1, C2, hA, hB);
+    run_case<192, true, true>("pool x|d N=4096", 196608, 4096, 1024, 1, A, B, C1, C2, hA, hB);
     run_case<192, true, true>("dec 256->512", 1572864, 512, 256, 1, A, B, C1, C2, hA, hB);
     run_case<192, true, false>("enc dgrad NN", 196608, 512, 2048, 1, A, B, C1, C2, hA, hB);
     run_case<192, true, false>("dec dgrad NN", 1572864, 256, 512, 1, A, B, C1, C2, hA, hB);

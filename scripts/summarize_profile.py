@@ -30,7 +30,7 @@ with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 summary = {"tag": tag, "source": "rocprofv3 --kernel-trace --stats", "kernels": {}}
 for r in rows:
-    if r["Name"].startswith("void vnp_gemm_kernel") or r["Name"].startswith("vnp_"):
+    if "vnp_" in r["Name"].split("(")[0]:
         summary["kernels"][r["Name"].split("(")[0][:90]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                                             "total_ms": float(r["TotalDurationNs"]) / 1e6, "pct": float(r["Percentage"])}
 
@@ -52,7 +52,7 @@ if fetch_dir:
     fe, wr = pmc(fetch_dir, "FETCH_SIZE"), pmc(write_dir, "WRITE_SIZE")
     traffic = {}
     for k in fe:
-        if not (k.startswith("void vnp_gemm_kernel") or k.startswith("vnp_")):
+        if "vnp_" not in k:
             continue
         n = max(fe[k][1], 1)
         rd = 2.0 * fe[k][0] * 1024 / n

@@ -80,10 +80,15 @@ __global__ void vnp_chamfer_unpack_kernel(const unsigned long long* __restrict__
     idx[i] = (int)(unsigned)(v & 0xffffffffu);
 }
 
-// grad_xyz1[j] += g*(x1 - x2[idx]); grad_xyz2[idx] -= g*(x1 - x2[idx]), g = 2*grad_dist[j]   (chamfer3D.cu:155-174)
+// One direction of NmDistanceGradKernel (chamfer3D.cu:155-174): with v = 2*grad_dist[j]*(x1[j] - x2[idx[j]]),
+//   own[j] (+)= v   and   other[idx[j]] -= v.
+// Point j belongs to exactly one thread, so its own term is a plain store (FIRST pass: `own` need not be zeroed) or a plain
+// read-modify-write (second pass, after the first pass's scatter into the same array has completed at the kernel boundary);
+// only the scatter into the other cloud needs atomics.
+template <bool FIRST>
 __global__ void vnp_chamfer_grad_kernel(int n, const float* __restrict__ xyz1, int m, const float* __restrict__ xyz2,
                                         const float* __restrict__ grad_dist, const int* __restrict__ idx,
-                                        float* __restrict__ grad1, float* __restrict__ grad2)
+                                        float* __restrict__ own, float* __restrict__ other)
 {
     const int b = blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,8 +100,8 @@ __global__ void vnp_chamfer_grad_kernel(int n, const float* __restrict__ xyz1, i
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const float v = g * (xyz1[p + t] - xyz2[qq + t]);
-        atomicAdd(&grad1[p + t], v);
-        atomicAdd(&grad2[qq + t], -v);
+        own[p + t] = FIRST ? v : own[p + t] + v;
+        atomicAdd(&other[qq + t], -v);
     }
 }
 
@@ -434,7 +439,7 @@ extern "C" int vnp_chamfer_fwd(hipStream_t st, int B, int n, const float* xyz1, 
     return vnp_chamfer_one_direction(st, B, m, xyz2, n, xyz1, dist2, idx2, (unsigned long long*)ws);
 }
 
-// Replaces chamfer_3D.backward (chamfer_cuda.cpp:22-26, chamfer3D.cu:176-195).  grad_xyz1/2 are zeroed here.
+// Replaces chamfer_3D.backward (chamfer_cuda.cpp:22-26, chamfer3D.cu:176-195).  grad_xyz1/2 need not be zeroed.
 extern "C" int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                                const float* grad_dist1, const int* idx1, const float* grad_dist2, const int* idx2,
                                float* grad_xyz1, float* grad_xyz2)
@@ -442,11 +447,10 @@ extern "C" int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, 
     if (B <= 0 || n <= 0 || m <= 0 || !xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2)
         return VNP_EINVAL;
     if (B > 65535) return VNP_EINVAL;
-    hipError_t e = hipMemsetAsync(grad_xyz1, 0, (size_t)B * n * 12, st);
+    hipError_t e = hipMemsetAsync(grad_xyz2, 0, (size_t)B * m * 12, st);
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(grad_xyz2, 0, (size_t)B * m * 12, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vnp_chamfer_grad_kernel, dim3(vnp_cdiv(n, 256), B), dim3(256), 0, st, n, xyz1, m, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2);
-    hipLaunchKernelGGL(vnp_chamfer_grad_kernel, dim3(vnp_cdiv(m, 256), B), dim3(256), 0, st, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
+    // pass 1 stores grad_xyz1 and scatters into the zeroed grad_xyz2; pass 2 adds its own terms to grad_xyz2 and scatters into grad_xyz1
+    hipLaunchKernelGGL(vnp_chamfer_grad_kernel<true>, dim3(vnp_cdiv(n, 256), B), dim3(256), 0, st, n, xyz1, m, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2);
+    hipLaunchKernelGGL(vnp_chamfer_grad_kernel<false>, dim3(vnp_cdiv(m, 256), B), dim3(256), 0, st, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
     return vnp_last_error();
 }

@@ -195,7 +195,13 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
         const int sbi = w / nwg, t = w - sbi * nwg;
         const int q = nwg >> 3, r = nwg & 7, x = t & 7;
         const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
-        m0 = (wg / nbn) * BM; n0 = (wg % nbn) * BN;
+        // column tiles in groups of cg: (group, row panel, column in group), column fastest
+        const int cg = (p.col_group > 0 && p.col_group < nbn) ? p.col_group : nbn;
+        const int full = (nbn / cg) * cg * nbm;
+        int row, col;
+        if (wg < full) { const int g = wg / (nbm * cg), rem = wg - g * (nbm * cg); row = rem / cg; col = g * cg + rem % cg; }
+        else { const int wl = nbn - (nbn / cg) * cg, rem = wg - full; row = rem / wl; col = (nbn / cg) * cg + rem % wl; }
+        m0 = row * BM; n0 = col * BN;
         split = sbi % p.nsplit; batch = sbi / p.nsplit;
         kt0 = split * p.tiles_per_split;
         kt1 = min(nk, kt0 + p.tiles_per_split);
