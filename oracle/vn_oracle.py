@@ -257,6 +257,87 @@ def vn_dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats
     return h.squeeze(-1).contiguous(), g
 
 
+# ------------------------------------------------------------- non-equivariant baselines
+def _bn1d(sd, prefix, x, training, new_stats):
+    """nn.BatchNorm1d on [B, C, N] (momentum 0.1, eps 1e-5)."""
+    w, b, rm, rv = sd[f"{prefix}.weight"], sd[f"{prefix}.bias"], sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"]
+    if not training:
+        return (x - rm[None, :, None]) / torch.sqrt(rv[None, :, None] + 1e-5) * w[None, :, None] + b[None, :, None]
+    mean = x.mean(dim=(0, 2))
+    var = x.var(dim=(0, 2), unbiased=False)
+    if new_stats is not None:
+        n = x.shape[0] * x.shape[2]
+        new_stats[f"{prefix}.running_mean"] = 0.9 * rm + 0.1 * mean
+        new_stats[f"{prefix}.running_var"] = 0.9 * rv + 0.1 * var * n / max(n - 1, 1)
+    return (x - mean[None, :, None]) / torch.sqrt(var[None, :, None] + 1e-5) * w[None, :, None] + b[None, :, None]
+
+
+def foldingnet_forward(sd, coarse, feature_global, training=True, grid_size=4, prefix="decoder", new_stats=None):
+    """models/pcn.py:274-317 (FoldingNet.forward; `rot` is accepted and ignored there).  coarse [B,Mc,3],
+    feature_global [B,2048,3] (flattened to 6144) -> fine [B, Mc*S, 3]."""
+    B, Mc, _ = coarse.shape
+    S = grid_size ** 2
+    Md = Mc * S
+    g = feature_global.reshape(B, -1)
+    point_feat = coarse.unsqueeze(2).expand(-1, -1, S, -1).reshape(B, Md, 3).transpose(2, 1)        # [B,3,Md]
+    lin = torch.linspace(-0.05, 0.05, steps=grid_size, dtype=coarse.dtype)
+    a = lin.view(1, grid_size).expand(grid_size, grid_size).reshape(1, -1)
+    b = lin.view(grid_size, 1).expand(grid_size, grid_size).reshape(1, -1)
+    seed = torch.cat([a, b], dim=0).view(1, 2, 1, S).expand(B, -1, Mc, -1).reshape(B, 2, Md)
+    feat = torch.cat([g.unsqueeze(2).expand(-1, -1, Md), seed, point_feat], dim=1)
+
+    def conv(i, x):
+        return torch.einsum("oc,bcn->bon", sd[f"{prefix}.final_conv.{i}.weight"][:, :, 0], x) + sd[f"{prefix}.final_conv.{i}.bias"][None, :, None]
+    h = torch.relu(_bn1d(sd, f"{prefix}.final_conv.1", conv(0, feat), training, new_stats))
+    h = torch.relu(_bn1d(sd, f"{prefix}.final_conv.4", conv(3, h), training, new_stats))
+    fine = conv(6, h) + point_feat
+    return fine.transpose(1, 2).contiguous()
+
+
+def graph_feature(coor_q, x_q, coor_k, x_k, k=16):
+    """models/dgcnn.py:101-124 (DGCNN_fps.get_graph_feature).  coor [B,3,N], x [B,C,N] -> [B,2C,Nq,k]."""
+    B, C, Nk = x_k.shape
+    Nq = x_q.shape[2]
+    idx = knn_torch(coor_k.transpose(1, 2), coor_q.transpose(1, 2), k)                 # [B,Nq,k]
+    flat = x_k.transpose(1, 2).reshape(B * Nk, C)
+    gi = (idx + torch.arange(B).view(B, 1, 1) * Nk).reshape(-1)
+    feature = flat[gi].view(B, Nq, k, C).permute(0, 3, 1, 2)                             # [B,C,Nq,k]
+    xq = x_q.unsqueeze(-1).expand(-1, -1, -1, k)
+    return torch.cat((feature - xq, xq), dim=1)
+
+
+def dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats=None):
+    """models/dgcnn.py:126-161 (DGCNN_fps.forward, num_coarse != 224).  x [B,N,3] -> (coarse [B,Mc,3], feature_global [B,1024])."""
+    p = prefix
+    B = x.shape[0]
+    coor = x.transpose(1, 2)                                                             # [B,3,N]
+    f = torch.einsum("oc,bcn->bon", sd[f"{p}.input_trans.weight"][:, :, 0], coor) + sd[f"{p}.input_trans.bias"][None, :, None]
+
+    def layer(name, e):
+        y = torch.einsum("oc,bcnk->bonk", sd[f"{p}.{name}.0.weight"][:, :, 0, 0], e)
+        y = torch.nn.functional.group_norm(y, 4, sd[f"{p}.{name}.1.weight"], sd[f"{p}.{name}.1.bias"], 1e-5)
+        return torch.nn.functional.leaky_relu(y, 0.2).max(dim=-1)[0]
+
+    def down(coor, f, m):
+        i = fps_torch(coor.transpose(1, 2), m)
+        return (torch.gather(coor, 2, i[:, None, :].expand(-1, 3, -1)), torch.gather(f, 2, i[:, None, :].expand(-1, f.shape[1], -1)))
+
+    f = layer("layer1", graph_feature(coor, f, coor, f, k))
+    cq, fq = down(coor, f, 512)
+    f = layer("layer2", graph_feature(cq, fq, coor, f, k))
+    coor = cq
+    f = layer("layer3", graph_feature(coor, f, coor, f, k))
+    cq, fq = down(coor, f, 128)
+    f = layer("layer4", graph_feature(cq, fq, coor, f, k))
+    h = torch.einsum("oc,bcn->bon", sd[f"{p}.increase_dim.0.weight"][:, :, 0], f) + sd[f"{p}.increase_dim.0.bias"][None, :, None]
+    h = torch.nn.functional.leaky_relu(_bn1d(sd, f"{p}.increase_dim.1", h, training, new_stats), 0.2)
+    h = torch.einsum("oc,bcn->bon", sd[f"{p}.increase_dim.3.weight"][:, :, 0], h) + sd[f"{p}.increase_dim.3.bias"][None, :, None]
+    g = h.max(dim=-1)[0]                                                                 # [B,1024]
+    c = torch.relu(g @ sd[f"{p}.coarse_pred.0.weight"].t() + sd[f"{p}.coarse_pred.0.bias"])
+    c = c @ sd[f"{p}.coarse_pred.2.weight"].t() + sd[f"{p}.coarse_pred.2.bias"]
+    return c.reshape(B, -1, 3).contiguous(), g
+
+
 # ------------------------------------------------------------- VN transformer / attention decoder
 def vn_attention(sd, prefix, vn_x, num_heads, scale):
     """models/transformer.py:90-106 (Attention.forward).  vn_x [B,C,3,N]."""

@@ -449,6 +449,133 @@ def main_dgcnn():
     npz("dgcnn_small.npz", **out)
 
 
+def main_baselines():
+    """Section 8: the non-equivariant baselines of the plugin surface: FoldingNet decoder
+    (models/pcn.py:274-317) on a VN encoder's [B,2048,3] feature, and the DGCNN_fps encoder (models/dgcnn.py:19-161)."""
+    _standins()
+    from oracle import vn_oracle as O
+    from types import SimpleNamespace
+    import models.pcn as RP
+    import models.dgcnn as RD
+    gen = torch.Generator().manual_seed(91)
+    cfg = SimpleNamespace(num_coarse=64, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cpu")
+    out = {}
+    # --- FoldingNet decoder
+    torch.manual_seed(5)
+    dec = RP.FoldingNet(cfg)
+    dec.num_dense = 64 * 16
+    dec.train()
+    coarse = (torch.rand(2, 64, 3, generator=gen) - 0.5).requires_grad_(True)
+    fg = (0.5 * torch.randn(2, 2048, 3, generator=gen)).requires_grad_(True)
+    gf = torch.randn(2, 1024, 3, generator=gen)
+    sd0 = {"decoder." + k: v.clone() for k, v in dec.state_dict().items()}
+    fine = dec(coarse, fg)
+    (fine * gf).sum().backward()
+    new_stats = {}
+    fo = O.foldingnet_forward(sd0, coarse.detach(), fg.detach(), True, 4, "decoder", new_stats)
+    check(fo, fine, "foldingnet fine", 1e-4)
+    for k, v in dec.state_dict().items():
+        if "running" in k:
+            check(new_stats["decoder." + k], v, "foldingnet " + k, 1e-4)
+            out["fold.after." + k] = v.clone()
+    out.update({"fold.coarse": coarse.detach(), "fold.fg": fg.detach(), "fold.gf": gf, "fold.fine": fine.detach(),
+                "fold.g_coarse": coarse.grad, "fold.g_fg": fg.grad})
+    def norms64(tag, module64, module32):
+        """fp64 gradient norms, and a strided sample (<= 16384 values) of every gradient in fp32 and fp64: the tests compare the
+        HIP path's error against fp64 with the reference's own fp32 error on the same sample."""
+        out[tag + ".grad_norms64"] = np.array([prm.grad.double().norm().item() for _, prm in module64.named_parameters()])
+        for (k, p64), (_, p32) in zip(module64.named_parameters(), module32.named_parameters()):
+            stride = max(1, -(-p64.numel() // 16384))
+            out[f"{tag}.gs64.{k}"] = p64.grad.flatten()[::stride].numpy()
+            out[f"{tag}.gs32.{k}"] = p32.grad.flatten()[::stride].numpy()
+
+    def summarise(tag, named, sd, pre):
+        names, norms, heads, wsum, wabs = [], [], [], [], []
+        for k, prm in named:
+            names.append(k)
+            wsum.append(sd[pre + k].double().sum().item())
+            wabs.append(sd[pre + k].double().abs().sum().item())
+            norms.append(prm.grad.double().norm().item())
+            hh = torch.zeros(16)
+            hh[:min(16, prm.numel())] = prm.grad.flatten()[:16]
+            heads.append(hh.numpy())
+        out.update({tag + ".names": np.array(names), tag + ".grad_norms": np.array(norms), tag + ".grad_heads": np.stack(heads),
+                    tag + ".weight_sum": np.array(wsum), tag + ".weight_abssum": np.array(wabs)})
+    summarise("fold", dec.named_parameters(), sd0, "decoder.")      # weights are re-created from the seed (5) in the tests
+    # fp64 yardstick: this fixture (B = 2, a 6144-value global feature that dominates the first BatchNorm's variance) is
+    # ill-conditioned in backward — the reference's own fp32 gradients sit ~1e-3 from its fp64 gradients
+    dec64 = RP.FoldingNet(cfg).double()
+    dec64.num_dense = 64 * 16
+    dec64.folding_seed = dec64.folding_seed.double()
+    dec64.load_state_dict({k[len("decoder."):]: (v.double() if v.dtype.is_floating_point else v) for k, v in sd0.items()})
+    dec64.train()
+    c64 = coarse.detach().double().requires_grad_(True)
+    f64 = fg.detach().double().requires_grad_(True)
+    fine64 = dec64(c64, f64)
+    (fine64 * gf.double()).sum().backward()
+    out.update({"fold.fine64": fine64.detach(), "fold.g_coarse64": c64.grad, "fold.g_fg64": f64.grad})
+    norms64("fold", dec64, dec)
+    # eval mode (BatchNorm on running statistics: no batch coupling, so backward is well conditioned): forward and gradients,
+    # fp32 and fp64 — the tight gradient check of the tests; the train-mode gradients above are chaotic at the 1e-7 level
+    dec.eval()
+    dec.zero_grad()
+    ce = coarse.detach().clone().requires_grad_(True)
+    fe = fg.detach().clone().requires_grad_(True)
+    fine_e = dec(ce, fe)
+    (fine_e * gf).sum().backward()
+    out["fold.fine_eval"] = fine_e.detach()
+    dec64e = RP.FoldingNet(cfg).double()
+    dec64e.num_dense = 64 * 16
+    dec64e.folding_seed = dec64e.folding_seed.double()
+    dec64e.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in dec.state_dict().items()})
+    dec64e.eval()
+    ce64 = coarse.detach().double().requires_grad_(True)
+    fe64 = fg.detach().double().requires_grad_(True)
+    (dec64e(ce64, fe64) * gf.double()).sum().backward()
+    out.update({"folde.g_coarse": ce.grad, "folde.g_fg": fe.grad, "folde.g_coarse64": ce64.grad, "folde.g_fg64": fe64.grad})
+    for (k, p64), (_, p32) in zip(dec64e.named_parameters(), dec.named_parameters()):
+        stride = max(1, -(-p64.numel() // 16384))
+        out[f"folde.gs64.{k}"] = p64.grad.flatten()[::stride].numpy()
+        out[f"folde.gs32.{k}"] = p32.grad.flatten()[::stride].numpy()
+    out["folde.grad_norms64"] = np.array([prm.grad.double().norm().item() for _, prm in dec64e.named_parameters()])
+    check(O.foldingnet_forward({"decoder." + k: v for k, v in dec.state_dict().items()}, coarse.detach(), fg.detach(), False, 4, "decoder"),
+          out["fold.fine_eval"], "foldingnet eval", 1e-4)
+    # --- DGCNN_fps encoder (N = 640 -> 512 -> 128, k = 16, 32 coarse points)
+    cfg2 = SimpleNamespace(num_coarse=32, latent_dim=1024, only_coarse=True, enc_pretrained="none", device="cpu")
+    x = torch.rand(2, 640, 3, generator=gen) - 0.5
+    gc, gg = torch.randn(2, 32, 3, generator=gen), torch.randn(2, 1024, generator=gen)
+    chosen = None
+    for seed in range(20):
+        torch.manual_seed(seed)
+        enc = RD.DGCNN_fps(cfg2).train()
+        sd1 = {"encoder." + k: v.clone() for k, v in enc.state_dict().items()}
+        c32, g32 = enc(x)
+        enc64 = RD.DGCNN_fps(cfg2).double().train()
+        enc64.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in enc.state_dict().items()})
+        # note: the first forward already updated enc's running stats; they do not enter a train-mode forward
+        c64, g64 = enc64(x.double())
+        dc, dg = (c32.double() - c64).abs().max().item(), (g32.double() - g64).abs().max().item()
+        print(f"dgcnn_fps seed {seed}: reference fp32 vs fp64: coarse {dc:.2e} global {dg:.2e}")
+        if dc < 2e-5 and dg < 2e-5:
+            chosen = seed
+            break
+    assert chosen is not None
+    (c32 * gc).sum().backward(retain_graph=True)
+    (g32 * gg).sum().backward()
+    (c64 * gc.double()).sum().backward(retain_graph=True)
+    (g64 * gg.double()).sum().backward()
+    norms64("enc", enc64, enc)
+    co, go = O.dgcnn_fps_forward(sd1, x, True)
+    check(co, c32, "dgcnn_fps coarse", 1e-4), check(go, g32, "dgcnn_fps global", 1e-4)
+    out.update({"enc.seed": chosen, "enc.x": x, "enc.coarse": c32.detach(), "enc.global": g32.detach(), "enc.coarse64": c64, "enc.global64": g64,
+                "enc.gc": gc, "enc.gg": gg})
+    summarise("enc", enc.named_parameters(), sd1, "encoder.")
+    for k, v in enc.state_dict().items():
+        if "running" in k:
+            out["enc.after." + k] = v.clone()
+    npz("baselines_small.npz", **out)
+
+
 def main_attention():
     """Section 6: Attention_VN_FoldingNet (BASELINE config 4 decoder) at reduced size: B=2, 128 centres -> 2048 points.
     The decoder (two transformer blocks + two folding stages, 6 train-mode BatchNorms over few hundred samples) amplifies
@@ -657,3 +784,5 @@ if __name__ == "__main__":
         main_dgcnn()
     if which in ("all", "attention"):
         main_attention()
+    if which in ("all", "baselines"):
+        main_baselines()

@@ -212,3 +212,27 @@ def test_emd_oracle_properties():
     # n != m: integer multipliers (emd_kernel.cu:29-35): rows of the larger side carry weight 1, the smaller n/m each
     m2 = CO.emd_approxmatch(a[:, :32], b)                                              # n = 32 < m = 96 -> multiL = 3
     assert np.abs(m2.sum(1) - 3).max() < 1e-2 and np.abs(m2.sum(2) - 1).max() < 1e-2
+
+
+def test_baseline_oracles_shapes_and_determinism():
+    """The non-VN baseline restatements (oracle.foldingnet_forward / dgcnn_fps_forward) were checked against the reference
+    while tests/golden/baselines_small.npz was generated; here: they reproduce the stored outputs from seed-rebuilt weights."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from conftest import load_golden
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd.baselines import DGCNN_fps, FoldingNet
+    G = load_golden("baselines_small.npz")
+    cfg = SimpleNamespace(num_coarse=64, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cpu")
+    torch.manual_seed(5)
+    dec = FoldingNet(cfg)                                   # parameters only: same members, same init stream as the reference
+    sd = {"decoder." + k: v for k, v in dec.state_dict().items()}
+    fine = O.foldingnet_forward(sd, torch.as_tensor(G["fold.coarse"]), torch.as_tensor(G["fold.fg"]), True)
+    assert np.abs(fine.numpy() - G["fold.fine"]).max() < 1e-4
+    cfg2 = SimpleNamespace(num_coarse=32, latent_dim=1024, only_coarse=True, enc_pretrained="none", device="cpu")
+    torch.manual_seed(int(G["enc.seed"]))
+    enc = DGCNN_fps(cfg2)
+    sd = {"encoder." + k: v for k, v in enc.state_dict().items()}
+    coarse, g = O.dgcnn_fps_forward(sd, torch.as_tensor(G["enc.x"]), True)
+    assert np.abs(coarse.numpy() - G["enc.coarse"]).max() < 1e-4 and np.abs(g.numpy() - G["enc.global"]).max() < 1e-4

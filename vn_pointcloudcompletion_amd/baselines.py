@@ -1,0 +1,166 @@
+"""The two non-equivariant members of the reference's plugin surface:
+
+  * ``FoldingNet``   — dec_type "foldingnet"  (/root/reference/models/pcn.py:274-317)
+  * ``DGCNN_fps``    — enc_type "dgcnn_fps"   (/root/reference/models/dgcnn.py:19-161)
+
+Same constructor signatures, attribute names and ``state_dict`` keys as the reference (parameters live in the same
+``nn.Conv1d`` / ``nn.Conv2d`` / ``nn.BatchNorm1d`` / ``nn.GroupNorm`` / ``nn.Linear`` members, created in the same order,
+so the same seed gives the same weights and reference checkpoints load).
+
+These are baselines outside the measured hot path.  Everything with real arithmetic in it runs on libvnpcc — every
+1x1 convolution / linear layer is ``vnp_gemm`` (point-major rows ``[B*N, C]``), neighbour search is ``vnp_knn``, sampling is
+``vnp_fps``, the loss is the HIP Chamfer — and there is no CPU path (CPU tensors raise).  The normalisation / activation /
+max glue between the GEMMs is expressed with ATen ops on the device; as in the VN networks, broadcast input channels are
+never materialised: the decoder's first layer is a per-sample bias plus a rank-5 per-point term instead of a GEMM over a
+``[B, 6149, 16384]`` tensor, and EdgeConv is ``W1 x_k[idx] + (W2 - W1) x_q`` (two per-point GEMMs and a gather) instead of a
+GEMM over the k-times larger edge tensor.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _linear(rows, weight, bias=None):
+    """rows [P, Cin] x weight [Cout, Cin]^T (+ bias) on vnp_gemm, with autograd."""
+    y = ops.VNLinearFn.apply(rows, weight, None, 0)
+    return y if bias is None else y + bias
+
+
+def _bn_rows(bn: nn.BatchNorm1d, rows):
+    """nn.BatchNorm1d of a [B, C, N] tensor, evaluated on its point-major rows [B*N, C] (same statistics)."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(rows, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+
+
+class FoldingNet(nn.Module):
+    """models/pcn.py:274-317.  forward(coarse [B,Mc,3], feature_global [B,2048,3] | [B,6144], rot ignored) -> fine [B,Mc*S,3]."""
+
+    def __init__(self, config, grid_size=4):
+        super().__init__()
+        self.grid_size = grid_size
+        if config.num_coarse == 448:
+            self.num_coarse = config.num_coarse // 2
+            self.num_dense = 14336
+            self.grid_size = 8
+        else:
+            self.num_coarse = config.num_coarse
+            self.num_dense = 16384
+            self.grid_size = 4
+        self.final_conv = nn.Sequential(
+            nn.Conv1d(2048 * 3 + 3 + 2, 512, 1),
+            nn.BatchNorm1d(512),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(512, 512, 1),
+            nn.BatchNorm1d(512),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(512, 3, 1),
+        )
+        g = self.grid_size
+        lin = torch.linspace(-0.05, 0.05, steps=g, dtype=torch.float)
+        a = lin.view(1, g).expand(g, g).reshape(1, -1)
+        b = lin.view(g, 1).expand(g, g).reshape(1, -1)
+        self.folding_seed = torch.cat([a, b], dim=0).view(1, 2, g ** 2)         # plain attribute, as in the reference
+
+    def forward(self, coarse, feature_global, rot=None):
+        B, Mc, _ = coarse.shape
+        S = self.grid_size ** 2
+        if Mc * S != self.num_dense:
+            raise RuntimeError(f"FoldingNet: num_coarse*grid^2 = {Mc * S} != num_dense = {self.num_dense}")
+        dev = coarse.device
+        coarse = coarse.contiguous().float()
+        g = feature_global.reshape(B, -1).float()
+        c0, bn0, c1, bn1, c2 = self.final_conv[0], self.final_conv[1], self.final_conv[3], self.final_conv[4], self.final_conv[6]
+        W0 = c0.weight[:, :, 0]
+        L = g.shape[1]
+        if W0.shape[1] != L + 5:
+            raise RuntimeError(f"FoldingNet expects a {W0.shape[1] - 5}-value global feature, got {L}")
+        # cat([global.expand(Md), seed, point_feat]) @ W0^T  =  per-sample bias + seed term (per grid cell) + coarse term (per centre)
+        bias = _linear(g, W0[:, :L], c0.bias)                                                   # [B, 512]
+        seed = self.folding_seed.to(dev)[0].t().contiguous()                                     # [S, 2]
+        t_seed = seed @ W0[:, L:L + 2].t()                                                       # [S, 512]   (K = 2: ATen)
+        t_coarse = _linear(coarse.reshape(B * Mc, 3), W0[:, L + 2:L + 5])                        # [B*Mc, 512]
+        pre = (bias.view(B, 1, 1, -1) + t_coarse.view(B, Mc, 1, -1) + t_seed.view(1, 1, S, -1)).reshape(B * Mc * S, -1)
+        h = torch.relu(_bn_rows(bn0, pre))
+        h = torch.relu(_bn_rows(bn1, _linear(h, c1.weight[:, :, 0], c1.bias)))
+        point_feat = coarse.unsqueeze(2).expand(-1, -1, S, -1).reshape(B * Mc * S, 3)
+        fine = _linear(h, c2.weight[:, :, 0], c2.bias) + point_feat
+        return fine.reshape(B, Mc * S, 3)
+
+
+class DGCNN_fps(nn.Module):
+    """models/dgcnn.py:19-161.  forward(x [B,N,3]) -> (coarse [B,Mc,3] | (coarse, coarse_cat), feature_global [B,1024])."""
+
+    def __init__(self, config, latent_dim=1024, grid_size=4, only_coarse=False, num_dense=16384):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.num_dense = num_dense
+        self.grid_size = grid_size
+        self.num_coarse = config.num_coarse // 2 if config.num_coarse == 448 else config.num_coarse
+        self.only_coarse = only_coarse
+        self.k = 16
+        self.input_trans = nn.Conv1d(3, 8, 1)
+
+        def block(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.GroupNorm(4, cout), nn.LeakyReLU(negative_slope=0.2))
+        self.layer1 = block(16, 32)
+        self.layer2 = block(64, 64)
+        self.layer3 = block(128, 64)
+        self.layer4 = block(128, 128)
+        self.increase_dim = nn.Sequential(nn.Conv1d(128, 1024, 1), nn.BatchNorm1d(1024), nn.LeakyReLU(negative_slope=0.2),
+                                          nn.Conv1d(1024, 1024, 1))
+        self.coarse_pred = nn.Sequential(nn.Linear(1024, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 3 * self.num_coarse))
+
+    @staticmethod
+    def fps_downsample(coor, x, num_group):
+        """coor [B,N,3], x rows [B,N,C] -> the num_group furthest-point samples of both (vnp_fps: starts at point 0)."""
+        idx = ops.fps_indices(coor, num_group).long()
+        return (torch.gather(coor, 1, idx[..., None].expand(-1, -1, 3)),
+                torch.gather(x, 1, idx[..., None].expand(-1, -1, x.shape[2])))
+
+    def _edge_conv(self, layer, coor_q, x_q, coor_k, x_k):
+        """get_graph_feature + Conv2d(1x1, no bias) + GroupNorm(4) + LeakyReLU + max over the k neighbours
+        (models/dgcnn.py:101-124 and the layerN blocks).  coor [B,N,3]; x rows [B,N,C] -> [B,Nq,Cout]."""
+        conv, gn = layer[0], layer[1]
+        B, Nq, C = x_q.shape
+        Nk = x_k.shape[1]
+        W = conv.weight[:, :, 0, 0]
+        Cout = W.shape[0]
+        with torch.no_grad():
+            idx = ops.knn_indices(coor_k, coor_q, self.k).long()                       # [B,Nq,k], sorted by (distance, index)
+            gidx = (idx + torch.arange(B, device=idx.device).view(B, 1, 1) * Nk).reshape(-1)
+        u = _linear(x_k.reshape(B * Nk, C), W[:, :C])                                   # neighbour term  W1 x_k
+        v = _linear(x_q.reshape(B * Nq, C), W[:, C:] - W[:, :C])                        # centre term  (W2 - W1) x_q
+        e = (u[gidx].view(B, Nq, self.k, Cout) + v.view(B, Nq, 1, Cout)).view(B, Nq * self.k, gn.num_groups, Cout // gn.num_groups)
+        mean = e.mean(dim=(1, 3), keepdim=True)
+        var = e.var(dim=(1, 3), unbiased=False, keepdim=True)
+        y = ((e - mean) * torch.rsqrt(var + gn.eps)).view(B, Nq, self.k, Cout) * gn.weight + gn.bias
+        return F.leaky_relu(y, 0.2).max(dim=2)[0]
+
+    def forward(self, x):
+        B, N, _ = x.shape
+        coor = x.contiguous().float()
+        f = _linear(coor.reshape(B * N, 3), self.input_trans.weight[:, :, 0], self.input_trans.bias).view(B, N, -1)
+        f = self._edge_conv(self.layer1, coor, f, coor, f)
+        coor_q, f_q = self.fps_downsample(coor, f, 512)
+        f = self._edge_conv(self.layer2, coor_q, f_q, coor, f)
+        coor = coor_q
+        f = self._edge_conv(self.layer3, coor, f, coor, f)
+        coor_q, f_q = self.fps_downsample(coor, f, 128)
+        f = self._edge_conv(self.layer4, coor_q, f_q, coor, f)                           # [B,128,128]
+        n4 = f.shape[1]
+        c0, bn, c3 = self.increase_dim[0], self.increase_dim[1], self.increase_dim[3]
+        h = F.leaky_relu(_bn_rows(bn, _linear(f.reshape(B * n4, -1), c0.weight[:, :, 0], c0.bias)), 0.2)
+        h = _linear(h, c3.weight[:, :, 0], c3.bias).view(B, n4, -1)
+        feature_global = h.max(dim=1)[0]                                                 # [B,1024]
+        l0, l2 = self.coarse_pred[0], self.coarse_pred[2]
+        coarse = _linear(torch.relu(_linear(feature_global, l0.weight, l0.bias)), l2.weight, l2.bias).reshape(-1, self.num_coarse, 3)
+        if self.num_coarse == 224:
+            idx = ops.fps_indices(x.contiguous().float(), 224).long()
+            inp_sparse = torch.gather(x, 1, idx[..., None].expand(-1, -1, 3))
+            return (coarse.contiguous(), torch.cat([coarse, inp_sparse], dim=1).contiguous()), feature_global
+        return coarse.contiguous(), feature_global

@@ -23,8 +23,8 @@ def _make_encoder(config, enc_type):
         return VN_PCTransformer(in_chans=3, embed_dim=384, depth=[6, 8], drop_rate=0., num_query=224, knn_layer=1,
                                 dgcnn="vn_dgcnn", trans="vn_trans", memory_profile=False, only_coarse=True)
     if enc_type == "dgcnn_fps":
-        raise NotImplementedError("enc_type 'dgcnn_fps' (non-equivariant baseline) is outside the VN hot path "
-                                  "(SURVEY.md §8f rank 4)")
+        from .baselines import DGCNN_fps
+        return DGCNN_fps(config, latent_dim=1024, grid_size=4, only_coarse=config.only_coarse)
     raise Exception(f"encoder type {enc_type} not supported yet")          # models/model.py:20-21,26
 
 
@@ -35,8 +35,8 @@ def _make_decoder(config, dec_type, enc_type):
         from .attention_decoder import Attention_VN_FoldingNet
         return Attention_VN_FoldingNet(config)
     if dec_type == "foldingnet":
-        raise NotImplementedError("dec_type 'foldingnet' (non-equivariant baseline) is outside the VN hot path "
-                                  "(SURVEY.md §8f rank 4)")
+        from .baselines import FoldingNet
+        return FoldingNet(config)
     raise Exception(f"encoder type {enc_type} not supported yet")          # sic, models/model.py:48
 
 
