@@ -149,3 +149,36 @@ def test_split_planes_reconstruct_exactly():
     assert torch.equal(ops.gemm(A, eye_n), A)                                   # A K-contiguous
     assert torch.equal(ops.gemm(eye_m, A, op_b=1), A)                           # B row-contiguous (transposed staging)
     assert torch.equal(ops.gemm(A, eye_m, op_a=1, op_b=1, nsplit=1), A.t())     # A row-contiguous
+
+
+@pytest.mark.parametrize("M,K", [(200, 37), (2048, 3), (100, 32), (192, 33), (7, 3)])
+def test_split_exact_on_ragged_shapes(M, K):
+    """The generic (bounds-checked, unaligned) loaders of the split kernel stage all three planes too: A * I returns A bit
+    for bit in every operand layout, for K that is not a multiple of the 32-wide K tile or of the 16-byte vector width."""
+    from vn_pointcloudcompletion_amd import ops, _lib
+    _lib.set_gemm_mode("split")
+    g = torch.Generator().manual_seed(M + K)
+    A = ((torch.rand(M, K, generator=g) * 2 - 1) * torch.exp2(torch.randint(-8, 9, (M, K), generator=g).float())).cuda()
+    eye = torch.eye(K, device="cuda")
+    assert torch.equal(ops.gemm(A, eye), A)
+    assert torch.equal(ops.gemm(A, eye, op_b=1), A)
+    assert torch.equal(ops.gemm(A.t().contiguous(), eye, op_a=1, op_b=1, nsplit=1), A)
+
+
+@pytest.mark.parametrize("K,rho", [(512, 1e-2), (512, 1e-3), (6144, 1e-3)])
+def test_common_mode_rows_keep_their_differences(K, rho):
+    """Rows that are one common vector plus a small per-row variation (what follows a batch-statistics normalisation with a
+    dominant common mode): the accuracy that matters downstream is that of the row-to-row DIFFERENCES of the product.  The
+    split kernel must resolve them as well as the fp32-input MFMA does."""
+    from vn_pointcloudcompletion_amd import ops, _lib
+    g = torch.Generator().manual_seed(K)
+    A = (torch.relu(torch.randn(1, K, generator=g)) + rho * torch.randn(2048, K, generator=g)).cuda()
+    B = (torch.randn(512, K, generator=g) / K ** 0.5).cuda()
+    ref = A.double() @ B.double().t()
+    refc = ref - ref.mean(0, keepdim=True)
+    err = {}
+    for mode in ("fp32", "split"):
+        _lib.set_gemm_mode(mode)
+        c = ops.gemm(A, B).double()
+        err[mode] = ((c - c.mean(0, keepdim=True) - refc).norm() / refc.norm()).item()
+    assert err["split"] <= 1.25 * err["fp32"], err
