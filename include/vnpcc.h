@@ -160,6 +160,10 @@ int vnp_fold_bwd(hipStream_t st, const float* g, int ldg, const float* seed, int
  * call sites models/dgcnn.py:11,210-218,236,257-259, models/pcn.py:6-9).  Point-major clouds [B,N,D].
  * knn: k nearest (squared L2) of each query among ref, sorted by (distance, index); idx [B][Nq][k] local indices. */
 int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k, int* idx, float* dist);
+/* same contract and bits as vnp_knn for large D (feature-space graphs): distance matrix once (ws: B*Nq*Nr floats), then a
+ * per-row selection; Nr <= 16384 */
+int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k, int* idx, float* dist,
+                   float* ws);
 /* furthest_point_sample: starts at index 0, ties to the lowest index; idx [B][M]; N <= 16384 */
 int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx);
 /* rows layout: out point i <- x point src[i] (gather_operation); and its adjoint gx[src[i]] += g[i] (gx zeroed here) */

@@ -124,3 +124,37 @@ def test_pcnnet_dgcnn_foldingnet_end_to_end(D):
         coarse, fine = net(t(D["x"]))
     assert fine.shape == (2, 512, 3)
     assert (fine.cpu() - torch.as_tensor(D["fine"])).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("Dm,Nr,Nq,k", [(12, 130, 130, 8), (96, 512, 512, 16), (192, 70, 33, 5), (33, 1000, 257, 20), (384, 256, 256, 16)])
+def test_knn_matrix_path_equals_per_query_kernel(lib_built, Dm, Nr, Nq, k):
+    """Feature-space graphs go through vnp_knn_matrix (distance matrix once + per-row selection): indices and distances are
+    bit-identical to the one-thread-per-query kernel vnp_knn (same fmaf chain per entry, same (distance, index) order)."""
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(Dm + Nr)
+    r, q = torch.randn(2, Nr, Dm, generator=g).cuda(), torch.randn(2, Nq, Dm, generator=g).cuda()
+    r[:, 5] = r[:, 3]                                               # exact duplicates: ties
+    out = []
+    for matrix in (False, True):
+        idx = torch.empty(2, Nq, k, device="cuda", dtype=torch.int32)
+        dist = torch.empty(2, Nq, k, device="cuda")
+        if matrix:
+            ws = torch.empty(2 * Nq * Nr, device="cuda")
+            call("vnp_knn_matrix", 2, Dm, ptr(r), Nr, ptr(q), Nq, k, ptr(idx), ptr(dist), ptr(ws))
+        elif Dm <= 320:
+            call("vnp_knn", 2, Dm, ptr(r), Nr, ptr(q), Nq, k, ptr(idx), ptr(dist))
+        else:
+            continue                                                 # the per-query kernel stops at D = 320 (LDS)
+        out.append((idx, dist))
+    if len(out) == 2:
+        assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1].view(torch.int32), out[1][1].view(torch.int32))
+    # and it IS the k-nearest set in ascending order (checked in fp64; robust to the summation order over D, which at D = 384
+    # legitimately reorders neighbours whose distances agree to 1e-7)
+    idx, dist = out[-1]
+    d64 = ((q.double()[:, :, None] - r.double()[:, None]) ** 2).sum(-1)                       # [2,Nq,Nr]
+    mine = d64.gather(2, idx.long())
+    assert (mine[..., 1:] >= mine[..., :-1] * (1 - 1e-6)).all()
+    assert torch.allclose(dist.double(), mine, rtol=1e-5)
+    kth = d64.sort(dim=-1)[0][..., k - 1]
+    assert (mine[..., -1] <= kth * (1 + 1e-6)).all()
+    assert all(len(set(row.tolist())) == k for row in idx[0, :8].cpu())

@@ -183,3 +183,13 @@ def test_linear_pool_fused_epilogue_equals_unfused(lib_built, G, gs, C, K):
     # the ties really occurred and were resolved to the lower index
     i0 = res[True][1][0]
     assert (i0 != gs // 2).all() and (i0 != gs - 1).all()
+
+
+@pytest.mark.parametrize("nb,n,W", [(3, 1248, 40), (2, 2048, 64), (2, 1031, 16), (1, 7, 5), (4, 4992, 24)])
+def test_reduce_rows_any_count(lib_built, nb, n, W):
+    """Partial-sum reduction for counts that are not multiples of 256 (config 5 folds 1248 coarse points) and for primes."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(n)
+    part = torch.randn(nb, n, W, generator=g).cuda()
+    out = ops.reduce_rows(part, nb, n, W)
+    assert relerr(out, part.double().sum(1)) < 1e-6

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "vnp_fold_fwd": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i],
     "vnp_fold_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "vnp_knn": [_i, _i, _vp, _i, _vp, _i, _i, _vp, _vp],
+    "vnp_knn_matrix": [_i, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp],
     "vnp_fps": [_i, _i, _vp, _i, _vp],
     "vnp_gather_points": [_vp, _i, _vp, _ll, _i, _vp, _i],
     "vnp_scatter_add_points": [_vp, _i, _vp, _ll, _i, _vp, _i, _ll],

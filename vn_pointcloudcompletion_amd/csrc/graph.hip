@@ -58,6 +58,112 @@ __global__ void __launch_bounds__(KNN_THREADS) vnp_knn_kernel(const float* __res
     }
 }
 
+// Feature-space graphs (D = 3*C up to a few hundred; VN-DGCNN / VN-PoinTr build them in every edge-conv layer): the
+// one-thread-per-query kernel above recomputes every distance in each of its k passes with the query vector in LDS, which
+// at D = 192, N = 2048 costs 60 ms per call.  Instead: (1) the distance matrix is formed once, tiled like an SGEMM on the
+// VALU — a 256-thread block owns a 64 x 64 tile, each thread a 4 x 4 block, both operands staged d-major in LDS so a thread
+// reads them as two float4 — with the SAME arithmetic per entry (dd = fmaf(r - q, r - q, dd), d ascending), (2) one wave per
+// query row then does the k selection passes over the 8-64 KB row in LDS.  Same indices and distances, bit for bit.
+#define KD_T 64
+#define KD_DC 32
+__global__ void __launch_bounds__(256) vnp_knn_dist_kernel(const float* __restrict__ ref, int Nr, const float* __restrict__ qry, int Nq,
+                                                          int D, float* __restrict__ dist)
+{
+    __shared__ __attribute__((aligned(16))) float qs[KD_DC][KD_T + 4], rs[KD_DC][KD_T + 4];
+    const int b = blockIdx.z, q0 = blockIdx.y * KD_T, r0 = blockIdx.x * KD_T;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const float* qb = qry + (size_t)b * Nq * D;
+    const float* rb = ref + (size_t)b * Nr * D;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int row = tid >> 2, dc = (tid & 3) * 8;
+    for (int d0 = 0; d0 < D; d0 += KD_DC) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = d0 + dc + e;
+            // rows / dims outside the problem are zero on BOTH sides: they add fmaf(0, 0, dd) = dd, i.e. nothing
+            qs[dc + e][row] = (q0 + row < Nq && d < D) ? qb[(size_t)(q0 + row) * D + d] : 0.f;
+            rs[dc + e][row] = (r0 + row < Nr && d < D) ? rb[(size_t)(r0 + row) * D + d] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int dd = 0; dd < KD_DC; ++dd) {
+            const float4 qv = *(const float4*)&qs[dd][4 * ty];
+            const float4 rv = *(const float4*)&rs[dd][4 * tx];
+            const float q4[4] = {qv.x, qv.y, qv.z, qv.w}, r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float t = r4[j] - q4[i]; acc[i][j] = fmaf(t, t, acc[i][j]); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = q0 + 4 * ty + i;
+        if (q >= Nq) continue;
+        float* drow = dist + ((size_t)b * Nq + q) * Nr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + 4 * tx + j;
+            if (r < Nr) drow[r] = acc[i][j];
+        }
+    }
+}
+
+// one wave per query row of the distance matrix: k passes, pass p takes the smallest (d, idx) pair lexicographically greater
+// than the pair of pass p-1 (exact ties, ascending (distance, index) order)
+__global__ void __launch_bounds__(64) vnp_knn_select_kernel(const float* __restrict__ dist, int Nr, int k, int* __restrict__ idx_out,
+                                                           float* __restrict__ dist_out)
+{
+    extern __shared__ float srow[];
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* d = dist + row * Nr;
+    for (int i = lane; i < Nr; i += 64) srow[i] = d[i];
+    __syncthreads();
+    float last_d = -1.f; int last_i = -1;
+    for (int p = 0; p < k; ++p) {
+        float best = INFINITY; int bi = 0x7fffffff;
+        for (int i = lane; i < Nr; i += 64) {
+            const float dd = srow[i];
+            const bool after = dd > last_d || (dd == last_d && i > last_i);
+            if (after && (dd < best || (dd == best && i < bi))) { best = dd; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        last_d = best; last_i = bi;
+        if (lane == 0) {
+            idx_out[row * k + p] = bi == 0x7fffffff ? 0 : bi;
+            if (dist_out) dist_out[row * k + p] = best;
+        }
+    }
+}
+
+// Same contract as vnp_knn with a caller-provided distance matrix: ws of B*Nq*Nr floats.  Any D; Nr <= 16384.
+extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k,
+                              int* idx, float* dist, float* ws)
+{
+    if (!ref || !qry || !idx || !ws || B <= 0 || D <= 0 || Nr <= 0 || Nq <= 0 || k <= 0 || k > Nr || B > 65535 || Nr > 16384) return VNP_EINVAL;
+    if (vnp_cdiv(Nq, KD_T) > 65535 || (long long)B * Nq > 2147483647LL) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_knn_dist_kernel, dim3(vnp_cdiv(Nr, KD_T), vnp_cdiv(Nq, KD_T), B), dim3(256), 0, st, ref, Nr, qry, Nq, D, ws);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)vnp_knn_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(vnp_knn_select_kernel, dim3((unsigned)((long long)B * Nq)), dim3(64), (size_t)Nr * 4, st,
+                       (const float*)ws, Nr, k, idx, dist);
+    return vnp_last_error();
+}
+
 // idx [B][Nq][k] (indices local to the sample), dist (optional) squared distances.  k <= Nr.
 extern "C" int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k,
                        int* idx, float* dist)

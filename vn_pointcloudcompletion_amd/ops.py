@@ -96,13 +96,14 @@ def reduce_rows(part, nb, n, W):
     walks more than a few hundred partials)."""
     dev = part.device
     if n > 1024:
-        m = 256
-        n1 = (n + m - 1) // m
-        if n % m:
-            raise _lib.VnpError("reduce_rows: large partial counts must be a multiple of 256")
-        tmp = torch.empty((nb, n1, W), device=dev, dtype=torch.float32)
-        call("vnp_reduce_rows", ptr(part), nb * n1, m * W, m, W, W, ptr(tmp), W)
-        part, n = tmp, n1
+        # first level over chunks of m partials, m the largest divisor of n in [16, 512] (n = 1248 -> 416); a count without
+        # such a divisor (a large prime) is reduced in one level, which is only slower
+        m = next((d for d in range(512, 15, -1) if n % d == 0), 0)
+        if m:
+            n1 = n // m
+            tmp = torch.empty((nb, n1, W), device=dev, dtype=torch.float32)
+            call("vnp_reduce_rows", ptr(part), nb * n1, m * W, m, W, W, ptr(tmp), W)
+            part, n = tmp, n1
     out = torch.empty((nb, W), device=dev, dtype=torch.float32)
     call("vnp_reduce_rows", ptr(part), nb, n * W, n, W, W, ptr(out), W)
     return out
@@ -728,7 +729,12 @@ def knn_indices(ref, query, k, return_dist=False):
     Nq = query.shape[1]
     idx = torch.empty((B, Nq, k), device=ref.device, dtype=torch.int32)
     dist = torch.empty((B, Nq, k), device=ref.device, dtype=torch.float32) if return_dist else None
-    call("vnp_knn", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist))
+    if D > 3 and Nr <= 16384 and B * Nq * Nr <= (1 << 29):
+        # feature-space graph: distance matrix once + per-row selection (same bits as vnp_knn, ~50x faster at D = 192)
+        ws = torch.empty(B * Nq * Nr, device=ref.device, dtype=torch.float32)
+        call("vnp_knn_matrix", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist), ptr(ws))
+    else:
+        call("vnp_knn", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist))
     return (idx, dist) if return_dist else idx
 
 
