@@ -36,7 +36,7 @@ int vnp_chamfer_fwd(hipStream_t st, int B, int n, const float* xyz1, int m, cons
 int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                     const float* grad_dist1, const int* idx1, const float* grad_dist2, const int* idx2,
                     float* grad_xyz1, float* grad_xyz2);
-/* Same outputs as vnp_chamfer_fwd, bit for bit, by a pruned exact search for dense clouds (n, m <= 16384): both clouds are
+/* Same outputs as vnp_chamfer_fwd, bit for bit, by a pruned exact search for dense clouds (n, m <= 32768): both clouds are
  * Morton-sorted into 64-point chunks with bounding boxes and a wave of 256 queries skips every chunk that cannot hold a
  * nearest neighbour for any of them.  ws: vnp_chamfer_pruned_ws_bytes(B, n, m) bytes (0 = sizes not supported). */
 long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m);

@@ -168,7 +168,7 @@ _CLOUDS = {
 
 @pytest.mark.parametrize("qa,qb", [("uniform", "uniform"), ("surface", "surface"), ("blob", "uniform"), ("uniform", "blob"),
                                    ("lattice", "lattice"), ("line", "surface"), ("huge", "huge"), ("blob", "blob")])
-@pytest.mark.parametrize("B,n,m", [(2, 4096, 4096), (1, 16384, 14336), (3, 5000, 4097)])
+@pytest.mark.parametrize("B,n,m", [(2, 4096, 4096), (1, 16384, 14336), (3, 5000, 4097), (1, 19968, 32768)])
 def test_pruned_equals_brute_force_bits(lib_built, qa, qb, B, n, m):
     g = torch.Generator().manual_seed(n + m + len(qa) * 7 + len(qb))
     a, b = _CLOUDS[qa](g, B, n).cuda().contiguous(), _CLOUDS[qb](g, B, m).cuda().contiguous()

@@ -126,7 +126,7 @@ static int vnp_chamfer_one_direction(hipStream_t st, int B, int n, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Pruned exact search (dense clouds, n, m <= 16384): same outputs, bit for bit, as the brute-force kernel above.
+// Pruned exact search (dense clouds, n, m <= 32768): same outputs, bit for bit, as the brute-force kernel above.
 //
 // Each cloud is binned along a Morton curve once per call (vnp_chamfer_bin_kernel: one workgroup per sample, a counting
 // sort on 15-bit keys — 5 bits per axis of the cloud's bounding box — with the 32768 counters in LDS) and cut into chunks
@@ -145,7 +145,7 @@ static int vnp_chamfer_one_direction(hipStream_t st, int B, int n, const float* 
 // A visited chunk is staged in LDS (1 KB) and read back as broadcast ds_read_b128, as in the brute-force kernel.
 #define CHP_CHUNK 64
 #define CHP_QPT 1
-#define CHP_MAXN 16384
+#define CHP_MAXN 32768
 #define CHP_BINS 32768
 
 __device__ __forceinline__ unsigned vnp_morton_spread5(unsigned v)
@@ -397,7 +397,7 @@ extern "C" long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m)
     return 16LL * B * ((long long)n + m) + 32LL * B * (c1 + c2) + 256;
 }
 
-// Same contract as vnp_chamfer_fwd, by the pruned search.  n, m <= 16384; ws of vnp_chamfer_pruned_ws_bytes(B, n, m) bytes.
+// Same contract as vnp_chamfer_fwd, by the pruned search.  n, m <= 32768; ws of vnp_chamfer_pruned_ws_bytes(B, n, m) bytes.
 extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                                       float* dist1, int* idx1, float* dist2, int* idx2, void* ws)
 {
