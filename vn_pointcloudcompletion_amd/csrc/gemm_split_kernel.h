@@ -367,7 +367,10 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                         float v = acc[i][j][e];
                         if (brow) v += brow[col];
                         if (p.accumulate) v += drow[col];
-                        drow[col] = v;
+                        // activation-sized outputs are streamed (non-temporal: they do not fit any cache and would only evict the
+                        // A / B panels); split-K slabs are re-read at once by the slab reduction and stay cached
+                        if (p.nsplit == 1) __builtin_nontemporal_store(v, &drow[col]);
+                        else drow[col] = v;
                     }
                 }
             }

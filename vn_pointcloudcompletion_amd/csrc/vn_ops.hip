@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __rest
     if (c < C) {
         for (long long pt = p0 + py; pt < p1; pt += 4) {
             const float* r = p + (size_t)pt * 3 * ld + c;
-            const float n = sqrtf(vnp_sq3(r[0], r[ld], r[2 * ld])) + VNP_EPS;
+            const float n = sqrtf(vnp_sq3(__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + ld), __builtin_nontemporal_load(r + 2 * ld))) + VNP_EPS;
             ++k;
             const float delta = n - mean;
             mean += delta / (float)k;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
         }
         if (d) {
             const float* rd = d + (size_t)pt * 3 * ldd + c;
-            const float d0 = rd[0], d1 = rd[ldd], d2 = rd[2 * ldd];
+            const float d0 = __builtin_nontemporal_load(rd), d1 = __builtin_nontemporal_load(rd + ldd), d2 = __builtin_nontemporal_load(rd + 2 * ldd);
             const float dot = q0 * d0 + q1 * d1 + q2 * d2;
             if (dot < 0.f) {
                 const float a = (1.f - ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
@@ -136,12 +136,13 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
             }
         }
         float* o = out + (size_t)pt * 3 * ldo + c;
-        o[0] = q0; o[ldo] = q1; o[2 * ldo] = q2;
+        __builtin_nontemporal_store(q0, o); __builtin_nontemporal_store(q1, o + ldo); __builtin_nontemporal_store(q2, o + 2 * ldo);
     }
 }
 
 // (Measured: giving every lane 4 consecutive channels (dwordx4) does not speed these HBM-bound passes up: 1.71 -> 1.79 ms
-// for bwd2; they run at ~4.5 TB/s of mixed read/write traffic either way.)
+// for bwd2.  Non-temporal loads and stores do: these tensors are streamed once per kernel and do not fit any cache —
+// bwd1 3.05 -> 2.73 ms, bwd2 1.71 -> 1.50 ms, forward 0.81 -> 0.74 ms per step.)
 // Backward, phase 1.  Upstream gradient go is either a matrix [P*3, ldgo] or (go == nullptr) the rank-1 form
 // go[r][c] = go_row[r] * go_col[c] (gradient of the final VNLinear(C->1), models/pcn.py:346).
 // Writes gq = dL/dq (q = bn(p)) and gd = dL/dd, and the per-chunk partial sums S1 = sum g_nhat, S2 = sum g_nhat*xhat
@@ -168,11 +169,11 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
         if (!go) gc = go_col[c];
         for (long long pt = p0 + py; pt < p1; pt += 4) {
             const float* r = p + (size_t)pt * 3 * ldp + c;
-            const float x0 = r[0], x1 = r[ldp], x2 = r[2 * ldp];
+            const float x0 = __builtin_nontemporal_load(r), x1 = __builtin_nontemporal_load(r + ldp), x2 = __builtin_nontemporal_load(r + 2 * ldp);
             float g0, g1, g2;
             if (go) {
                 const float* rg = go + (size_t)pt * 3 * ldgo + c;
-                g0 = rg[0]; g1 = rg[ldgo]; g2 = rg[2 * ldgo];
+                g0 = __builtin_nontemporal_load(rg); g1 = __builtin_nontemporal_load(rg + ldgo); g2 = __builtin_nontemporal_load(rg + 2 * ldgo);
             } else {
                 g0 = go_row[pt * 3] * gc; g1 = go_row[pt * 3 + 1] * gc; g2 = go_row[pt * 3 + 2] * gc;
             }
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
             const float q0 = x0 * s, q1 = x1 * s, q2 = x2 * s;
             if (d) {
                 const float* rd = d + (size_t)pt * 3 * ldd + c;
-                const float d0 = rd[0], d1 = rd[ldd], d2 = rd[2 * ldd];
+                const float d0 = __builtin_nontemporal_load(rd), d1 = __builtin_nontemporal_load(rd + ldd), d2 = __builtin_nontemporal_load(rd + 2 * ldd);
                 const float dot = q0 * d0 + q1 * d1 + q2 * d2;
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f;
                 if (gw_partial) {
@@ -211,10 +212,10 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                     g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;
                 }
                 float* wd = gd + (size_t)pt * 3 * ldgd + c;
-                wd[0] = e0; wd[ldgd] = e1; wd[2 * ldgd] = e2;
+                __builtin_nontemporal_store(e0, wd); __builtin_nontemporal_store(e1, wd + ldgd); __builtin_nontemporal_store(e2, wd + 2 * ldgd);
             }
             float* wq = gq + (size_t)pt * 3 * ldgq + c;
-            wq[0] = g0; wq[ldgq] = g1; wq[2 * ldgq] = g2;
+            __builtin_nontemporal_store(g0, wq); __builtin_nontemporal_store(g1, wq + ldgq); __builtin_nontemporal_store(g2, wq + 2 * ldgq);
             if (mean) {
                 const float gnh = (g0 * x0 + g1 * x1 + g2 * x2) / n;     // dL/dnhat = (gq . p) / n
                 s1 += gnh; s2 += gnh * xh;
@@ -249,11 +250,11 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_rowdot_kernel(const float* _
     const float* rd = d + (size_t)pt * 3 * ldd;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int c = lane; c < C; c += 64) {
-        float q0 = rp[c], q1 = rp[ldp + c], q2 = rp[2 * ldp + c];
+        float q0 = __builtin_nontemporal_load(rp + c), q1 = __builtin_nontemporal_load(rp + ldp + c), q2 = __builtin_nontemporal_load(rp + 2 * ldp + c);
         const float n = sqrtf(vnp_sq3(q0, q1, q2)) + VNP_EPS;
         const float s = ((n - mean[c]) * rstd[c] * gamma[c] + beta[c]) / n;
         q0 *= s; q1 *= s; q2 *= s;
-        const float d0 = rd[c], d1 = rd[ldd + c], d2 = rd[2 * ldd + c];
+        const float d0 = __builtin_nontemporal_load(rd + c), d1 = __builtin_nontemporal_load(rd + ldd + c), d2 = __builtin_nontemporal_load(rd + 2 * ldd + c);
         const float dot = q0 * d0 + q1 * d1 + q2 * d2;
         if (dot < 0.f) {
             const float al = (1.f - ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
@@ -288,9 +289,9 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
     const float m1 = S ? S[2 * c] * inv_count : 0.f, m2 = S ? S[2 * c + 1] * inv_count : 0.f;
     for (long long pt = p0 + py; pt < p1; pt += 4) {
         const float* r = p + (size_t)pt * 3 * ldp + c;
-        const float x0 = r[0], x1 = r[ldp], x2 = r[2 * ldp];
+        const float x0 = __builtin_nontemporal_load(r), x1 = __builtin_nontemporal_load(r + ldp), x2 = __builtin_nontemporal_load(r + 2 * ldp);
         float* rg = g + (size_t)pt * 3 * ldg + c;
-        const float g0 = rg[0], g1 = rg[ldg], g2 = rg[2 * ldg];
+        const float g0 = __builtin_nontemporal_load(rg), g1 = __builtin_nontemporal_load(rg + ldg), g2 = __builtin_nontemporal_load(rg + 2 * ldg);
         const float pn = sqrtf(vnp_sq3(x0, x1, x2));
         const float n = pn + VNP_EPS;
         const float xh = (n - mu) * rs;
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
         const float gnh = gs / n;
         const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
         const float k = pn > 0.f ? gn / pn : 0.f;
-        rg[0] = s * g0 + k * x0; rg[ldg] = s * g1 + k * x1; rg[2 * ldg] = s * g2 + k * x2;
+        __builtin_nontemporal_store(s * g0 + k * x0, rg); __builtin_nontemporal_store(s * g1 + k * x1, rg + ldg); __builtin_nontemporal_store(s * g2 + k * x2, rg + 2 * ldg);
     }
 }
 
@@ -506,7 +507,7 @@ __global__ void __launch_bounds__(256) vnp_colsum_kernel(const float* __restrict
     float s = 0.f;
     if (c < C)
         for (long long r = r0 + py; r < r1; r += 4)
-            s += base[(size_t)r * row_stride + c] * (w ? w[(size_t)blockIdx.z * R + r] : 1.f);
+            s += __builtin_nontemporal_load(&base[(size_t)r * row_stride + c]) * (w ? w[(size_t)blockIdx.z * R + r] : 1.f);
     red[py][cx] = s;
     __syncthreads();
     if (py == 0 && c < C)
@@ -720,11 +721,11 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
                     const float al = (1.f - a.ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
                     o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
                 }
-                if (live) { a.out[row * a.ldo + j] = o0; a.out[(row + 1) * a.ldo + j] = o1; a.out[(row + 2) * a.ldo + j] = o2; }
+                if (live) { __builtin_nontemporal_store(o0, &a.out[row * a.ldo + j]); __builtin_nontemporal_store(o1, &a.out[(row + 1) * a.ldo + j]); __builtin_nontemporal_store(o2, &a.out[(row + 2) * a.ldo + j]); }
                 continue;
             }
             float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-            if (live) { g0 = a.go[row * a.ldgo + j]; g1 = a.go[(row + 1) * a.ldgo + j]; g2 = a.go[(row + 2) * a.ldgo + j]; }
+            if (live) { g0 = __builtin_nontemporal_load(&a.go[row * a.ldgo + j]); g1 = __builtin_nontemporal_load(&a.go[(row + 1) * a.ldgo + j]); g2 = __builtin_nontemporal_load(&a.go[(row + 2) * a.ldgo + j]); }
             float h0 = 0.f, h1 = 0.f, h2 = 0.f;                    // dL/dd
             if (dot < 0.f) {
                 const float cc = 1.f - a.ns;
