@@ -98,7 +98,7 @@ def main():
     model.train()
     D.broadcast_model(model)
     opt = FusedAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999))
-    overlap = world > 1 and os.environ.get("VNP_OVERLAP_ALLREDUCE", "1") != "0"
+    overlap = D.collectives_on() and os.environ.get("VNP_OVERLAP_ALLREDUCE", "1") != "0"
     if overlap:
         opt.enable_overlapped_allreduce()            # bucketed all-reduce overlapped with backward (distributed.py)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -208,7 +208,7 @@ def main():
                "config": {"workload": f"vn_pointnet+vn_foldingnet train step (fwd+2xCD-L1+bwd+allreduce+Adam), B={B}/GPU, "
                                       f"{N}->{Mc}->{Md} pts, fp32 (GEMM mode: {gemm_mode})", "global_batch": B * world,
                           "parallelism": f"dp{world}",
-                          "allreduce": "none" if world == 1 else ("32 MB buckets overlapped with backward" if overlap
+                          "allreduce": "none" if not D.collectives_on() else ("32 MB buckets overlapped with backward" if overlap
                                                                   else "one flat all-reduce after backward")},
                "points_per_s_per_gpu": value / world,
                "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
@@ -223,6 +223,7 @@ def main():
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out))
     D.barrier()
+    D.shutdown()
 
 
 if __name__ == "__main__":

@@ -138,3 +138,22 @@ def test_two_ranks_overlapped_allreduce_matches_manual_average(lib_built):
     for g in out[0][2]:
         err = (torch.as_tensor(g) - ref).abs().max().item()
         assert err < 1e-5 * scale, (err, scale)
+
+
+def test_rccl_code_path_with_one_forced_rank(lib_built):
+    """RCCL refuses two ranks on one device, so the real transport is exercised with ONE rank and VNP_FORCE_COLLECTIVES=1:
+    process-group creation with the nccl backend, weight broadcast, the bucketed ncclAvg all-reduces launched asynchronously
+    from the autograd hooks, barrier and scalar max — through bench.py itself, in a fresh process (small batch)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VNP_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "2", "--batch", "2",
+                        "--no-cpu-baseline", "--no-fp32-mode"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["config"]["allreduce"].startswith("32 MB buckets") and out["n_gpus"] == 1
+    assert out["value"] > 0 and all(v == v for v in out["loss"].values())          # finite losses

@@ -20,6 +20,16 @@ import torch
 import torch.distributed as dist
 
 
+# VNP_FORCE_COLLECTIVES=1: create the process group and issue every collective even when there is a single rank — the only way
+# to exercise the RCCL code path (communicator, ncclAvg, asynchronous all-reduce from autograd hooks) on a one-GPU box
+FORCE_COLLECTIVES = os.environ.get("VNP_FORCE_COLLECTIVES") == "1"
+
+
+def collectives_on():
+    """True when gradient / scalar collectives have to be issued (more than one rank, or forced for testing)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
@@ -28,7 +38,7 @@ def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
     Returns (rank, local_rank, world_size).  A single process needs no group."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -48,8 +58,14 @@ def get_rank():
 
 
 def barrier():
-    if world_size() > 1:
+    if collectives_on():
         dist.barrier()
+
+
+def shutdown():
+    """Destroy the process group (if any) before the interpreter exits."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def shard_batch(global_batch: int):
@@ -62,14 +78,14 @@ def shard_batch(global_batch: int):
 
 
 def broadcast_tensors(tensors, src=0):
-    if world_size() > 1:
+    if collectives_on():
         for t in tensors:
             dist.broadcast(t, src=src)
 
 
 def broadcast_model(model, src=0):
     """Make every replica start from rank `src`'s parameters and buffers."""
-    if world_size() > 1:
+    if collectives_on():
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=src)
@@ -78,7 +94,7 @@ def broadcast_model(model, src=0):
 def allreduce_mean_(flat: torch.Tensor):
     """In-place average of a flat buffer over all ranks (RCCL ncclAvg; SUM + scale on gloo)."""
     w = world_size()
-    if w == 1:
+    if not collectives_on():
         return flat
     if dist.get_backend() == "nccl":
         dist.all_reduce(flat, op=dist.ReduceOp.AVG)
@@ -151,7 +167,7 @@ class OverlappedGradReducer:
         self.launched = b + 1
 
     def _hook(self, p):
-        if world_size() == 1:
+        if not collectives_on():
             return
         b = self.bucket_of[id(p)]
         if id(p) in self.fired:
@@ -174,7 +190,7 @@ class OverlappedGradReducer:
 
     def finish(self):
         """Call after backward: send the remaining buckets, wait for all of them, re-arm for the next step."""
-        if world_size() > 1:
+        if collectives_on():
             if self.late:
                 self._begin()
                 raise RuntimeError("a parameter received its gradient after its bucket had been all-reduced: the set of "
@@ -207,7 +223,7 @@ def allreduce_gradients(optimizer_or_params):
         for r in reducers:
             r.finish()
         return
-    if world_size() == 1:
+    if not collectives_on():
         return
     flats = getattr(optimizer_or_params, "flat_buffers", None)
     if flats is not None:
@@ -221,7 +237,7 @@ def allreduce_gradients(optimizer_or_params):
 
 
 def allreduce_scalar_max(x: float) -> float:
-    if world_size() == 1:
+    if not collectives_on():
         return x
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([x], dtype=torch.float64, device=dev)

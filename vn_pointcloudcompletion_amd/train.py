@@ -98,7 +98,7 @@ def train(config, args):
     D.broadcast_model(model)
 
     optimizer = FusedAdam(model.parameters(), lr=config.lr, betas=(0.9, 0.999))
-    if world > 1 and os.environ.get("VNP_OVERLAP_ALLREDUCE", "1") != "0":
+    if D.collectives_on() and os.environ.get("VNP_OVERLAP_ALLREDUCE", "1") != "0":
         optimizer.enable_overlapped_allreduce()      # VNP_OVERLAP_ALLREDUCE=0: one all-reduce after backward instead
     start_epoch, best_cd_l1, best_epoch_l1 = 0, 1e8, -1
     if args.resume:
