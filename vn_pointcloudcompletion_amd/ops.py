@@ -74,7 +74,7 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
             tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
             nk = (K + 31) // 32
             if tiles < 256 and nk >= 8:
-                nsplit = max(1, min(nk // 4, 1024 // tiles))
+                nsplit = max(1, min(nk // 4, 512 // tiles))       # 512 = the persistent grid (2 workgroups x 256 CUs): one item each
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit, M, N), device=A.device, dtype=torch.float32)
