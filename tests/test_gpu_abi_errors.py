@@ -1,0 +1,47 @@
+"""Error behaviour of the C ABI (include/vnpcc.h): every entry point validates its arguments on the host and returns
+VNP_EINVAL (-1) instead of launching — the reference's extensions printf() and carry on (chamfer3D.cu:145-151).  Through
+_lib.call that is a VnpError.  Called with real device buffers so that only the argument under test is wrong."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rc(name, *args):
+    from vn_pointcloudcompletion_amd import _lib
+    return getattr(_lib.lib(), name)(torch.cuda.current_stream().cuda_stream, *args)
+
+
+def test_einval_instead_of_launching(lib_built):
+    from vn_pointcloudcompletion_amd._lib import ptr
+    f = lambda *s: torch.zeros(*s, device="cuda")
+    i = lambda *s: torch.zeros(*s, device="cuda", dtype=torch.int32)
+    a, b = f(2, 8, 3), f(2, 9, 3)
+    d1, d2, i1, i2, ws = f(2, 8), f(2, 9), i(2, 8), i(2, 9), torch.zeros(64, device="cuda", dtype=torch.int64)
+    # Chamfer: null pointer, non-positive sizes, batch beyond the grid limit
+    assert _rc("vnp_chamfer_fwd", 2, 8, None, 9, ptr(b), ptr(d1), ptr(i1), ptr(d2), ptr(i2), ptr(ws)) == -1
+    assert _rc("vnp_chamfer_fwd", 2, 0, ptr(a), 9, ptr(b), ptr(d1), ptr(i1), ptr(d2), ptr(i2), ptr(ws)) == -1
+    assert _rc("vnp_chamfer_fwd", 70000, 8, ptr(a), 9, ptr(b), ptr(d1), ptr(i1), ptr(d2), ptr(i2), ptr(ws)) == -1
+    assert _rc("vnp_chamfer_fwd_pruned", 2, 40000, ptr(a), 9, ptr(b), ptr(d1), ptr(i1), ptr(d2), ptr(i2), ptr(ws)) == -1   # > 32768 points
+    from vn_pointcloudcompletion_amd import _lib
+    assert _lib.lib().vnp_chamfer_pruned_ws_bytes(2, 40000, 9) == 0
+    # kNN: k larger than the reference cloud; FPS: more samples than points / more points than the kernel holds
+    idx = i(2, 8, 4)
+    assert _rc("vnp_knn", 2, 3, ptr(b), 9, ptr(a), 8, 10, ptr(idx), None) == -1
+    assert _rc("vnp_knn", 2, 400, ptr(b), 9, ptr(a), 8, 2, ptr(idx), None) == -1                # D beyond the per-query kernel's LDS
+    assert _rc("vnp_fps", 2, 8, ptr(a), 9, ptr(idx)) == -1
+    assert _rc("vnp_fps", 1, 20000, ptr(a), 4, ptr(idx)) == -1
+    # GEMM: missing operand, bias without a group size, split-K without scratch, unknown mode
+    A, B, C = f(8, 4), f(5, 4), f(8, 5)
+    assert _rc("vnp_gemm", 0, 0, 8, 5, 4, None, 4, ptr(B), 4, ptr(C), 5, None, 0, 0, 0, 1, None) == -1
+    assert _rc("vnp_gemm", 0, 0, 8, 5, 4, ptr(A), 4, ptr(B), 4, ptr(C), 5, ptr(C), 5, 0, 0, 1, None) == -1
+    assert _rc("vnp_gemm", 0, 0, 8, 5, 64, ptr(A), 4, ptr(B), 4, ptr(C), 5, None, 0, 0, 0, 2, None) == -1
+    assert _lib.lib().vnp_gemm_set_mode(7) == -1 and _lib.get_gemm_mode() in ("split", "fp32")
+    # fused linear + pool: shapes outside its tiling are refused (callers fall back to vnp_gemm + vnp_vn_pool_fwd)
+    assert _rc("vnp_linear_pool_fwd", ptr(A), 4, ptr(B), 4, 1, 30, 64, 32, ptr(idx), ptr(C), 64, ptr(ws)) == -1
+    # and the Python layer turns the status into an exception
+    with pytest.raises(_lib.VnpError):
+        _lib.call("vnp_fps", 2, 8, ptr(a), 9, ptr(idx))
+    torch.cuda.synchronize()                                    # nothing was launched, nothing faulted
