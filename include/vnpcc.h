@@ -53,7 +53,7 @@ int vnp_emd_matchcost(hipStream_t st, int B, int n, int m, const float* xyz1, co
 int vnp_emd_matchcost_bwd(hipStream_t st, int B, int n, int m, const float* grad_cost, const float* xyz1, const float* xyz2,
                           const float* match, float* grad1, float* grad2);
 
-/* ---- fp32 MFMA GEMM -----------------------------------------------------------------------------------------
+/* ---- fp32 GEMM on the matrix cores (MFMA) -----------------------------------------------------------------------
  * replaces the x.transpose(1,-1) -> nn.Linear -> transpose chains of models/vn_layers.py:21,36,65,69,162 and their
  * autograd.  C[M,N] (+)= op(A) op(B) (+ bias).
  *   op_a = 0: A is [M,K] row-major; 1: A is [K,M] row-major.   op_b = 0: B is [N,K] row-major; 1: B is [K,N].

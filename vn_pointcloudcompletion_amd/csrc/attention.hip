@@ -2,7 +2,7 @@
 //   VNLayerNorm (models/vn_layers.py:129-150)  : LayerNorm over the CHANNEL axis of the vector norms, per point
 //   rows <-> heads layout change               : [B*N*3, C] rows  <->  [B, H, N, (C/H)*3] tokens (transformer.py:91-93,103)
 //   row softmax forward / backward             : attn = softmax(q k^T * scale) (transformer.py:98-99)
-// The two attention matrix products run on the batched fp32-MFMA GEMM (vnp_gemm_batched).  All kernels are HBM-bound.
+// The two attention matrix products run on the batched GEMM (vnp_gemm_batched: fp32 results, see gemm.hip).  All kernels are HBM-bound.
 #include "vnp_common.h"
 
 #define LN_EPS 1e-5f

@@ -1,6 +1,6 @@
 // fp32 GEMM on the CDNA4 matrix cores.  Two kernels with the same tiling, arguments and results to fp32 rounding:
 //   * gemm_split_kernel.h (default): every operand is split exactly into three bf16 terms on its way into LDS and six
-//     v_mfma_f32_32x32x16_bf16 products are accumulated in fp32 — error vs fp64 at or below the fp32 kernel's
+//     v_mfma_f32_16x16x32_bf16 products are accumulated in fp32 — error vs fp64 at or below the fp32 kernel's
 //     (tests/test_gpu_gemm.py), 1.45-1.75x its speed;
 //   * gemm_kernel.h (vnp_gemm_set_mode(1) / VNP_GEMM_MODE=fp32): v_mfma_f32_32x32x2_f32, 157 TF/s peak.
 //

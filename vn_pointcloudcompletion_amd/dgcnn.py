@@ -1,5 +1,5 @@
 """VN-DGCNN encoder with FPS down-sampling: reference class name, constructor signature and ``state_dict`` keys
-(/root/reference/models/dgcnn.py:164-324), on libvnpcc kernels (kNN, FPS, gathers, fp32-MFMA GEMMs, VN pointwise).
+(/root/reference/models/dgcnn.py:164-324), on libvnpcc kernels (kNN, FPS, gathers, vnp_gemm GEMMs, VN pointwise).
 
 EdgeConv restructuring (same math): the reference builds the edge tensor cat(feature - x, x) of shape [B,2C,3,N,k]
 (dgcnn.py:250-278) and applies W to it; here u = x W1^T and v = x (W2 - W1)^T are computed once per point and the edge

@@ -837,7 +837,7 @@ def _from_heads(heads, B, N, C, H):
 
 class VNAttentionFn(Function):
     """softmax(q k^T * scale) v over tokens whose features are the flattened (C/H, 3) vectors of each head
-    (models/transformer.py:91-104).  q, k, v: rows [B*N*3, C].  The two matrix products are batched fp32-MFMA GEMMs."""
+    (models/transformer.py:91-104).  q, k, v: rows [B*N*3, C].  The two matrix products are batched vnp_gemm GEMMs (fp32 results; split-bf16 or fp32-input MFMA, see gemm.hip)."""
 
     @staticmethod
     def forward(ctx, q, k, v, B, N, H, scale):
