@@ -170,6 +170,19 @@ int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx);
 int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo);
 int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* src, long long Pout, int W,
                            float* gx, int ldgx, long long Pin);
+/* Fused EdgeConv: VNLinearLeakyReLU on the kNN edge tensor + mean over the k neighbours (models/dgcnn.py:250-278 and the
+ * conv1/4/5/6 blocks; VN-PoinTr grouper) without materialising the edge tensor: (p | d)(q, j) = u[nbr[q][j]] + v[q] is recomputed
+ * in each pass from the per-point matrices u = x W1^T, v = x (W2 - W1)^T (columns [feat | dir]).
+ * mode 0: Welford partials of |p| per block of vnp_edge_block_queries() queries -> vnp_vn_bn_finalize_chunked(chunk = 64 k);
+ * mode 1: out[q] = mean_j leaky(bn(p), d); mode 2: backward sums (dL/dbeta, dL/dgamma partials); mode 3: gv[q] = sum_j g(q, j),
+ * gu[nbr] += g(q, j) (atomics; gu zeroed here).  count = number of edges (Pq * k). */
+int vnp_edge_block_queries(void);
+int vnp_vn_bn_finalize_chunked(hipStream_t st, const float* partial, int nchunk, int chunk_points, int C, long long count,
+                               float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps);
+int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
+                   long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                   float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
+                   const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv);
 /* out[(p*k+j)*3+t][c] = u[nbr[p*k+j]*3+t][c] + v[p*3+t][c]: edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278)
  * with the layer's weights applied per point first (W [feat-x | x] = W1 feat + (W2-W1) x) */
 int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr,

@@ -158,3 +158,34 @@ def test_knn_matrix_path_equals_per_query_kernel(lib_built, Dm, Nr, Nq, k):
     kth = d64.sort(dim=-1)[0][..., k - 1]
     assert (mine[..., -1] <= kth * (1 + 1e-6)).all()
     assert all(len(set(row.tolist())) == k for row in idx[0, :8].cpu())
+
+
+@pytest.mark.parametrize("P,k,C,Pu", [(130, 16, 32, 130), (512, 20, 64, 512), (70, 8, 96, 200), (1000, 16, 128, 1000)])
+@pytest.mark.parametrize("training", [True, False])
+def test_edge_conv_fused_equals_unfused(lib_built, P, k, C, Pu, training):
+    """EdgeConv with the edge tensor recomputed inside each pass (ops.EdgeConvFn / vnp_edge_fused) against the materialising
+    chain EdgeGatherAddFn -> VNBnLeakyFn -> VNMeanPoolFn: outputs, all gradients and the BatchNorm running statistics."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(P + k + C)
+    u0 = torch.randn(Pu * 3, 2 * C, generator=g)
+    v0 = torch.randn(P * 3, 2 * C, generator=g)
+    nbr = torch.randint(0, Pu, (P, k), generator=g, dtype=torch.int32).cuda()
+    gam0, bet0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    gout = torch.randn(P * 3, C, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        u, v = u0.cuda().requires_grad_(True), v0.cuda().requires_grad_(True)
+        gam, bet = gam0.cuda().requires_grad_(True), bet0.cuda().requires_grad_(True)
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        if fused:
+            out = ops.EdgeConvFn.apply(u, v, nbr, gam, bet, rm, rv, training, 0.2)
+        else:
+            pd = ops.EdgeGatherAddFn.apply(u, v, nbr)
+            f = ops.VNBnLeakyFn.apply(pd, True, gam, bet, rm, rv, training, 0.2)
+            out = ops.VNMeanPoolFn.apply(f, P, k)
+        (out * gout).sum().backward()
+        res.append((out.detach(), u.grad, v.grad, gam.grad, bet.grad, rm, rv))
+    names = ("out", "gu", "gv", "ggamma", "gbeta", "running_mean", "running_var")
+    for name, a, b in zip(names, res[0], res[1]):
+        scale = b.abs().max().item() + 1e-12
+        assert (a - b).abs().max().item() <= 2e-5 * scale, (name, (a - b).abs().max().item(), scale)

@@ -94,6 +94,9 @@ _SIGNATURES = {
     "vnp_fps": [_i, _i, _vp, _i, _vp],
     "vnp_gather_points": [_vp, _i, _vp, _ll, _i, _vp, _i],
     "vnp_scatter_add_points": [_vp, _i, _vp, _ll, _i, _vp, _i, _ll],
+    "vnp_vn_bn_finalize_chunked": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _f, _f],
+    "vnp_edge_fused": [_i, _vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _ll, _vp, _i, _ll,
+                       _vp, _i],
     "vnp_edge_gather_add": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_fold_fused": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll,
                        _vp, _vp],
@@ -105,7 +108,7 @@ _SIGNATURES = {
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
-_NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
+_NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i]}
 _RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll}
 

@@ -62,8 +62,8 @@ __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __rest
 
 // mean / rstd per channel from the chunk partials (Chan merge in double), running-stat update as torch does
 // (momentum, unbiased variance for running_var).
-__global__ void __launch_bounds__(256) vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int C, long long count,
-                                                             float* __restrict__ mean, float* __restrict__ rstd,
+__global__ void __launch_bounds__(256) vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int chunk_points, int C,
+                                                             long long count, float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* running_mean, float* running_var, float momentum, float eps)
 {
     __shared__ double rn[4][64], rm[4][64], rM[4][64];
@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(256) vnp_bn_finalize_kernel(const float2* __re
     if (c < C) {
         for (int k = py; k < nchunk; k += 4) {
             const float2 v = partial[(size_t)k * C + c];
-            const long long left = count - (long long)k * VNP_CHUNK;
-            const double nb = (double)(left < VNP_CHUNK ? left : VNP_CHUNK);
+            const long long left = count - (long long)k * chunk_points;
+            const double nb = (double)(left < chunk_points ? left : chunk_points);
             if (na == 0.0) { na = nb; ma = v.x; Ma = v.y; }
             else vnp_chan_merge(na, ma, Ma, nb, (double)v.x, (double)v.y);
         }
@@ -832,6 +832,144 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
     return vnp_last_error();
 }
 
+// ------------------------------------------------------------------------------------------------ fused EdgeConv
+// VNLinearLeakyReLU on the kNN edge tensor + mean over the k neighbours (models/dgcnn.py:250-278 + conv1/4/5/6, the
+// VN-PoinTr grouper) WITHOUT the edge tensor.  After the layer's linear maps have been applied per point (u = x W1^T,
+// v = x (W2 - W1)^T, columns [feat | dir]) an edge's pre-activations are  (p | d)(q, j) = u[nbr[q][j]] + v[q];  they are
+// recomputed from the (L2-resident, k times smaller) per-point matrices in each of the four passes instead of being
+// written once and re-read eight times:
+//   MODE 0  norm statistics of p over all edges (Welford partial per block of 64 queries)
+//   MODE 1  out[q] = 1/k sum_j leaky(bn(p), d)(q, j)
+//   MODE 2  backward sums  S1 = sum g_nhat, S2 = sum g_nhat * xhat  (= dL/dbeta, dL/dgamma), upstream gradient go[q] / k per edge
+//   MODE 3  backward:  gv[q] = sum_j (dL/dp | dL/dd)(q, j)   and   gu[nbr[q][j]] += (dL/dp | dL/dd)(q, j)  (atomics)
+// The per-edge arithmetic is that of vnp_bn_leaky_fwd / bwd1 / bwd2 above, term for term.
+struct VnpEdgeArgs {
+    const float* u; int ldu; const float* v; int ldv; const int* nbr;
+    long long Pq; int k, C;
+    const float* mean; const float* rstd; const float* gamma; const float* beta; float ns;
+    float2* partial;                           // MODE 0 / 2 output: [nblock][C]
+    float* out; int ldo;                       // MODE 1
+    const float* go; int ldgo;                 // MODE 2 / 3
+    const float* sums; float inv_count;        // MODE 3 ([C][2]; nullptr in eval mode)
+    float* gu; int ldgu; float* gv; int ldgv;  // MODE 3
+};
+#define VNP_EDGE_QB 64                         // queries per block
+
+template <int MODE>
+__global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a)
+{
+    __shared__ float2 red[4][64];
+    __shared__ int cnt[4];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx, C = a.C, k = a.k;
+    const bool live = c < C;
+    const int cc = live ? c : 0;
+    const long long q0 = (long long)blockIdx.y * VNP_EDGE_QB;
+    const long long q1 = min(a.Pq, q0 + VNP_EDGE_QB);
+    float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, m1 = 0.f, m2 = 0.f;
+    if (MODE >= 1) { mu = a.mean[cc]; rs = a.rstd[cc]; ga = a.gamma[cc]; be = a.beta[cc]; }
+    if (MODE == 3 && a.sums) { m1 = a.sums[2 * cc] * a.inv_count; m2 = a.sums[2 * cc + 1] * a.inv_count; }
+    const float kf = (float)k;
+    float wmean = 0.f, wm2 = 0.f, s1 = 0.f, s2 = 0.f;
+    int wn = 0;
+    for (long long q = q0 + py; q < q1; q += 4) {
+        const float* rv = a.v + (size_t)q * 3 * a.ldv + cc;
+        const float vp0 = rv[0], vp1 = rv[a.ldv], vp2 = rv[2 * a.ldv];
+        const float vd0 = rv[C], vd1 = rv[a.ldv + C], vd2 = rv[2 * a.ldv + C];
+        float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f;
+        if (MODE >= 2) {
+            const float* rg = a.go + (size_t)q * 3 * a.ldgo + cc;
+            ge0 = rg[0] / kf; ge1 = rg[a.ldgo] / kf; ge2 = rg[2 * a.ldgo] / kf;           // vnp_mean_pool_bwd: g / gs
+        }
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f;                 // MODE 1: sum of outputs; MODE 3: gv (p | d)
+        const int* nb = a.nbr + (size_t)q * k;
+        for (int j = 0; j < k; ++j) {
+            const size_t urow = (size_t)nb[j] * 3;
+            const float* ru = a.u + urow * a.ldu + cc;
+            const float x0 = ru[0] + vp0, x1 = ru[a.ldu] + vp1, x2 = ru[2 * a.ldu] + vp2;
+            const float pn = sqrtf(vnp_sq3(x0, x1, x2));
+            const float n = pn + VNP_EPS;
+            if (MODE == 0) {
+                ++wn;
+                const float delta = n - wmean;
+                wmean += delta / (float)wn;
+                wm2 += delta * (n - wmean);
+                continue;
+            }
+            const float d0 = ru[C] + vd0, d1 = ru[a.ldu + C] + vd1, d2 = ru[2 * a.ldu + C] + vd2;
+            const float xh = (n - mu) * rs;
+            const float nh = xh * ga + be;
+            const float s = nh / n;
+            const float y0 = x0 * s, y1 = x1 * s, y2 = x2 * s;                             // q = bn(p)
+            const float dot = y0 * d0 + y1 * d1 + y2 * d2;
+            if (MODE == 1) {
+                float r0 = y0, r1 = y1, r2 = y2;
+                if (dot < 0.f) {
+                    const float al = (1.f - a.ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                    r0 -= al * d0; r1 -= al * d1; r2 -= al * d2;
+                }
+                o0 += r0; o1 += r1; o2 += r2;
+                continue;
+            }
+            float g0 = ge0, g1 = ge1, g2 = ge2, e0 = 0.f, e1 = 0.f, e2 = 0.f;
+            if (dot < 0.f) {
+                const float cf = 1.f - a.ns;
+                const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                const float al = dot * inv;
+                const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
+                const float k1 = cf * gdd * inv;
+                e0 = -cf * (al * g0 + gdd * (y0 * inv - 2.f * al * inv * d0));
+                e1 = -cf * (al * g1 + gdd * (y1 * inv - 2.f * al * inv * d1));
+                e2 = -cf * (al * g2 + gdd * (y2 * inv - 2.f * al * inv * d2));
+                g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;
+            }
+            const float gs = g0 * x0 + g1 * x1 + g2 * x2;
+            const float gnh = gs / n;
+            if (MODE == 2) { s1 += gnh; s2 += gnh * xh; continue; }
+            const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
+            const float kk = pn > 0.f ? gn / pn : 0.f;
+            const float f0 = s * g0 + kk * x0, f1 = s * g1 + kk * x1, f2 = s * g2 + kk * x2;   // dL/dp of this edge
+            o0 += f0; o1 += f1; o2 += f2; h0 += e0; h1 += e1; h2 += e2;
+            if (live) {
+                float* wu = a.gu + urow * a.ldgu + c;
+                atomicAdd(wu, f0); atomicAdd(wu + a.ldgu, f1); atomicAdd(wu + 2 * a.ldgu, f2);
+                atomicAdd(wu + C, e0); atomicAdd(wu + a.ldgu + C, e1); atomicAdd(wu + 2 * a.ldgu + C, e2);
+            }
+        }
+        if (MODE == 1 && live) {
+            float* w = a.out + (size_t)q * 3 * a.ldo + c;
+            w[0] = o0 / kf; w[a.ldo] = o1 / kf; w[2 * a.ldo] = o2 / kf;                    // vnp_mean_pool_fwd: s / gs
+        }
+        if (MODE == 3 && live) {
+            float* w = a.gv + (size_t)q * 3 * a.ldgv + c;
+            w[0] = o0; w[a.ldgv] = o1; w[2 * a.ldgv] = o2;
+            w[C] = h0; w[a.ldgv + C] = h1; w[2 * a.ldgv + C] = h2;
+        }
+    }
+    if (MODE == 0) {
+        red[py][cx] = make_float2(wmean, wm2);
+        if (cx == 0) cnt[py] = wn;
+        __syncthreads();
+        if (py == 0 && live) {
+            double na = cnt[0], ma = red[0][cx].x, Ma = red[0][cx].y;
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                if (na == 0.0) { na = cnt[j]; ma = red[j][cx].x; Ma = red[j][cx].y; }
+                else vnp_chan_merge(na, ma, Ma, (double)cnt[j], (double)red[j][cx].x, (double)red[j][cx].y);
+            }
+            a.partial[(size_t)blockIdx.y * C + c] = make_float2((float)ma, (float)Ma);
+        }
+    }
+    if (MODE == 2) {
+        red[py][cx] = make_float2(s1, s2);
+        __syncthreads();
+        if (py == 0 && live) {
+            const float2 r0 = red[0][cx], r1 = red[1][cx], r2 = red[2][cx], r3 = red[3][cx];
+            a.partial[(size_t)blockIdx.y * C + c] = make_float2((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y));
+        }
+    }
+}
+
 // ================================================================================================ C-ABI
 static inline dim3 vnp_grid_pc(long long P, int C) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, VNP_CHUNK)); }
 
@@ -846,7 +984,7 @@ extern "C" int vnp_vn_bn_finalize(hipStream_t st, const float* partial, int nchu
                                   float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps)
 {
     if (!partial || !mean || !rstd || C <= 0 || count <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(256), 0, st, (const float2*)partial, nchunk, C, count,
+    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(256), 0, st, (const float2*)partial, nchunk, VNP_CHUNK, C, count,
                        mean, rstd, running_mean, running_var, momentum, eps);
     return vnp_last_error();
 }
@@ -1058,5 +1196,65 @@ extern "C" int vnp_ref_to_rows(hipStream_t st, const float* ref, int B, int C, i
     if (!rows || !ref || B <= 0 || C <= 0 || N <= 0) return VNP_EINVAL;
     const long long total = (long long)B * C * 3 * N;
     hipLaunchKernelGGL(vnp_ref_to_rows_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st, ref, B, C, N, rows, ld);
+    return vnp_last_error();
+}
+
+// BatchNorm statistics from partials whose chunks hold `chunk_points` values each (the fused EdgeConv: 64 queries x k edges)
+extern "C" int vnp_vn_bn_finalize_chunked(hipStream_t st, const float* partial, int nchunk, int chunk_points, int C, long long count,
+                                          float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps)
+{
+    if (!partial || !mean || !rstd || C <= 0 || count <= 0 || chunk_points <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(256), 0, st, (const float2*)partial, nchunk, chunk_points, C, count,
+                       mean, rstd, running_mean, running_var, momentum, eps);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_edge_block_queries(void) { return VNP_EDGE_QB; }
+
+// Fused EdgeConv passes (see vnp_edge_fused_kernel).  u [Pu*3, ldu >= 2C], v [Pq*3, ldv >= 2C], nbr [Pq][k] ids < Pu.
+// mode 0: partial [ceil(Pq/64)][C][2].  mode 1: out [Pq*3, ldo].  mode 2: go, partial.  mode 3: go, sums ([C][2] or NULL), count =
+// number of edges, gu [Pu*3, ldgu >= 2C] (zeroed here), gv [Pq*3, ldgv >= 2C].
+extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
+                              long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
+                              const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv)
+{
+    if (!u || !v || !nbr || Pq <= 0 || k <= 0 || C <= 0 || mode < 0 || mode > 3) return VNP_EINVAL;
+    if (mode >= 1 && (!mean || !rstd || !gamma || !beta)) return VNP_EINVAL;
+    if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
+    if (mode == 1 && !out) return VNP_EINVAL;
+    if (mode >= 2 && !go) return VNP_EINVAL;
+    if (mode == 3 && (!gu || !gv || Pu <= 0)) return VNP_EINVAL;
+    const long long nblk = (Pq + VNP_EDGE_QB - 1) / VNP_EDGE_QB;
+    if (nblk > 65535LL * 32768LL) return VNP_EINVAL;
+    VnpEdgeArgs a;
+    a.u = u; a.ldu = ldu; a.v = v; a.ldv = ldv; a.nbr = nbr; a.Pq = Pq; a.k = k; a.C = C;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
+    a.partial = (float2*)partial; a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo;
+    a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f;
+    a.gu = gu; a.ldgu = ldgu; a.gv = gv; a.ldgv = ldgv;
+    if (mode == 3) {
+        hipError_t e = ldgu == 2 * C ? hipMemsetAsync(gu, 0, (size_t)Pu * 3 * ldgu * 4, st)
+                                     : hipMemset2DAsync(gu, (size_t)ldgu * 4, 0, (size_t)2 * C * 4, (size_t)Pu * 3, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    // gridDim.y <= 65535: slices of query blocks
+    for (long long b0 = 0; b0 < nblk; b0 += 65535) {
+        const int nb = (int)((nblk - b0) < 65535 ? (nblk - b0) : 65535);
+        VnpEdgeArgs s = a;
+        const long long qoff = b0 * VNP_EDGE_QB;
+        s.v = v + (size_t)qoff * 3 * ldv; s.nbr = nbr + (size_t)qoff * k; s.Pq = (Pq - qoff) < (long long)nb * VNP_EDGE_QB ? (Pq - qoff) : (long long)nb * VNP_EDGE_QB;
+        if (partial) s.partial = (float2*)partial + (size_t)b0 * C;
+        if (out) s.out = out + (size_t)qoff * 3 * ldo;
+        if (go) s.go = go + (size_t)qoff * 3 * ldgo;
+        if (gv) s.gv = gv + (size_t)qoff * 3 * ldgv;
+        const dim3 grid(vnp_cdiv(C, 64), nb), block(256);
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(vnp_edge_fused_kernel<0>, grid, block, 0, st, s); break;
+        case 1: hipLaunchKernelGGL(vnp_edge_fused_kernel<1>, grid, block, 0, st, s); break;
+        case 2: hipLaunchKernelGGL(vnp_edge_fused_kernel<2>, grid, block, 0, st, s); break;
+        default: hipLaunchKernelGGL(vnp_edge_fused_kernel<3>, grid, block, 0, st, s); break;
+        }
+    }
     return vnp_last_error();
 }

@@ -25,9 +25,13 @@ def edge_conv_rows(layer: VNLinearLeakyReLU, x_rows, nbr, k):
     Wv = torch.cat([Wf[:, C:] - Wf[:, :C], Wd[:, C:] - Wd[:, :C]], dim=0)
     u = ops.VNLinearFn.apply(x_rows, Wu, None, 0)
     v = ops.VNLinearFn.apply(x_rows, Wv, None, 0)
-    pd = ops.EdgeGatherAddFn.apply(u, v, nbr)                              # [P*k*3, 2C']
     bn = layer.batchnorm.bn
     layer.batchnorm._tick()
+    if ops.EDGE_FUSED:
+        # edge pre-activations u[nbr] + v recomputed inside each pass: the [P*k*3, 2C'] tensor is never written
+        return ops.EdgeConvFn.apply(u, v, nbr, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
+                                    layer.negative_slope)
+    pd = ops.EdgeGatherAddFn.apply(u, v, nbr)                              # [P*k*3, 2C']
     f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
                               layer.negative_slope)                         # [P*k*3, C']
     return ops.VNMeanPoolFn.apply(f, x_rows.shape[0] // 3, k)

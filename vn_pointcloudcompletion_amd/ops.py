@@ -23,6 +23,9 @@ BN_MOMENTUM = 0.1
 # VNLinearMaxPoolFn).  Set VNP_POOL_AS_WRITTEN=1 to keep the reference's evaluation order.
 import os as _os
 POOL_DIRECTION_REASSOCIATE = _os.environ.get("VNP_POOL_AS_WRITTEN", "0") != "1"
+# EdgeConv (configs 3, 5): recompute the edge pre-activations in every pass instead of materialising the k-times larger edge
+# tensor (EdgeConvFn); VNP_EDGE_UNFUSED=1 keeps gather-add -> BatchNorm/leaky -> mean-pool as separate kernels
+EDGE_FUSED = _os.environ.get("VNP_EDGE_UNFUSED", "0") != "1"
 # VNLinear -> VNMaxPool: fuse the pool into the GEMM epilogue (vnp_linear_pool_fwd) when shapes allow; VNP_POOL_UNFUSED=1 keeps
 # the two GEMMs + pool kernels
 POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
@@ -805,6 +808,58 @@ class EdgeGatherAddFn(Function):
         call("vnp_vn_mean_pool_fwd", ptr(g), _ld(g), P, k, W, ptr(gv), W)          # mean over k ...
         gv.mul_(float(k))                                                          # ... times k = sum
         return gu, gv, None
+
+
+class EdgeConvFn(Function):
+    """VNLinearLeakyReLU on the kNN edge tensor followed by mean_pool over the k neighbours, with the edge tensor never
+    materialised (vnp_edge_fused): u, v = the layer's linear maps applied per point ([P*3, 2C'], columns feat | dir),
+    nbr [Pq, k] global neighbour ids.  Equivalent to EdgeGatherAddFn -> VNBnLeakyFn -> VNMeanPoolFn."""
+
+    @staticmethod
+    def forward(ctx, u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
+        u, v = _rows(u), _rows(v)
+        nbr = nbr.contiguous()
+        Pq, k = nbr.shape
+        C = u.shape[1] // 2
+        dev = u.device
+        qb = _lib.lib().vnp_edge_block_queries()
+        nblk = (Pq + qb - 1) // qb
+        if training:
+            part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_edge_fused", 0, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
+                 ptr(part), None, 0, None, 0, None, 0, None, 0, 0, None, 0)
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
+                 ptr(running_var), BN_MOMENTUM, BN_EPS)
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+        out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
+        call("vnp_edge_fused", 1, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+             float(ns), None, ptr(out), C, None, 0, None, 0, None, 0, 0, None, 0)
+        ctx.save_for_backward(u, v, nbr, gamma, beta, mean, rstd)
+        ctx.cfg = (Pq, k, C, bool(training), float(ns), nblk)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        u, v, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
+        Pq, k, C, training, ns, nblk = ctx.cfg
+        go = _rows(go)
+        dev = go.device
+        part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
+        call("vnp_edge_fused", 2, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0, 0, None, 0)
+        S = reduce_rows(part, 1, nblk, 2 * C).view(C, 2)
+        Pu = u.shape[0] // 3
+        gu = torch.empty((Pu * 3, 2 * C), device=dev, dtype=torch.float32)
+        gv = torch.empty((Pq * 3, 2 * C), device=dev, dtype=torch.float32)
+        call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             None, None, 0, ptr(go), _ld(go), ptr(S) if training else None, Pq * k, ptr(gu), 2 * C, Pu, ptr(gv), 2 * C)
+        return gu, gv, None, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, None, None
 
 
 # ------------------------------------------------------------------------------- transformer ops (configs 4, 5)
