@@ -182,3 +182,30 @@ def test_common_mode_rows_keep_their_differences(K, rho):
         c = ops.gemm(A, B).double()
         err[mode] = ((c - c.mean(0, keepdim=True) - refc).norm() / refc.norm()).item()
     assert err["split"] <= 1.25 * err["fp32"], err
+
+
+def test_degenerate_shapes_take_streaming_kernels():
+    """K = 1 (outer product, with per-sample bias / accumulate / strided output), N = 1 (matrix-vector) and the weighted column
+    sums of their gradients (TN with N = 1 or M = 1, long K) are served by HBM-bound kernels inside vnp_gemm; same results."""
+    from vn_pointcloudcompletion_amd import ops
+    # outer product + per-sample VN bias into a column slice, then accumulate
+    M, N = 2 * 50 * 3, 70
+    a, w, b = _mk(M, 1, seed=41), _mk(N, 1, seed=42), _mk(6, N, seed=43)
+    out = torch.zeros(M, 2 * N, device="cuda")
+    ops.gemm(a, w, out=out[:, N:], bias=b, rows_per_group=150)
+    r = torch.arange(M, device="cuda")
+    ref = a.double() @ w.double().t() + b.double()[(r // 150) * 3 + r % 3]
+    assert relerr(out[:, N:], ref) < 1e-6 and out[:, :N].abs().max().item() == 0.0
+    ops.gemm(a, w, out=out[:, N:], accumulate=True)
+    assert relerr(out[:, N:], ref + a.double() @ w.double().t()) < 1e-6
+    wn = _mk(1, N, seed=44)                                            # B as [K, N] (op_b = 1)
+    assert relerr(ops.gemm(a, wn, op_b=1), a.double() @ wn.double()) < 1e-6
+    # matrix-vector, both B layouts
+    A = _mk(5000, 512, seed=45)
+    v = _mk(1, 512, seed=46)
+    assert relerr(ops.gemm(A, v), A.double() @ v.double().t()) < 1e-5
+    assert relerr(ops.gemm(A, v.t().contiguous(), op_b=1), A.double() @ v.double().t()) < 1e-5
+    # weighted column sums (gradients of the two above): long K, N = 1 and M = 1
+    G, x = _mk(60000, 200, seed=47), _mk(60000, 1, seed=48)
+    assert relerr(ops.gemm(G, x, op_a=1, op_b=1), G.double().t() @ x.double()) < 1e-5          # [200, 1]
+    assert relerr(ops.gemm(x, G, op_a=1, op_b=1), x.double().t() @ G.double()) < 1e-5          # [1, 200]

@@ -58,6 +58,58 @@ __global__ void vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit
     }
 }
 
+// ---------------------------------------------------------------------------------------------- degenerate shapes
+// K = 1 (a layer whose only per-point input channel is one VN feature: the attention-folding stages), N = 1 or M = 1 (its
+// gradients, VNLinear(C -> 1)) are outer products, matrix-vector products and weighted column sums: HBM-bound streaming
+// kernels, not tensor-core work (the MFMA kernel spends a full 32-deep K tile on them: 0.95 ms instead of 0.4 for the 1.6 GB
+// outer product of config 4).
+// C[r][c] (+)= a[r] * b[c] (+ per-sample VN bias)
+__global__ void __launch_bounds__(256) vnp_gemm_rank1_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, long long bstride,
+                                                            float* __restrict__ C, int ldc, int M, int N, const float* __restrict__ bias,
+                                                            int ldbias, int rows_per_group, int accumulate)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= N) return;
+    const float bv = B[(size_t)c * bstride];
+    for (long long r = (long long)blockIdx.y * 64 + (threadIdx.x >> 6); r < M && r < ((long long)blockIdx.y + 1) * 64; r += 4) {
+        float v = A[(size_t)r * lda] * bv;
+        if (bias) v += bias[(size_t)((r / rows_per_group) * 3 + r % 3) * ldbias + c];
+        float* dst = C + (size_t)r * ldc + c;
+        if (accumulate) v += *dst;
+        __builtin_nontemporal_store(v, dst);
+    }
+}
+
+// C[r] (+)= sum_k A[r][k] * b[k]   (A K-contiguous; one wave per row)
+__global__ void __launch_bounds__(256) vnp_gemm_matvec_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, long long bstride,
+                                                             float* __restrict__ C, int ldc, int M, int K, int accumulate)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(__builtin_nontemporal_load(&A[(size_t)r * lda + k]), B[(size_t)k * bstride], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) C[(size_t)r * ldc] = accumulate ? C[(size_t)r * ldc] + s : s;
+}
+
+// slab[z][c] = sum over the K-rows of split z of X[k][c] * w[k]   (X C-contiguous: weighted column sums)
+__global__ void __launch_bounds__(256) vnp_gemm_wcolsum_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ w, long long wstride,
+                                                              int K, int Ccols, int rows_per_split, float* __restrict__ slab)
+{
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long k0 = (long long)blockIdx.y * rows_per_split, k1 = min((long long)K, k0 + rows_per_split);
+    float s = 0.f;
+    if (c < Ccols)
+        for (long long k = k0 + py; k < k1; k += 4) s = fmaf(__builtin_nontemporal_load(&X[(size_t)k * ldx + c]), w[(size_t)k * wstride], s);
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && c < Ccols) slab[(size_t)blockIdx.y * Ccols + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 // op_a: 0 = A is [M, K] row-major (K contiguous), 1 = A is [K, M] row-major (M contiguous)
 // op_b: 0 = B is [N, K] row-major (K contiguous), 1 = B is [K, N] row-major (N contiguous)
@@ -73,6 +125,39 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1 && !ws) return VNP_EINVAL;
     if (nbatch < 1 || (nbatch > 1 && nsplit > 1)) return VNP_EINVAL;
+    if (nbatch == 1 && K >= 1) {
+        // outer product: A [M,1] (op_a = 0) x b [N]
+        if (K == 1 && op_a == 0 && M <= 2147483647 / 2) {
+            hipLaunchKernelGGL(vnp_gemm_rank1_kernel, dim3(vnp_cdiv(N, 64), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B,
+                               (long long)(op_b == 0 ? ldb : 1), C, ldc, M, N, bias, ldbias, rows_per_group > 0 ? rows_per_group : 1, accumulate);
+            return vnp_last_error();
+        }
+        // matrix-vector: A [M,K] K-contiguous, one output column
+        if (N == 1 && op_a == 0 && !bias) {
+            hipLaunchKernelGGL(vnp_gemm_matvec_kernel, dim3(vnp_cdiv(M, 4)), dim3(256), 0, stream, A, lda, B, (long long)(op_b == 0 ? 1 : ldb),
+                               C, ldc, M, K, accumulate);
+            return vnp_last_error();
+        }
+        // weighted column sums: C[m][0] = sum_k A[k][m] B[k][0]  or  C[0][n] = sum_k A[k][0] B[k][n]   (both operands [K, .])
+        if (op_a == 1 && op_b == 1 && (N == 1 || M == 1) && !bias && K > 4096) {
+            const float* X = N == 1 ? A : B; const int ldx = N == 1 ? lda : ldb, cols = N == 1 ? M : N;
+            const float* wv = N == 1 ? B : A; const long long ws_ = N == 1 ? ldb : lda;
+            int ns = nsplit > 1 && ws ? nsplit : 1;
+            if (ns > 65535) ns = 65535;
+            const int rps = vnp_cdiv(K, ns);
+            ns = vnp_cdiv(K, rps);
+            float* slab = ws;
+            if (ns > 1) {
+            hipLaunchKernelGGL(vnp_gemm_wcolsum_kernel, dim3(vnp_cdiv(cols, 64), ns), dim3(256), 0, stream, X, ldx, wv, ws_, K, cols, rps, slab);
+            int rc2 = vnp_last_error();
+            if (rc2) return rc2;
+            int blocks = vnp_cdiv(cols, 256);
+            hipLaunchKernelGGL(vnp_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)slab, ns, (long long)cols, C,
+                               M, N, ldc, accumulate);
+            return vnp_last_error();
+            }                                                  // without split-K scratch the MFMA path below handles it
+        }
+    }
     constexpr int BK = 32;
     VnpGemmArgs p;
     p.A = A; p.B = B; p.bias = bias;
