@@ -102,9 +102,18 @@ __global__ void __launch_bounds__(256) vnp_gemm_wcolsum_kernel(const float* __re
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const long long k0 = (long long)blockIdx.y * rows_per_split, k1 = min((long long)K, k0 + rows_per_split);
-    float s = 0.f;
-    if (c < Ccols)
-        for (long long k = k0 + py; k < k1; k += 4) s = fmaf(__builtin_nontemporal_load(&X[(size_t)k * ldx + c]), w[(size_t)k * wstride], s);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                  // four rows in flight per thread
+    if (c < Ccols) {
+        long long k = k0 + py;
+        for (; k + 12 < k1; k += 16) {
+            const float x0 = __builtin_nontemporal_load(&X[(size_t)k * ldx + c]), x1 = __builtin_nontemporal_load(&X[(size_t)(k + 4) * ldx + c]);
+            const float x2 = __builtin_nontemporal_load(&X[(size_t)(k + 8) * ldx + c]), x3 = __builtin_nontemporal_load(&X[(size_t)(k + 12) * ldx + c]);
+            s0 = fmaf(x0, w[(size_t)k * wstride], s0); s1 = fmaf(x1, w[(size_t)(k + 4) * wstride], s1);
+            s2 = fmaf(x2, w[(size_t)(k + 8) * wstride], s2); s3 = fmaf(x3, w[(size_t)(k + 12) * wstride], s3);
+        }
+        for (; k < k1; k += 4) s0 = fmaf(__builtin_nontemporal_load(&X[(size_t)k * ldx + c]), w[(size_t)k * wstride], s0);
+    }
+    const float s = (s0 + s1) + (s2 + s3);
     red[py][cx] = s;
     __syncthreads();
     if (py == 0 && c < Ccols) slab[(size_t)blockIdx.y * Ccols + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
