@@ -40,7 +40,24 @@ __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __rest
     float mean = 0.f, m2 = 0.f;
     int k = 0;
     if (c < C) {
-        for (long long pt = p0 + py; pt < p1; pt += 4) {
+        long long pt = p0 + py;
+        // four points in flight per thread (12 independent loads), then the four dependent Welford updates in the same order
+        for (; pt + 12 < p1; pt += 16) {
+            float nn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* r = p + (size_t)(pt + 4 * u) * 3 * ld + c;
+                nn[u] = sqrtf(vnp_sq3(__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + ld), __builtin_nontemporal_load(r + 2 * ld))) + VNP_EPS;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ++k;
+                const float delta = nn[u] - mean;
+                mean += delta / (float)k;
+                m2 += delta * (nn[u] - mean);
+            }
+        }
+        for (; pt < p1; pt += 4) {
             const float* r = p + (size_t)pt * 3 * ld + c;
             const float n = sqrtf(vnp_sq3(__builtin_nontemporal_load(r), __builtin_nontemporal_load(r + ld), __builtin_nontemporal_load(r + 2 * ld))) + VNP_EPS;
             ++k;
@@ -505,9 +522,18 @@ __global__ void __launch_bounds__(256) vnp_colsum_kernel(const float* __restrict
     const long long r0 = (long long)blockIdx.y * VNP_CHUNK, r1 = min(R, r0 + VNP_CHUNK);
     const float* base = X + (size_t)blockIdx.z * batch_stride;
     float s = 0.f;
-    if (c < C)
-        for (long long r = r0 + py; r < r1; r += 4)
-            s += __builtin_nontemporal_load(&base[(size_t)r * row_stride + c]) * (w ? w[(size_t)blockIdx.z * R + r] : 1.f);
+    if (c < C) {
+        long long r = r0 + py;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;                    // four rows in flight per thread
+        for (; r + 12 < r1; r += 16) {
+            const float x0 = __builtin_nontemporal_load(&base[(size_t)r * row_stride + c]), x1 = __builtin_nontemporal_load(&base[(size_t)(r + 4) * row_stride + c]);
+            const float x2 = __builtin_nontemporal_load(&base[(size_t)(r + 8) * row_stride + c]), x3 = __builtin_nontemporal_load(&base[(size_t)(r + 12) * row_stride + c]);
+            const float* ww = w ? w + (size_t)blockIdx.z * R + r : nullptr;
+            t0 += x0 * (ww ? ww[0] : 1.f); t1 += x1 * (ww ? ww[4] : 1.f); t2 += x2 * (ww ? ww[8] : 1.f); t3 += x3 * (ww ? ww[12] : 1.f);
+        }
+        for (; r < r1; r += 4) t0 += __builtin_nontemporal_load(&base[(size_t)r * row_stride + c]) * (w ? w[(size_t)blockIdx.z * R + r] : 1.f);
+        s = (t0 + t1) + (t2 + t3);
+    }
     red[py][cx] = s;
     __syncthreads();
     if (py == 0 && c < C)
