@@ -146,6 +146,59 @@ __global__ void __launch_bounds__(64) vnp_knn_select_kernel(const float* __restr
     }
 }
 
+// The same selection for rows of up to 64 * NPL values with the scan taken out of the k passes: every lane sorts its NPL
+// values once by (distance, index) — a bitonic network on registers, all indices static — and parks the sorted column in LDS;
+// a pass is then one LDS read of the lane's current head, a wave arg-min, and a pointer bump in the winning lane.
+// ~NPL log^2 NPL / 4 compare-exchanges + k * (1 read + 6 shuffle steps) instead of k * NPL dependent compare-selects.
+template <int NPL>
+__global__ void __launch_bounds__(64) vnp_knn_select_sorted_kernel(const float* __restrict__ dist, int Nr, int k, int* __restrict__ idx_out,
+                                                                  float* __restrict__ dist_out)
+{
+    __shared__ float sd[NPL + 1][64];
+    __shared__ int si[NPL + 1][64];
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* d = dist + row * Nr;
+    float v[NPL];
+    int id[NPL];
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; id[u] = i; v[u] = i < Nr ? d[i] : INFINITY; }
+    // bitonic sort ascending by (v, id); NaN distances compare false everywhere and stay where they are, like in the scan kernel
+#pragma unroll
+    for (int kk = 2; kk <= NPL; kk <<= 1)
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int u = 0; u < NPL; ++u) {
+                const int w = u ^ j;
+                if (w > u) {
+                    const bool up = (u & kk) == 0;
+                    const bool gt = v[u] > v[w] || (v[u] == v[w] && id[u] > id[w]);
+                    if (gt == up) { const float tv = v[u]; v[u] = v[w]; v[w] = tv; const int ti = id[u]; id[u] = id[w]; id[w] = ti; }
+                }
+            }
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { sd[u][lane] = v[u]; si[u][lane] = id[u] < Nr ? id[u] : 0x7fffffff; }
+    sd[NPL][lane] = INFINITY; si[NPL][lane] = 0x7fffffff;          // sentinel: an exhausted lane
+    __syncthreads();
+    int head = 0;
+    for (int p = 0; p < k; ++p) {
+        float best = sd[head][lane]; int bi = si[head][lane];
+        if (bi == 0x7fffffff) best = INFINITY;
+        float wv = best; int wi = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(wv, o); const int oi = __shfl_xor(wi, o);
+            if (ov < wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+        }
+        if (wi == bi && bi != 0x7fffffff) ++head;                  // this lane's head was taken
+        if (lane == 0) {
+            idx_out[row * k + p] = wi == 0x7fffffff ? 0 : wi;
+            if (dist_out) dist_out[row * k + p] = wv;
+        }
+    }
+}
+
 // Same contract as vnp_knn with a caller-provided distance matrix: ws of B*Nq*Nr floats.  Any D; Nr <= 16384.
 extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k,
                               int* idx, float* dist, float* ws)
@@ -159,8 +212,11 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(vnp_knn_select_kernel, dim3((unsigned)((long long)B * Nq)), dim3(64), (size_t)Nr * 4, st,
-                       (const float*)ws, Nr, k, idx, dist);
+    const dim3 rows((unsigned)((long long)B * Nq));
+    if (Nr <= 512)       hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<8>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+    else if (Nr <= 1024) hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<16>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+    else if (Nr <= 2048) hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<32>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+    else hipLaunchKernelGGL(vnp_knn_select_kernel, rows, dim3(64), (size_t)Nr * 4, st, (const float*)ws, Nr, k, idx, dist);
     return vnp_last_error();
 }
 
