@@ -247,7 +247,10 @@ extern "C" int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, c
 // One 1024-thread block per sample; each thread keeps the running min-distance of up to FPS_PER_THREAD points in
 // registers; every round: update against the last pick, block arg-max (wave shuffles + one LDS exchange).
 #define FPS_THREADS 1024
-#define FPS_PER_THREAD 16       // N <= 16384
+#define FPS_MAX_PER_THREAD 16   // N <= 16384
+// FPS_PER_THREAD = ceil(N / 1024) rounded up to 2, 4, 8 or 16: the per-round update loop is fully unrolled, so a 2048-point
+// cloud must not pay for 16 slots
+template <int FPS_PER_THREAD>
 __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __restrict__ xyz, int N, int M, int* __restrict__ out)
 {
     __shared__ float sv[FPS_THREADS / 64];
@@ -301,8 +304,11 @@ __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __res
 // furthest_point_sample(xyz[B,N,3], M) -> idx [B][M]; N <= 16384
 extern "C" int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx)
 {
-    if (!xyz || !idx || B <= 0 || N <= 0 || M <= 0 || M > N || N > FPS_THREADS * FPS_PER_THREAD) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_fps_kernel, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    if (!xyz || !idx || B <= 0 || N <= 0 || M <= 0 || M > N || N > FPS_THREADS * FPS_MAX_PER_THREAD) return VNP_EINVAL;
+    if (N <= 2 * FPS_THREADS)      hipLaunchKernelGGL(vnp_fps_kernel<2>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    else if (N <= 4 * FPS_THREADS) hipLaunchKernelGGL(vnp_fps_kernel<4>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    else if (N <= 8 * FPS_THREADS) hipLaunchKernelGGL(vnp_fps_kernel<8>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    else                           hipLaunchKernelGGL(vnp_fps_kernel<16>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
     return vnp_last_error();
 }
 
