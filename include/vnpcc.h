@@ -69,6 +69,13 @@ int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              int accumulate, int nsplit, float* ws);
 
 /* nbatch independent products C_i = op(A_i) op(B_i), element strides bsa/bsb/bsc (attention: one per (sample, head)) */
+/* vnp_gemm (NT, optional per-sample VN bias) that also returns, for the first stats_cols columns, the per-1024-point Welford
+ * partials vnp_vn_norm_stats would compute from C — taken from the accumulators, so the BatchNorm statistics of a VN layer cost
+ * no extra pass over its output.  part1024 [M/3072][stats_cols][2]; ws: vnp_gemm_vn_stats_ws_floats(M, stats_cols) floats.
+ * VNP_EINVAL unless split mode, M % 3072 == 0, N % 128 == 0, K % 32 == 0, stats_cols % 64 == 0, aligned operands. */
+long long vnp_gemm_vn_stats_ws_floats(long long M, int stats_cols);
+int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                      const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws);
 int vnp_gemm_batched(hipStream_t st, int op_a, int op_b, int M, int N, int K,
                      const float* A, int lda, long long bsa, const float* B, int ldb, long long bsb,
                      float* C, int ldc, long long bsc, int nbatch, int accumulate);

@@ -193,3 +193,42 @@ def test_reduce_rows_any_count(lib_built, nb, n, W):
     part = torch.randn(nb, n, W, generator=g).cuda()
     out = ops.reduce_rows(part, nb, n, W)
     assert relerr(out, part.double().sum(1)) < 1e-6
+
+
+@pytest.mark.parametrize("R,K,C,rpg", [(3072, 64, 64, 0), (6144, 96, 128, 3072), (9216, 32, 192, 1536)])
+def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
+    """vnp_gemm_vn_stats: [p | d] and the per-1024-point Welford partials of |p| from the GEMM's accumulators, against vnp_gemm
+    followed by vnp_vn_norm_stats: identical [p | d] bits (same GEMM arithmetic, rows only permuted inside the tile) and
+    statistics equal to fp32 rounding; through VNLinearLeakyFn the layer output and all gradients agree."""
+    from vn_pointcloudcompletion_amd import ops
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, K, generator=g).cuda()
+    W = (torch.randn(2 * C, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(R // rpg * 3, 2 * C, generator=g).cuda() if rpg else None
+    pd_ref = torch.empty(R, 2 * C, device="cuda")
+    ops.gemm(x, W, out=pd_ref, bias=bias, rows_per_group=rpg, nsplit=1)
+    part_ref = torch.empty(R // 3072, C, 2, device="cuda")
+    call("vnp_vn_norm_stats", ptr(pd_ref), 2 * C, R // 3, C, ptr(part_ref))
+    pd = torch.empty(R, 2 * C, device="cuda")
+    part = ops.gemm_pd_stats(x, W, pd, bias, rpg, C, True)
+    assert part is not None and torch.equal(pd, pd_ref)
+    assert (part[..., 0] - part_ref[..., 0]).abs().max().item() <= 2e-6 * part_ref[..., 0].abs().max().item()
+    assert (part[..., 1] - part_ref[..., 1]).abs().max().item() <= 2e-5 * part_ref[..., 1].abs().max().item()
+    # whole layer, fused statistics on / off
+    res = []
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    go = torch.randn(R, C, generator=g).cuda()
+    for on in (True, False):
+        ops.STATS_IN_EPILOGUE = on
+        try:
+            xx = x.clone().requires_grad_(True)
+            Wf, Wd = W[:C].clone().requires_grad_(True), W[C:].clone().requires_grad_(True)
+            rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+            out = ops.VNLinearLeakyFn.apply(xx, Wf, Wd, gam, bet, rm, rv, bias, rpg, True, 0.2)
+            (out * go).sum().backward()
+            res.append((out.detach(), xx.grad, Wf.grad, Wd.grad, rm, rv))
+        finally:
+            ops.STATS_IN_EPILOGUE = True
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-12)

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "vnp_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vnp_emd_matchcost_bwd": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_gemm": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "vnp_gemm_vn_stats": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "vnp_gemm_batched": [_i, _i, _i, _i, _i, _vp, _i, _ll, _vp, _i, _ll, _vp, _i, _ll, _i, _i],
     "vnp_vn_layernorm_fwd": [_vp, _i, _ll, _i, _vp, _vp, _vp, _i, _vp],
     "vnp_vn_layernorm_bwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
@@ -109,8 +110,8 @@ _SIGNATURES = {
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
 _NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
-              "vnp_linear_pool_ws_bytes": [_ll, _i, _i]}
-_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll}
+              "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_gemm_vn_stats_ws_floats": [_ll, _i]}
+_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_gemm_vn_stats_ws_floats": _ll}
 
 
 def exported_symbols():

@@ -285,6 +285,62 @@ extern "C" int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, cons
     return vnp_last_error();
 }
 
+// ---- [p | d] = x [Wf; Wd]^T with the BatchNorm statistics of p taken in the epilogue --------------------------------
+// merges 32 consecutive 32-point Welford partials into the 1024-point chunks vnp_vn_bn_finalize expects
+__global__ void __launch_bounds__(256) vnp_stats_merge32_kernel(const float2* __restrict__ part32, int C, float2* __restrict__ out)
+{
+    __shared__ double rm[4][64], rM[4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double na = 0.0, ma = 0.0, Ma = 0.0;
+    if (c < C) {
+        const float2* src = part32 + ((size_t)blockIdx.y * 32 + py * 8) * C + c;
+        for (int k = 0; k < 8; ++k) {
+            const float2 v = src[(size_t)k * C];
+            if (na == 0.0) { na = 32.0; ma = v.x; Ma = v.y; }
+            else { const double n = na + 32.0, delta = (double)v.x - ma; ma += delta * 32.0 / n; Ma += (double)v.y + delta * delta * na * 32.0 / n; na = n; }
+        }
+    }
+    rm[py][cx] = ma; rM[py][cx] = Ma;
+    __syncthreads();
+    if (py == 0 && c < C) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const double nb = 256.0, n = na + nb, delta = rm[j][cx] - ma;
+            ma += delta * nb / n; Ma += rM[j][cx] + delta * delta * na * nb / n; na = n;
+        }
+        out[(size_t)blockIdx.y * C + c] = make_float2((float)ma, (float)Ma);
+    }
+}
+
+extern "C" long long vnp_gemm_vn_stats_ws_floats(long long M, int stats_cols) { return (M / 96) * (long long)stats_cols * 2; }
+
+// C[M, N] = A[M, K] B[N, K]^T (+ per-sample VN bias), and for the first stats_cols columns the Welford partials
+// (mean, M2) of n = |row triple| + eps per 1024 points in part1024 [M/3072][stats_cols][2] — what vnp_vn_norm_stats would
+// have produced from C, without reading C back.  ws: vnp_gemm_vn_stats_ws_floats(M, stats_cols) floats.
+// VNP_EINVAL unless split GEMM mode, M % 3072 == 0, N % 128 == 0, K % 32 == 0, stats_cols % 64 == 0, 16-byte alignment.
+extern "C" int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws)
+{
+    if (!A || !B || !C || !part1024 || !ws || M <= 0 || N <= 0 || K <= 0 || stats_cols <= 0) return VNP_EINVAL;
+    if (g_vnp_gemm_mode != 0 || M % 3072 || N % 128 || K % 32 || stats_cols % 64 || stats_cols > N || lda % 4 || ldb % 4 ||
+        (uintptr_t)A % 16 || (uintptr_t)B % 16 || (bias && rows_per_group <= 0) || (bias && rows_per_group % 3))
+        return VNP_EINVAL;
+    VnpGemmArgs p{};
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldbias = ldbias;
+    p.rows_per_group = rows_per_group > 0 ? rows_per_group : 1;
+    p.tiles_per_split = K / 32; p.nsplit = 1; p.nbatch = 1; p.col_group = 8;
+    p.stats_part = (float2*)ws; p.stats_cols = stats_cols;
+    const long long items = (long long)(M / 192) * (N / 128);
+    const long long cap = (long long)vnp_num_cus() * 2;
+    dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
+    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
+    hipLaunchKernelGGL(vnp_stats_merge32_kernel, dim3(vnp_cdiv(stats_cols, 64), M / 3072), dim3(256), 0, st,
+                       (const float2*)ws, stats_cols, (float2*)part1024);
+    return vnp_last_error();
+}
+
 extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
                         const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                         const float* bias, int ldbias, int rows_per_group,

@@ -16,6 +16,9 @@ struct VnpGemmArgs {
     // VN max-pool epilogue of vnp_gemm_split_kernel<.., EPI = 1> (C is not written): per 32-point wave block and channel,
     // the best <x, d>, its point index inside the group of pool_gs points, and the winning x vector
     float* pool_val; int* pool_idx; float* pool_x; int pool_gs;
+    // EPI = 2: C is stored as usual AND the BatchNorm statistics of the first stats_cols columns are taken from the
+    // accumulators: Welford (mean, M2) of n = |x| + eps over each wave's 32 points -> stats_part[M/96][stats_cols]
+    float2* stats_part; int stats_cols;
     int col_group;                       // split kernel: walk the column tiles in groups of this many (0 = all): keeps the B
                                          // panels of a group L2-resident while the row panels stream past
 };

@@ -180,9 +180,9 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     int oa, sa, ob, sb;
     vnp_split_offsets<BM, AKC>(oa, sa, p.lda, tid);
     vnp_split_offsets<BN, BKC>(ob, sb, p.ldb, tid);
-    static_assert(EPI == 0 || (BM == 192 && BN == 128 && AKC && BKC && FAST), "the pool epilogue needs the aligned 192x128 NT kernel");
-    int perm_off[AV];                       // EPI == 1: element offset of the global row that LDS row tid/8 + 32 j holds
-    if (EPI == 1) {
+    static_assert(EPI == 0 || (BM == 192 && BN == 128 && AKC && BKC && FAST), "the VN epilogues need the aligned 192x128 NT kernel");
+    int perm_off[AV];                       // EPI >= 1: element offset of the global row that LDS row tid/8 + 32 j holds
+    if (EPI >= 1) {
 #pragma unroll
         for (int j = 0; j < AV; ++j) {
             const int rho = (tid >> 3) + 32 * j, half = rho / 96, within = rho % 96, i = within >> 4, r16 = within & 15;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
         const float* pB = p.B + (size_t)fbatch * p.bsb;
         const int k0 = kt * BK;
         const bool full = FAST || (k0 + BK <= p.K);
-        if (EPI == 1) {
+        if (EPI >= 1) {
             const float* blk = pA + (size_t)fm0 * p.lda + k0;
 #pragma unroll
             for (int j = 0; j < AV; ++j) ra[j] = *(const vnp_f4*)(blk + perm_off[j]);
@@ -335,6 +335,63 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                     p.pool_idx[slot] = loc0 + bi;
                     p.pool_x[3 * slot + 0] = bx0; p.pool_x[3 * slot + 1] = bx1; p.pool_x[3 * slot + 2] = bx2;
                 }
+            }
+        } else if (EPI == 2) {
+            // C store under the row permutation of EPI = 1 (MFMA row-tile 3 i3 + t, row r  <->  component t of wave-local point
+            // 16 i3 + r) plus the BatchNorm statistics of the p columns: every lane holds whole 3-vectors, so n = |x| + eps is
+            // formed in registers; Welford over the lane's 8 points, Chan merges across the 4 lane groups -> 32 points per wave.
+            float* Cz = p.C;
+            int g0 = 0, r0 = 0;
+            const bool has_bias = p.bias != nullptr;
+            const bool bias_fast = has_bias && p.rows_per_group >= BM;
+            if (has_bias) { g0 = m0 / p.rows_per_group; r0 = m0 - g0 * p.rows_per_group; }
+            float wmean[TN], wm2[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { wmean[j] = 0.f; wm2[j] = 0.f; }
+            int wn_cnt = 0;
+#pragma unroll
+            for (int i3 = 0; i3 < 2; ++i3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int lr = wm * 96 + (16 * i3 + 4 * lq + e) * 3;         // tile-local row of component 0
+                    const float* b0 = nullptr; const float* b1 = nullptr; const float* b2 = nullptr;
+                    if (has_bias) {
+                        const int grp = bias_fast ? g0 + ((r0 + lr) >= p.rows_per_group ? 1 : 0) : (m0 + lr) / p.rows_per_group;
+                        b0 = p.bias + (size_t)(grp * 3) * p.ldbias; b1 = b0 + p.ldbias; b2 = b1 + p.ldbias;
+                    }
+                    float* d0 = Cz + (size_t)(m0 + lr) * p.ldc;
+                    ++wn_cnt;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = n0 + wn * (BN / 2) + j * 16 + l16;
+                        float x0 = acc[3 * i3][j][e], x1 = acc[3 * i3 + 1][j][e], x2 = acc[3 * i3 + 2][j][e];
+                        if (has_bias) { x0 += b0[col]; x1 += b1[col]; x2 += b2[col]; }
+                        __builtin_nontemporal_store(x0, d0 + col);
+                        __builtin_nontemporal_store(x1, d0 + p.ldc + col);
+                        __builtin_nontemporal_store(x2, d0 + 2 * p.ldc + col);
+                        const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2) + VNP_EPS;
+                        const float delta = nrm - wmean[j];
+                        wmean[j] += delta / (float)wn_cnt;
+                        wm2[j] += delta * (nrm - wmean[j]);
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // Chan merge with the partner lane group, twice (8 -> 16 -> 32 points); both sides hold equal counts
+                float fm = wmean[j], fM = wm2[j];
+                double cnt = 8.0;
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const double ma = (double)fm, Ma = (double)fM;
+                    const double mb = (double)__shfl_xor(fm, o), Mb = (double)__shfl_xor(fM, o);
+                    const double delta = mb - ma;
+                    fm = (float)(ma + delta * 0.5);
+                    fM = (float)(Ma + Mb + delta * delta * cnt * 0.5);
+                    cnt *= 2.0;
+                }
+                const int col = n0 + wn * (BN / 2) + j * 16 + l16;
+                if (lq == 0 && col < p.stats_cols)
+                    p.stats_part[(size_t)(m0 / 96 + wm) * p.stats_cols + col] = make_float2(fm, fM);
             }
         } else
         // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg

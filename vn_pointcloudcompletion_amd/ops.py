@@ -26,6 +26,9 @@ POOL_DIRECTION_REASSOCIATE = _os.environ.get("VNP_POOL_AS_WRITTEN", "0") != "1"
 # EdgeConv (configs 3, 5): recompute the edge pre-activations in every pass instead of materialising the k-times larger edge
 # tensor (EdgeConvFn); VNP_EDGE_UNFUSED=1 keeps gather-add -> BatchNorm/leaky -> mean-pool as separate kernels
 EDGE_FUSED = _os.environ.get("VNP_EDGE_UNFUSED", "0") != "1"
+# VNLinearLeakyReLU: take the BatchNorm statistics of p from the GEMM's accumulators (vnp_gemm_vn_stats) instead of re-reading
+# p; VNP_STATS_UNFUSED=1 keeps the separate vnp_vn_norm_stats pass
+STATS_IN_EPILOGUE = _os.environ.get("VNP_STATS_UNFUSED", "0") != "1"
 # VNLinear -> VNMaxPool: fuse the pool into the GEMM epilogue (vnp_linear_pool_fwd) when shapes allow; VNP_POOL_UNFUSED=1 keeps
 # the two GEMMs + pool kernels
 POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
@@ -126,8 +129,33 @@ def _per_sample_colsum(g, rows_per_group):
     return out
 
 
-def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training, ns, use_bn=True):
-    """p, d: [R, C] views (d may be None).  Returns out, mean, rstd."""
+def gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, want_stats):
+    """pd[R, 2C] = x Wcat^T (+ per-sample bias).  When the shapes allow (aligned 192x128 tiles, whole 1024-point chunks) and
+    ``want_stats``, the GEMM's epilogue also produces the per-chunk Welford partials of |p| (vnp_gemm_vn_stats) and they are
+    returned ([P/1024, C, 2]); otherwise None and the caller runs vnp_vn_norm_stats."""
+    R, K = x.shape
+    ok = (want_stats and STATS_IN_EPILOGUE and _lib.get_gemm_mode() == "split" and R % 3072 == 0 and (2 * C) % 128 == 0 and K % 32 == 0
+          and C % 64 == 0 and _ld(x) % 4 == 0 and x.data_ptr() % 16 == 0 and Wcat.is_contiguous() and Wcat.data_ptr() % 16 == 0
+          and (bias is None or (rows_per_group > 0 and rows_per_group % 3 == 0)))
+    if not ok:
+        gemm(x, Wcat, out=pd, bias=bias, rows_per_group=rows_per_group, nsplit=1)
+        return None
+    part = torch.empty((R // 3072, C, 2), device=x.device, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().vnp_gemm_vn_stats_ws_floats(R, C), device=x.device, dtype=torch.float32)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("vnp_gemm_vn_stats", R, 2 * C, K, ptr(x), _ld(x), ptr(Wcat), K, ptr(pd), _ld(pd), ptr(bias),
+         _ld(bias) if bias is not None else 0, rows_per_group, C, ptr(part), ptr(ws))
+    if prof is not None:
+        e1.record()
+        prof.append(("NT", 2.0 * R * 2 * C * K, 1, (R, 2 * C, K), e0, e1))
+    return part
+
+
+def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training, ns, use_bn=True, part=None):
+    """p, d: [R, C] views (d may be None).  Returns out, mean, rstd.  ``part``: precomputed statistics partials."""
     R = p.shape[0]
     P = R // 3
     dev = p.device
@@ -135,8 +163,9 @@ def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training,
     if use_bn:
         if training:
             nch = _nchunk(P)
-            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-            call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
+            if part is None:
+                part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+                call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
             mean = torch.empty(C, device=dev, dtype=torch.float32)
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
             call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
@@ -279,8 +308,8 @@ class VNLinearLeakyFn(Function):
         # one GEMM for both halves: [Wf; Wd] is copied into a [2C, Cin] matrix (a few MB at most) so that x is streamed
         # once and the launch has twice the columns
         Wcat = torch.cat([Wf, Wd], dim=0)
-        gemm(x, Wcat, out=pd, bias=bias, rows_per_group=rows_per_group, nsplit=1)
-        out, mean, rstd = _bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, running_mean, running_var, training, ns)
+        part = gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, training)
+        out, mean, rstd = _bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, running_mean, running_var, training, ns, part=part)
         ctx.save_for_backward(x, Wcat, gamma, beta, pd, mean, rstd)
         ctx.cfg = (C, rows_per_group, training, ns, bias is not None)
         return out
@@ -314,12 +343,14 @@ class VNLinearLeakyOutFn(Function):
         C = Wf.shape[0]
         dev = x.device
         Wcat = torch.cat([Wf, Wd], dim=0)
-        pd = gemm(x, Wcat, nsplit=1)                                           # [R, 2C]
+        pd = torch.empty((R, 2 * C), device=dev, dtype=torch.float32)
+        part = gemm_pd_stats(x, Wcat, pd, None, 0, C, training)                # [R, 2C] (+ the statistics of p from the epilogue)
         p, d = pd[:, :C], pd[:, C:]
         if training:
             nch = _nchunk(P)
-            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-            call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
+            if part is None:
+                part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+                call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
             mean = torch.empty(C, device=dev, dtype=torch.float32)
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
             call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
