@@ -110,3 +110,19 @@ def test_flat_buffers_and_adam_state_dict_format():
     m[0].weight.grad = None                                          # a caller used set_to_none=True
     fb.zero_grad()
     assert m[0].weight.grad is not None
+
+
+def test_integration_md_stubs_declare_correct_argtypes():
+    """Every libvnpcc function the INTEGRATION.md stubs call has its argtypes declared there (ctypes would otherwise pass 64-bit
+    pointers as C ints) and the declared lists equal the signature table of _lib.py.  The stubs are executed on the GPU in
+    tests/test_gpu_integration_doc.py."""
+    from vn_pointcloudcompletion_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = "\n".join(b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "ctypes" in b or "_L." in b)
+    compile(code, "INTEGRATION.md", "exec")
+    called = set(re.findall(r"_L\.(vnp_\w+)\(", code))
+    declared = dict(re.findall(r"_L\.(vnp_\w+)\.argtypes\s*=\s*\[(.*?)\]", code))
+    assert called and called <= set(declared), sorted(called - set(declared))
+    names = {_lib._vp: "_vp", _lib._i: "_i", _lib._ll: "_ll", _lib._f: "_f"}
+    for fn, lst in declared.items():
+        assert [x.strip() for x in lst.split(",")] == ["_vp"] + [names[t] for t in _lib._SIGNATURES[fn]], fn
