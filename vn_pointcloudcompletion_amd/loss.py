@@ -26,52 +26,49 @@ def emd_loss(pcs1, pcs2):
     return torch.mean(EarthMoverDistance()(pcs1, pcs2))
 
 
+def _sample_means(d_a, d_b):
+    """Per-sample means of two one-sided squared distances and of their square roots."""
+    return d_a.mean(dim=1), d_b.mean(dim=1), d_a.sqrt().mean(dim=1), d_b.sqrt().mean(dim=1)
+
+
 def calc_cd(output, gt, calc_f1=False, return_raw=False, normalize=False, separate=False):
-    """metrics/loss.py:58-75."""
-    dist1, dist2, idx1, idx2 = chamfer_3DDist()(gt, output)
-    cd_p = (torch.sqrt(dist1).mean(1) + torch.sqrt(dist2).mean(1)) / 2
-    cd_t = dist1.mean(1) + dist2.mean(1)
-    if separate:
-        res = [torch.cat([torch.sqrt(dist1).mean(1).unsqueeze(0), torch.sqrt(dist2).mean(1).unsqueeze(0)]),
-               torch.cat([dist1.mean(1).unsqueeze(0), dist2.mean(1).unsqueeze(0)])]
-    else:
-        res = [cd_p, cd_t]
+    """metrics/loss.py:58-75: per-sample Chamfer terms [cd_p (L1 form), cd_t (L2 form)] (+ F-score@1e-4, + raw outputs).
+    The operator is called as (gt, output), so dist1/idx1 belong to the ground-truth points, as in the reference."""
+    d_gt, d_out, i_gt, i_out = chamfer_3DDist()(gt, output)
+    m_gt, m_out, r_gt, r_out = _sample_means(d_gt, d_out)
+    res = [torch.stack([r_gt, r_out]), torch.stack([m_gt, m_out])] if separate else [(r_gt + r_out) / 2, m_gt + m_out]
     if calc_f1:
         from .metric import fscore
-        f1, _, _ = fscore(dist1, dist2, 0.0001)
-        res.append(f1)
+        res.append(fscore(d_gt, d_out, 0.0001)[0])
     if return_raw:
-        res.extend([dist1, dist2, idx1, idx2])
+        res += [d_gt, d_out, i_gt, i_out]
     return res
 
 
+def _density_side(dist, idx, n_targets, alpha, n_lambda, frac):
+    """One direction of the density-aware term: every query is weighted by 1 / (number of queries that share its nearest
+    neighbour)^lambda (a batched histogram of the arg-min indices; the reference loops over the batch with bincount)."""
+    idx = idx.long()
+    hits = torch.zeros((dist.shape[0], n_targets), device=dist.device, dtype=torch.float32)
+    hits.scatter_add_(1, idx, torch.ones_like(dist, dtype=torch.float32))
+    weight = (hits.gather(1, idx).detach() ** n_lambda + 1e-6) ** (-1) * frac
+    return (1.0 - torch.exp(-alpha * dist) * weight).mean(dim=1)
+
+
 def calc_dcd(x, gt, alpha=1000, n_lambda=1, return_raw=False, non_reg=False):
-    """Density-aware Chamfer distance, metrics/loss.py:77-118."""
-    x = x.float()
-    gt = gt.float()
-    batch_size, n_x, _ = x.shape
-    _, n_gt, _ = gt.shape
-    assert x.shape[0] == gt.shape[0]
+    """Density-aware Chamfer distance, metrics/loss.py:77-118.  Returns [dcd per sample, cd_p, cd_t] (+ raw outputs)."""
+    x, gt = x.float(), gt.float()
+    if x.shape[0] != gt.shape[0]:
+        raise AssertionError("calc_dcd: batch sizes differ")
+    n_x, n_gt = x.shape[1], gt.shape[1]
+    ratio_x, ratio_gt = n_x / n_gt, n_gt / n_x
     if non_reg:
-        frac_12 = max(1, n_x / n_gt)
-        frac_21 = max(1, n_gt / n_x)
-    else:
-        frac_12 = n_x / n_gt
-        frac_21 = n_gt / n_x
-    cd_p, cd_t, dist1, dist2, idx1, idx2 = calc_cd(x, gt, return_raw=True)
-    exp_dist1, exp_dist2 = torch.exp(-dist1 * alpha), torch.exp(-dist2 * alpha)
-    # per-sample histogram of the arg-min indices, batched (the reference loops over the batch in Python)
-    i1, i2 = idx1.long(), idx2.long()
-    count1 = torch.zeros((batch_size, n_x), device=x.device, dtype=torch.float32).scatter_add_(
-        1, i1, torch.ones_like(i1, dtype=torch.float32))
-    count2 = torch.zeros((batch_size, n_gt), device=x.device, dtype=torch.float32).scatter_add_(
-        1, i2, torch.ones_like(i2, dtype=torch.float32))
-    weight1 = (count1.gather(1, i1).detach() ** n_lambda + 1e-6) ** (-1) * frac_21
-    weight2 = (count2.gather(1, i2).detach() ** n_lambda + 1e-6) ** (-1) * frac_12
-    loss1 = (-exp_dist1 * weight1 + 1.).mean(1)
-    loss2 = (-exp_dist2 * weight2 + 1.).mean(1)
-    loss = (loss1 + loss2) / 2
-    res = [loss, cd_p, cd_t]
+        ratio_x, ratio_gt = max(1, ratio_x), max(1, ratio_gt)
+    cd_p, cd_t, d_gt, d_out, i_gt, i_out = calc_cd(x, gt, return_raw=True)
+    # d_gt / i_gt: each ground-truth point's nearest prediction (indices into x); d_out / i_out: the converse
+    side_gt = _density_side(d_gt, i_gt, n_x, alpha, n_lambda, ratio_gt)
+    side_out = _density_side(d_out, i_out, n_gt, alpha, n_lambda, ratio_x)
+    res = [(side_gt + side_out) / 2, cd_p, cd_t]
     if return_raw:
-        res.extend([dist1, dist2, idx1, idx2])
+        res += [d_gt, d_out, i_gt, i_out]
     return res
