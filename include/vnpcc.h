@@ -3,7 +3,9 @@
  * Drop-in boundary: these entry points are what the reference's Python would bind in place of its two pybind11
  * CUDA extensions and of the eager ATen chains inside models/vn_layers.py.  All functions
  *   - take raw DEVICE pointers, explicit sizes / leading dimensions and the caller's hipStream_t,
- *   - allocate nothing (scratch is passed in), are re-entrant, launch on the given stream without synchronising,
+ *   - allocate nothing (scratch is passed in), are re-entrant and thread-safe (no mutable global state apart from the
+ *     process-wide GEMM-mode switch below, an atomic; per-device kernel attributes are set once per device under an atomic
+ *     flag), launch on the given stream without synchronising,
  *   - return 0 on success, VNP_EINVAL (-1) for bad arguments, or the positive hipError_t of a failed launch
  *     (stricter than the reference, which printf()s and swallows launch errors: chamfer3D.cu:145-151).
  *
@@ -171,8 +173,14 @@ int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, const float*
  * per-row selection; Nr <= 16384 */
 int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k, int* idx, float* dist,
                    float* ws);
-/* furthest_point_sample: starts at index 0, ties to the lowest index; idx [B][M]; N <= 16384 */
+/* furthest_point_sample: starts at index 0, ties to the lowest index; idx [B][M]; N <= 16384.  vnp_fps: plain FPS, every
+ * point is a candidate.  vnp_fps_ex(flags = VNP_FPS_SKIP_NEAR_ORIGIN): the convention of pointnet2_ops (the package the
+ * reference calls, models/pcn.py:7, models/dgcnn.py:210; its furthest_point_sampling_kernel has `if (mag <= 1e-3) continue;`):
+ * a candidate with x^2+y^2+z^2 <= 1e-3 is never selected and its running distance is not updated (point 0 is still sample 0;
+ * if every candidate is skipped the pick is index 0).  The Python binding uses the pointnet2_ops convention by default. */
+#define VNP_FPS_SKIP_NEAR_ORIGIN 1
 int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx);
+int vnp_fps_ex(hipStream_t st, int B, int N, const float* xyz, int M, int* idx, int flags);
 /* rows layout: out point i <- x point src[i] (gather_operation); and its adjoint gx[src[i]] += g[i] (gx zeroed here) */
 int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo);
 int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* src, long long Pout, int W,

@@ -81,11 +81,15 @@ def vn_linear_and_leaky_relu(x, w_lin, w_dir, negative_slope=0.2):
     return vn_leaky_relu(y, w_dir, negative_slope)
 
 
-def vn_max_pool(x, w_dir, return_index=False):
-    """models/vn_layers.py:153-167: argmax over the last axis of <x, W_d x>."""
+def vn_max_pool(x, w_dir, return_index=False, forced_idx=None):
+    """models/vn_layers.py:153-167: argmax over the last axis of <x, W_d x>.
+    ``forced_idx`` [B,C] (teacher forcing for parity tests): gather at these indices instead of the arg-max; the scores are
+    still computed and returned so that the caller can check that the forced choice is a (near-)maximum."""
     d = vn_linear(x, w_dir)
     dot = (x * d).sum(2, keepdim=True)                            # [B,C,1,N]
     idx = dot.argmax(dim=-1, keepdim=True)                        # first maximum
+    if forced_idx is not None:
+        idx = forced_idx.to(idx.dtype).reshape(idx.shape)
     shape = list(idx.shape)
     shape[2] = 3
     out = torch.gather(x, -1, idx.expand(shape)).squeeze(-1)
@@ -126,20 +130,30 @@ def _lin_leaky(sd, prefix, x, training, new_stats):
     return y
 
 
-def vn_pointnet_forward(sd, xyz, training=True, prefix="encoder", new_stats=None):
+def vn_pointnet_forward(sd, xyz, training=True, prefix="encoder", new_stats=None, pool_idx=None, trace=None):
     """models/pcn.py:165-184 (VN_PointNet.forward), num_coarse != 224 branch.
 
-    Returns (coarse [B,Mc,3], feature_global [B,C,3,1])."""
+    Returns (coarse [B,Mc,3], feature_global [B,C,3,1]).  ``pool_idx`` = (idx1 [B,512], idx2 [B,2*latent]) teacher-forces
+    the two arg-max pools (parity tests at sizes where a 1-ulp score difference can flip an index); ``trace`` (a dict)
+    receives the pool scores ``dot1``/``dot2`` [B,C,N], the oracle's own arg-max ``idx1``/``idx2`` and the stage tensors."""
     B, N, _ = xyz.shape
     p = prefix
     x = xyz.transpose(2, 1).unsqueeze(1)                          # [B,1,3,N]
     f = _lin_leaky(sd, f"{p}.first_conv.0", x, training, new_stats)
     f = vn_linear(f, sd[f"{p}.first_conv.1.map_to_feat.weight"])
-    g = vn_max_pool(f, sd[f"{p}.maxpool1.map_to_dir.weight"]).unsqueeze(-1)
+    g, i1, dot1 = vn_max_pool(f, sd[f"{p}.maxpool1.map_to_dir.weight"], True, None if pool_idx is None else pool_idx[0])
+    g = g.unsqueeze(-1)
+    if trace is not None:
+        trace.update(f1=f.detach(), g1=g.detach(), dot1=dot1.detach(), idx1=dot1.detach().argmax(-1))
     f = torch.cat([g.expand(-1, -1, -1, N), f], dim=1)
     f = _lin_leaky(sd, f"{p}.second_conv.0", f, training, new_stats)
+    if trace is not None:
+        trace.update(f2=f.detach())
     f = vn_linear(f, sd[f"{p}.second_conv.1.map_to_feat.weight"])
-    g = vn_max_pool(f, sd[f"{p}.maxpool2.map_to_dir.weight"]).unsqueeze(-1)   # [B,C,3,1]
+    g, i2, dot2 = vn_max_pool(f, sd[f"{p}.maxpool2.map_to_dir.weight"], True, None if pool_idx is None else pool_idx[1])
+    g = g.unsqueeze(-1)                                                       # [B,C,3,1]
+    if trace is not None:
+        trace.update(dot2=dot2.detach(), idx2=dot2.detach().argmax(-1))
     h = vn_linear_and_leaky_relu(g, sd[f"{p}.mlp.0.linear.map_to_feat.weight"],
                                  sd[f"{p}.mlp.0.leaky_relu.map_to_dir.weight"])
     h = vn_linear_and_leaky_relu(h, sd[f"{p}.mlp.1.linear.map_to_feat.weight"],
@@ -200,19 +214,24 @@ def knn_torch(ref, query, k):
     return torch.sort(d, dim=-1, stable=True)[1][..., :k]
 
 
-def fps_torch(xyz, m):
+def fps_torch(xyz, m, skip_near_origin=True):
     """xyz [B,N,3] -> idx [B,m] (int64): iterative furthest point sampling starting at index 0, ties to the lowest index.
-    Stands for pointnet2_ops.furthest_point_sample (third party, source absent; models/dgcnn.py:210): PARITY UNPINNED."""
+    Stands for pointnet2_ops.furthest_point_sample (third party, source absent; models/dgcnn.py:210): PARITY UNPINNED.
+    ``skip_near_origin`` restates the one documented quirk of that package's published kernel
+    (furthest_point_sampling_kernel: ``if (mag <= 1e-3) continue;``): a candidate with x^2+y^2+z^2 <= 1e-3 is never selected and
+    its running distance is not updated; if every candidate is skipped the pick is index 0."""
     B, N, _ = xyz.shape
     idx = torch.zeros(B, m, dtype=torch.long)
     md = torch.full((B, N), 1e10, dtype=xyz.dtype)
+    skipped = (xyz * xyz).sum(-1) <= 1e-3 if skip_near_origin else torch.zeros(B, N, dtype=torch.bool)
     cur = torch.zeros(B, dtype=torch.long)
     ar = torch.arange(B)
     for r in range(1, m):
         c = xyz[ar, cur]                                          # [B,3]
         d = ((xyz - c[:, None, :]) ** 2).sum(-1)
-        md = torch.minimum(md, d)
-        cur = md.argmax(dim=1)                                    # first maximum
+        md = torch.where(skipped, md, torch.minimum(md, d))
+        cand = md.masked_fill(skipped, -1.0)
+        cur = cand.argmax(dim=1)                                  # first maximum; all skipped -> all -1 -> index 0
         idx[:, r] = cur
     return idx
 
@@ -501,6 +520,17 @@ def chamfer_torch(a, b, chunk=1024):
                 colidx = torch.where(better, cj, colidx)
         d1.append(torch.cat(v1)), i1.append(torch.cat(j1).int()), d2.append(colmin), i2.append(colidx.int())
     return torch.stack(d1), torch.stack(d2), torch.stack(i1), torch.stack(i2)
+
+
+def chamfer_from_idx(a, b, idx1, idx2):
+    """Differentiable squared NN distances given the nearest-neighbour indices (e.g. from oracle/chamfer_oracle.c, which
+    finds them ~50x faster than chamfer_torch): dist1[b,i] = |a[b,i] - b[b,idx1[b,i]]|^2 in the direct form of
+    chamfer3D.cu:33-36.  Its autograd gradient is chamfer3D.cu:155-174's (each pair contributes 2 g (x1 - x2) to both sides)."""
+    i1 = torch.as_tensor(idx1).long().unsqueeze(-1).expand(-1, -1, 3)
+    i2 = torch.as_tensor(idx2).long().unsqueeze(-1).expand(-1, -1, 3)
+    d1 = ((a - torch.gather(b, 1, i1)) ** 2).sum(-1)
+    d2 = ((b - torch.gather(a, 1, i2)) ** 2).sum(-1)
+    return d1, d2
 
 
 def cd_loss_l1(dist1, dist2):

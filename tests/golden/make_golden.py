@@ -773,6 +773,58 @@ def main_pointr():
     npz("pointr_small.npz", **out)
 
 
+def main_dcd():
+    """Pins C4 / §8f-1,2: the reference's OWN calc_cd / calc_dcd (utils/loss.py:14-74, the copy train.py:22 imports; it is
+    line-identical to metrics/loss.py:58-118) and fscore (extensions/ChamferDistancePytorch/fscore.py:3-16), imported and
+    run on CPU.  utils/loss.py imports the CUDA-only `chamfer3D.dist_chamfer_3D` at module top; the stand-in below routes
+    chamfer_3DDist to the reference's own pure-PyTorch equivalent chamfer_python.distChamfer (the relation its
+    unit_test.py:22-33 asserts), so every line of arithmetic that runs is the reference's."""
+    from oracle import vn_oracle as O
+    cp = _load(os.path.join(REF, "extensions/ChamferDistancePytorch/chamfer_python.py"), "ref_chamfer_python")
+    pkg, mod = types.ModuleType("chamfer3D"), types.ModuleType("chamfer3D.dist_chamfer_3D")
+
+    class chamfer_3DDist(torch.nn.Module):                      # dist_chamfer_3D.py:67-74: forward(a, b) -> d1, d2, i1, i2
+        def forward(self, a, b):
+            return cp.distChamfer(a, b)
+    mod.chamfer_3DDist = chamfer_3DDist
+    pkg.dist_chamfer_3D = mod
+    sys.modules["chamfer3D"], sys.modules["chamfer3D.dist_chamfer_3D"] = pkg, mod
+    L = _load(os.path.join(REF, "utils/loss.py"), "ref_utils_loss")
+    F = _load(os.path.join(REF, "extensions/ChamferDistancePytorch/fscore.py"), "ref_fscore")
+
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    # case a: prediction smaller than the ground truth (the train.py:154 call: coarse vs complete cloud);
+    # case b: clustered prediction (many ground-truth points share one nearest neighbour -> large bincounts), one sample
+    #         shifted far away so that its F-score is 0/0 -> 0 (fscore.py:15)
+    xa, ga = torch.rand(3, 200, 3, generator=g) - 0.5, torch.rand(3, 500, 3, generator=g) - 0.5
+    xb = (torch.rand(2, 16, 3, generator=g) - 0.5).repeat_interleave(8, dim=1) + 1e-3 * torch.randn(2, 128, 3, generator=g)
+    gb = torch.rand(2, 300, 3, generator=g) - 0.5
+    xb[1] += 5.0
+    for tag, x, gt in (("a", xa, ga), ("b", xb, gb)):
+        out[f"x_{tag}"], out[f"gt_{tag}"] = x, gt
+        for j, (alpha, lam, non_reg) in enumerate(((200, 0.5, False), (1000, 1, False), (40, 1, True))):
+            xr = x.clone().requires_grad_(True)
+            loss, cd_p, cd_t, d1, d2, i1, i2 = L.calc_dcd(xr, gt, alpha=alpha, n_lambda=lam, return_raw=True, non_reg=non_reg)
+            loss.sum().backward()
+            lo, po, to = O.calc_dcd_oracle(x, gt, alpha, lam, non_reg)
+            check(lo, loss.detach(), f"calc_dcd {tag}{j}", 1e-5), check(po, cd_p.detach(), "cd_p", 1e-5), check(to, cd_t.detach(), "cd_t", 1e-5)
+            out[f"opts_{tag}{j}"] = np.array([alpha, lam, float(non_reg)], np.float64)
+            out[f"loss_{tag}{j}"], out[f"gx_{tag}{j}"] = loss, xr.grad
+            if j == 0:
+                out[f"cd_p_{tag}"], out[f"cd_t_{tag}"] = cd_p, cd_t
+                out[f"d1_{tag}"], out[f"d2_{tag}"], out[f"i1_{tag}"], out[f"i2_{tag}"] = d1, d2, i1, i2
+                for th in (0.001, 0.0001, 0.01):
+                    f, p1, p2 = F.fscore(d1.detach(), d2.detach(), th)
+                    fo, q1, q2 = O.fscore_oracle(d1.detach(), d2.detach(), th)
+                    assert torch.equal(f, fo) and torch.equal(p1, q1) and torch.equal(p2, q2)
+                    out[f"f_{tag}_{th}"] = torch.stack([f, p1, p2])
+                res = L.calc_cd(x, gt, calc_f1=True, separate=True)            # the other branches of calc_cd
+                out[f"sep_p_{tag}"], out[f"sep_t_{tag}"], out[f"f1_{tag}"] = res[0], res[1], res[2]
+    assert float(out["f_b_0.001"][0, 1]) == 0.0                               # the 0/0 -> 0 branch is in the fixture
+    npz("dcd.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -786,3 +838,5 @@ if __name__ == "__main__":
         main_attention()
     if which in ("all", "baselines"):
         main_baselines()
+    if which in ("all", "dcd"):
+        main_dcd()

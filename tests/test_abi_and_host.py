@@ -126,3 +126,60 @@ def test_integration_md_stubs_declare_correct_argtypes():
     names = {_lib._vp: "_vp", _lib._i: "_i", _lib._ll: "_ll", _lib._f: "_f"}
     for fn, lst in declared.items():
         assert [x.strip() for x in lst.split(",")] == ["_vp"] + [names[t] for t in _lib._SIGNATURES[fn]], fn
+
+
+def test_resume_does_not_decay_the_learning_rate_twice():
+    """resuming at epoch >= 50 replayed StepLR on top of the already-decayed lr that load_state_dict restores
+    (0.64 x base instead of 0.8 x base at epoch 55).  lr(epoch) of a run resumed at 55 must equal the uninterrupted run's,
+    including across the next boundary at 100."""
+    from vn_pointcloudcompletion_amd.train import make_scheduler
+
+    def fresh():
+        prm = [torch.nn.Parameter(torch.zeros(3))]
+        return torch.optim.Adam(prm, lr=1e-3)
+    opt = fresh()
+    sch = make_scheduler(opt, 0)
+    lrs, saved = [], None
+    for epoch in range(0, 120):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        if epoch == 54:
+            saved = {k: (v if k != "param_groups" else [dict(g) for g in v]) for k, v in opt.state_dict().items()}
+    assert abs(lrs[49] - 1e-3) < 1e-12 and abs(lrs[50] - 0.8e-3) < 1e-12 and abs(lrs[100] - 0.64e-3) < 1e-12
+    opt2 = fresh()
+    opt2.load_state_dict(saved)                                  # as train.py does on --resume (epoch 54 saved -> start at 55)
+    sch2 = make_scheduler(opt2, 55)
+    assert abs(sch2.get_last_lr()[0] - lrs[55]) < 1e-12
+    for epoch in range(55, 120):
+        assert abs(opt2.param_groups[0]["lr"] - lrs[epoch]) < 1e-12, epoch
+        opt2.step()
+        sch2.step()
+
+
+def test_sharded_batch_sampler_covers_every_sample_once_with_gradient_weights():
+    from vn_pointcloudcompletion_amd.distributed import ShardedBatchSampler
+    n, bs, world = 45, 12, 8                                    # the reference's batch_size 12 on 8 GPUs; last batch has 9
+    ranks = [ShardedBatchSampler(n, bs, shuffle=True, seed=3, rank=r, world=world, mode="train") for r in range(world)]
+    for s in ranks:
+        s.set_epoch(7)
+    per_rank = [list(s) for s in ranks]
+    assert all(len(b) == len(ranks[0]) == 4 for b in per_rank)                       # same number of steps on every rank
+    glob = ranks[0].global_batches()
+    for i, g in enumerate(glob):
+        shards = [per_rank[r][i] for r in range(world)]
+        assert sum(shards, []) == g                                                  # contiguous slices, in rank order
+        # all-reduce AVERAGE of weight * (local mean) == global-batch mean, for any per-sample values
+        vals = {j: float(j * j % 17) for j in g}
+        avg = sum(ranks[r].weight(i) * (sum(vals[j] for j in shards[r]) / len(shards[r])) for r in range(world)) / world
+        assert abs(avg - sum(vals.values()) / len(g)) < 1e-9
+    assert sorted(sum(glob, [])) == list(range(n))
+    ranks[0].set_epoch(8)
+    assert ranks[0].global_batches() != glob                                         # a new order every epoch, same on all ranks
+    # a batch smaller than the world: replicated in train mode (aligned collectives), dealt out once in eval mode
+    tr = [list(ShardedBatchSampler(3, 12, False, rank=r, world=8, mode="train")) for r in range(8)]
+    assert all(t == [[0, 1, 2]] for t in tr)
+    ev = [list(ShardedBatchSampler(3, 12, False, rank=r, world=8, mode="eval")) for r in range(8)]
+    assert sorted(sum(sum(ev, []), [])) == [0, 1, 2] and [len(ShardedBatchSampler(3, 12, False, rank=r, world=8, mode="eval")) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]
+    one = ShardedBatchSampler(10, 4, False, rank=0, world=1)
+    assert list(one) == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]] and one.weight(2) == 1.0

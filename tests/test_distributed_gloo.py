@@ -74,8 +74,19 @@ def _worker(rank, world, port, q):
         ok = ok and torch.allclose(fb.flat_grad, exp, atol=1e-6) and fb.view(fb.flat_grad, 1).abs().sum().item() == 0.0
         if step == 0:
             ok = ok and launched_in_backward == 0 and red.live is not None and len(red.live) == 2
+            # the never-used parameter has left the wire: two buckets, (24 + 4) floats instead of 44
+            ok = ok and len(red.buckets) == 2 and red.wire_bytes() == (24 + 4) * 4
         else:
             ok = ok and launched_in_backward >= 1                   # model[2]'s bucket left during backward
+    # the never-used parameter suddenly receives a gradient: every rank completes the step's collectives, then raises
+    fb.zero_grad()
+    model[2](model[1](model[0](torch.randn(4, 6)))).sum().backward()
+    try:
+        D.allreduce_gradients(Holder2)
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "set of parameters" in str(e)
+    D.barrier()                                                     # nobody is stuck inside an all-reduce
     red.remove()
     q.put((rank, ok, w0.sum().item(), mx))
     D.barrier()
@@ -97,3 +108,22 @@ def test_two_rank_gloo_data_parallel():
     assert all(o[1] for o in out)
     assert abs(out[0][2] - out[1][2]) < 1e-7                        # same weights on both ranks
     assert out[0][3] == out[1][3] == 2.0
+
+
+def test_bucket_cut_skips_never_live_ranges():
+    """Bucket layout of OverlappedGradReducer without a process group: large never-live ranges leave the wire, small ones
+    ride along inside a bucket, never-live parameters at either end are trimmed."""
+    from vn_pointcloudcompletion_amd import distributed as D
+    from vn_pointcloudcompletion_amd.optim import FlatBuffers
+    sizes = [100, 8, 100, 5000, 100, 100, 4000]                     # elements; [1] small dead gap, [3] and [6] large dead ranges
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+    fb = FlatBuffers(params)
+    red = D.OverlappedGradReducer(fb, bucket_bytes=1000, gap_bytes=64)
+    assert red.wire_bytes() == fb.numel * 4                         # before the first backward everything travels
+    red.live = {id(params[i]) for i in (0, 2, 4, 5)}
+    red._cut_buckets()
+    spans = [(lo_i, hi_i) for lo_i, hi_i, _, _ in red.buckets]
+    assert spans == [(4, 6), (0, 3)]                                # [6] trimmed, [3] cut out, [1] (32 B) rides in a bucket
+    assert red.wire_bytes() == (200 + 208) * 4
+    assert set(red.bucket_of) == {id(params[i]) for i in (0, 1, 2, 4, 5)}
+    red.remove()

@@ -32,6 +32,47 @@ def test_emd_vs_c_oracle(lib_built, B, n, m):
     assert relerr(ar.grad, g1) < 5e-4 and relerr(br.grad, g2) < 5e-4
 
 
+def _approxmatch(a, b):
+    """match [B, m, n] straight from the C ABI (the tensor emd_cuda.approxmatch_forward returns, emd.cpp:8-10)."""
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    B, n, _ = a.shape
+    m = b.shape[1]
+    match = torch.empty((B, m, n), device="cuda", dtype=torch.float32)
+    temp = torch.empty((B, (n + m) * 2), device="cuda", dtype=torch.float32)
+    call("vnp_emd_approxmatch", B, n, m, ptr(a), ptr(b), ptr(match), ptr(temp))
+    return match
+
+
+@pytest.mark.parametrize("n,m", [(1024, 1024), (512, 1024), (1024, 256)])
+def test_emd_match_invariants(lib_built, n, m):
+    """EMD parity is UNPINNED (no reference fixture, nvcc absent), so beside the C restatement the transport plan is held to
+    the invariants the algorithm of emd_kernel.cu:25-158 guarantees by construction, at the size train.py:148-150 uses:
+      * match >= 0;
+      * each xyz1 point ships multiL = max(1, m/n) units and each xyz2 point receives multiR = max(1, n/m) units — after
+        the final level-0 pass (exp(0) = 1: all remaining mass is spread) both marginals are met to 1e-3;
+      * relabelling the points of either cloud permutes the plan and leaves the cost unchanged (up to fp32 summation
+        order: 1e-4 relative on the plan's marginals and on the cost)."""
+    from vn_pointcloudcompletion_amd.emd import EarthMoverDistance
+    g = torch.Generator().manual_seed(n * 3 + m)
+    a = (torch.rand(2, n, 3, generator=g) - 0.5).cuda()
+    b = (torch.rand(2, m, 3, generator=g) - 0.5).cuda()
+    match = _approxmatch(a, b)
+    multiL = 1.0 if n >= m else float(m // n)
+    multiR = float(n // m) if n >= m else 1.0
+    assert match.min().item() >= 0.0 and torch.isfinite(match).all()
+    assert (match.sum(1) - multiL).abs().max().item() < 1e-3            # shipped by each xyz1 point (sum over xyz2)
+    assert (match.sum(2) - multiR).abs().max().item() < 1e-3            # received by each xyz2 point
+    pa, pb = torch.randperm(n, generator=g).cuda(), torch.randperm(m, generator=g).cuda()
+    match_p = _approxmatch(a[:, pa].contiguous(), b[:, pb].contiguous())
+    assert (match_p - match[:, pb][:, :, pa]).abs().max().item() < 1e-4 * max(multiL, multiR)
+    c0 = EarthMoverDistance()(a, b)
+    c1 = EarthMoverDistance()(a[:, pa].contiguous(), b[:, pb].contiguous())
+    assert relerr(c1, c0) < 1e-4
+    # the cost is the plan's transport cost with SQUARED distances: sum_lk match[l,k] |xyz1_k - xyz2_l|^2  (emd_kernel.cu:224-225)
+    d2 = (a[:, None, :, :] - b[:, :, None, :]).pow(2).sum(-1)
+    assert relerr(c0, (match.double() * d2.double()).sum((1, 2))) < 1e-4
+
+
 def test_emd_surface(lib_built):
     from vn_pointcloudcompletion_amd import _lib
     from vn_pointcloudcompletion_amd.emd import EarthMoverDistance

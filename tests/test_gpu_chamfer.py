@@ -118,6 +118,38 @@ def test_dcd_and_fscore_match_oracle(lib_built):
                / ((d2[0] < 0.01).float().mean() + (d1[0] < 0.01).float().mean())).item()) < 1e-6
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_dcd_and_fscore_match_reference_golden(lib_built, tag):
+    """PINNED: tests/golden/dcd.npz holds the outputs of the reference's own calc_cd / calc_dcd (utils/loss.py:14-74) and
+    fscore (fscore.py:3-16), imported and run by make_golden.py::main_dcd.  Tolerance 2e-6 absolute on losses / distances
+    (the reference's distChamfer forms |x|^2+|y|^2-2xy in fp64; ours is the direct fp32 form), indices exact."""
+    from vn_pointcloudcompletion_amd import loss, metric
+    G = load_golden("dcd.npz")
+    x, gt = t(G[f"x_{tag}"]), t(G[f"gt_{tag}"])
+    for j in range(3):
+        alpha, lam, non_reg = G[f"opts_{tag}{j}"]
+        xr = x.clone().requires_grad_(True)
+        res = loss.calc_dcd(xr, gt, alpha=float(alpha), n_lambda=float(lam), return_raw=True, non_reg=bool(non_reg))
+        assert len(res) == 7
+        assert np.abs(res[0].detach().cpu().numpy() - G[f"loss_{tag}{j}"]).max() < 2e-6, j
+        res[0].sum().backward()
+        ref = G[f"gx_{tag}{j}"]
+        assert np.abs(xr.grad.cpu().numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max()), j
+        if j == 0:
+            assert np.abs(res[1].detach().cpu().numpy() - G[f"cd_p_{tag}"]).max() < 2e-6
+            assert np.abs(res[2].detach().cpu().numpy() - G[f"cd_t_{tag}"]).max() < 2e-6
+            assert np.abs(res[3].detach().cpu().numpy() - G[f"d1_{tag}"]).max() < 2e-6
+            assert np.abs(res[4].detach().cpu().numpy() - G[f"d2_{tag}"]).max() < 2e-6
+            assert np.array_equal(res[5].cpu().numpy(), G[f"i1_{tag}"]) and np.array_equal(res[6].cpu().numpy(), G[f"i2_{tag}"])
+    d1, d2 = t(G[f"d1_{tag}"]), t(G[f"d2_{tag}"])
+    for th in (0.001, 0.0001, 0.01):
+        f, p1, p2 = metric.fscore(d1, d2, th)
+        assert np.array_equal(torch.stack([f, p1, p2]).cpu().numpy(), G[f"f_{tag}_{th}"]), th       # 0/0 -> 0 included (case b)
+    sep_p, sep_t, f1 = loss.calc_cd(x, gt, calc_f1=True, separate=True)
+    assert np.abs(sep_p.cpu().numpy() - G[f"sep_p_{tag}"]).max() < 2e-6 and np.abs(sep_t.cpu().numpy() - G[f"sep_t_{tag}"]).max() < 2e-6
+    assert np.abs(f1.cpu().numpy() - G[f"f1_{tag}"]).max() <= 1.0 / 128 + 1e-7     # threshold 1e-4 sits on distance noise: one point may flip
+
+
 # ------------------------------------------------------------------------------------------- pruned search (dense clouds)
 def _both_paths(a, b):
     """(brute-force kernel outputs, pruned kernel outputs) through the C ABI, same inputs."""

@@ -57,6 +57,33 @@ def test_fps_matches_oracle(D):
     assert np.array_equal(ops.fps_indices(x[:, :7].cuda(), 7).cpu().numpy(), O.fps_torch(x[:, :7], 7).numpy())
 
 
+def test_fps_pointnet2_near_origin_convention(lib_built):
+    """pointnet2_ops' kernel never selects a candidate with |p|^2 <= 1e-3 (default here; VNP_FPS_PLAIN=1 / skip_near_origin=False
+    is plain FPS).  Both conventions against the oracle's restatement, on clouds seeded with near-origin points."""
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd import ops
+    assert ops.FPS_SKIP_NEAR_ORIGIN is True
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(3, 2048, 3, generator=g) - 0.5
+    x[:, 5::97] *= 0.04                                           # ~21 points per cloud inside the r = 0.0316 ball
+    x[1, 0] = 0.0                                                 # the start point itself is near the origin: still sample 0
+    near = (x * x).sum(-1) <= 1e-3
+    assert near.sum().item() >= 40
+    for m in (224, 1024, 2048):
+        skip = ops.fps_indices(x.cuda(), m).cpu().long()
+        plain = ops.fps_indices(x.cuda(), m, skip_near_origin=False).cpu().long()
+        assert torch.equal(skip, O.fps_torch(x, m, skip_near_origin=True)), m
+        assert torch.equal(plain, O.fps_torch(x, m, skip_near_origin=False)), m
+        picked_near = torch.gather(near, 1, skip)
+        picked_near[:, 0] = False                                 # sample 0 is index 0 by definition
+        n_valid = (~near).sum(1)
+        for b in range(3):                                        # once the far candidates are exhausted the kernel yields index 0
+            assert not picked_near[b, :min(m, int(n_valid[b]))].any() or bool(near[b, 0])
+        assert torch.gather(near, 1, plain)[:, 1:].any()          # plain FPS does pick them (m >= 224 of 2048)
+    tiny = torch.full((1, 64, 3), 0.01)                           # every candidate skipped: the pick is index 0 throughout
+    assert torch.equal(ops.fps_indices(tiny.cuda(), 8).cpu().long(), torch.zeros(1, 8, dtype=torch.long))
+
+
 def test_gather_and_edge_ops(lib_built):
     from vn_pointcloudcompletion_amd import ops
     P, k, W = 50, 4, 70

@@ -107,12 +107,15 @@ def test_train_step_full_size_and_adam_matches_torch(net):
     assert opt2.flat_buffers[0].step == 1
 
 
-@pytest.mark.parametrize("enc,dec,B,latent,loss", [("vn_dgcnn_fps", "vn_foldingnet", 4, 512, "cd"),
-                                                   ("vn_pointnet", "attention_vn_foldingnet", 2, 2048, "emd"),
-                                                   ("vn_pointr", "vn_foldingnet", 2, 1024, "cd")])
-def test_other_configs_step_at_full_resolution(lib_built, enc, dec, B, latent, loss):
-    """BASELINE configs 3, 4, 5 at their full point counts (2048 -> 1024/1248 coarse -> 16384/19968 dense; small batch):
-    one complete training step runs, the loss is finite and every live parameter gets a finite gradient."""
+@pytest.mark.parametrize("enc,dec,B,latent,loss,ceiling_ms", [("vn_dgcnn_fps", "vn_foldingnet", 32, 512, "cd", 90.0),
+                                                              ("vn_pointnet", "attention_vn_foldingnet", 16, 2048, "emd", 160.0),
+                                                              ("vn_pointr", "vn_foldingnet", 32, 1024, "cd", 170.0)])
+def test_other_configs_step_at_full_batch_and_resolution(lib_built, enc, dec, B, latent, loss, ceiling_ms):
+    """BASELINE configs 3, 4, 5 at their FULL sizes on one GPU (config 3: B = 32, k = 20; config 4: B = 16 with the EMD coarse
+    loss; config 5: the per-GPU shard B = 32 of the B = 256 job, 2048 -> 1248 -> 19968): complete training steps run, the loss
+    is finite and decreases over a few steps on a fixed batch, every live parameter gets a finite gradient, and the step time
+    stays under a loose ceiling (~3x the measured 25 / 51 / 55 ms of DESIGN.md §6 — a regression tripwire, not a benchmark)."""
+    import time
     from vn_pointcloudcompletion_amd.model import PCNNet
     from vn_pointcloudcompletion_amd.optim import FusedAdam
     from vn_pointcloudcompletion_amd.train import train_step
@@ -125,7 +128,20 @@ def test_other_configs_step_at_full_resolution(lib_built, enc, dec, B, latent, l
     g = torch.Generator().manual_seed(2)
     p = (torch.rand(B, 2048, 3, generator=g) - 0.5).cuda()
     gt = (torch.rand(B, md, 3, generator=g) - 0.5).cuda()
-    loss_t, _, _ = train_step(cfg, net, opt, p, gt)
-    assert torch.isfinite(loss_t).item()
+    first, _, _ = train_step(cfg, net, opt, p, gt)
+    assert torch.isfinite(first).item()
     assert torch.isfinite(opt.flat_buffers[0].flat_grad).all().item()
     assert opt.flat_buffers[0].flat_grad.abs().sum().item() > 0
+    train_step(cfg, net, opt, p, gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        last, _, _ = train_step(cfg, net, opt, p, gt)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 4 * 1e3
+    print(f"{enc}+{dec} B={B} 2048->{md}: {ms:.1f} ms/step, loss {first.item():.4f} -> {last.item():.4f}, "
+          f"peak {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    assert torch.isfinite(last).item() and last.item() < first.item()
+    assert ms < ceiling_ms, ms
+    del net, opt
+    torch.cuda.empty_cache()

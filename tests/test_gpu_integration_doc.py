@@ -42,7 +42,8 @@ def test_integration_stubs_run_and_agree(lib_built):
     assert torch.allclose(ga, ar.grad, rtol=1e-5, atol=1e-7) and torch.allclose(gb, br.grad, rtol=1e-5, atol=1e-7)
     # EMD: the three emd_cuda functions
     x, y = a[:, :256].contiguous(), b[:, :256].contiguous()
-    match, _ = ns["emd_cuda"].approxmatch_forward(x, y)
+    match = ns["emd_cuda"].approxmatch_forward(x, y)
+    assert torch.is_tensor(match) and match.shape == (2, 256, 256)       # `match` only, as emd.cpp:8-10
     cost = ns["emd_cuda"].matchcost_forward(x, y, match)
     ref = EarthMoverDistanceFunction.apply(x, y)
     assert torch.allclose(cost, ref, rtol=1e-5)
@@ -53,3 +54,77 @@ def test_integration_stubs_run_and_agree(lib_built):
     assert idx.shape == (2, 8, 500) and torch.equal(idx.transpose(1, 2).int(), ops.knn_indices(a, b, 8))
     fps = ns["furthest_point_sample"](a, 64)
     assert torch.equal(fps, ops.fps_indices(a, 64))
+
+
+def test_reference_wrappers_run_unchanged_on_the_stub_modules(lib_built):
+    """Drop-in proof at the pybind boundary: the call sequences of the reference's two autograd wrappers —
+    extensions/earth_movers_distance/emd.py:6-43 and extensions/chamfer_distance/chamfer_distance.py:29-84 — re-typed here
+    statement for statement (caller-allocated, zero-filled outputs created on the CPU and moved; the tuple-free `match`),
+    bound to INTEGRATION.md's stub modules instead of `emd_cuda` / `chamfer_3D`, against this package's own operators."""
+    from vn_pointcloudcompletion_amd import ops
+    from vn_pointcloudcompletion_amd.emd import EarthMoverDistance as OurEMD
+    ns = _doc_namespace()
+    emd_cuda, chamfer_3D = ns["emd_cuda"], ns["chamfer_3D"]
+
+    class EarthMoverDistanceFunction(torch.autograd.Function):          # emd.py:6-22
+        @staticmethod
+        def forward(ctx, xyz1, xyz2):
+            xyz1 = xyz1.contiguous()
+            xyz2 = xyz2.contiguous()
+            assert xyz1.is_cuda and xyz2.is_cuda
+            match = emd_cuda.approxmatch_forward(xyz1, xyz2)
+            cost = emd_cuda.matchcost_forward(xyz1, xyz2, match)
+            ctx.save_for_backward(xyz1, xyz2, match)
+            return cost
+
+        @staticmethod
+        def backward(ctx, grad_cost):
+            xyz1, xyz2, match = ctx.saved_tensors
+            grad_cost = grad_cost.contiguous()
+            grad_xyz1, grad_xyz2 = emd_cuda.matchcost_backward(grad_cost, xyz1, xyz2, match)
+            return grad_xyz1, grad_xyz2
+
+    class chamfer_3DFunction(torch.autograd.Function):                  # chamfer_distance.py:29-71
+        @staticmethod
+        def forward(ctx, xyz1, xyz2):
+            batchsize, n, _ = xyz1.size()
+            _, m, _ = xyz2.size()
+            device = xyz1.device
+            dist1 = torch.zeros(batchsize, n).to(device)
+            dist2 = torch.zeros(batchsize, m).to(device)
+            idx1 = torch.zeros(batchsize, n).type(torch.IntTensor).to(device)
+            idx2 = torch.zeros(batchsize, m).type(torch.IntTensor).to(device)
+            torch.cuda.set_device(device)
+            chamfer_3D.forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
+            ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+            return dist1, dist2, idx1, idx2
+
+        @staticmethod
+        def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
+            xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+            graddist1 = graddist1.contiguous()
+            graddist2 = graddist2.contiguous()
+            device = graddist1.device
+            gradxyz1 = torch.zeros(xyz1.size()).to(device)
+            gradxyz2 = torch.zeros(xyz2.size()).to(device)
+            chamfer_3D.backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+            return gradxyz1, gradxyz2
+
+    g = torch.Generator().manual_seed(3)
+    a, b = (torch.rand(2, 512, 3, generator=g) - 0.5).cuda(), (torch.rand(2, 384, 3, generator=g) - 0.5).cuda()
+    # EMD: cost and both gradients equal this package's operator (same kernels underneath)
+    a1, b1, a2, b2 = (v.clone().requires_grad_(True) for v in (a, b, a, b))
+    w = torch.tensor([0.7, 1.3], device="cuda")
+    c1 = EarthMoverDistanceFunction.apply(a1, b1)
+    (c1 * w).sum().backward()
+    c2 = OurEMD()(a2, b2)
+    (c2 * w).sum().backward()
+    assert torch.allclose(c1, c2, rtol=1e-5) and torch.allclose(a1.grad, a2.grad, rtol=1e-4, atol=1e-8) and torch.allclose(b1.grad, b2.grad, rtol=1e-4, atol=1e-8)
+    # Chamfer: the reference's mean-of-distances use (metrics/loss.py:42-43) through its wrapper
+    a1, b1, a2, b2 = (v.clone().requires_grad_(True) for v in (a, b, a, b))
+    d1, d2, i1, i2 = chamfer_3DFunction.apply(a1, b1)
+    (d1.mean() + d2.mean()).backward()
+    e1, e2, j1, j2 = ops.ChamferFn.apply(a2, b2)
+    (e1.mean() + e2.mean()).backward()
+    assert torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
+    assert torch.allclose(a1.grad, a2.grad, rtol=1e-5, atol=1e-9) and torch.allclose(b1.grad, b2.grad, rtol=1e-5, atol=1e-9)

@@ -236,3 +236,23 @@ def test_baseline_oracles_shapes_and_determinism():
     sd = {"encoder." + k: v for k, v in enc.state_dict().items()}
     coarse, g = O.dgcnn_fps_forward(sd, torch.as_tensor(G["enc.x"]), True)
     assert np.abs(coarse.numpy() - G["enc.coarse"]).max() < 1e-4 and np.abs(g.numpy() - G["enc.global"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_dcd_and_fscore_oracle_vs_reference_golden(tag):
+    """oracle.calc_dcd_oracle / fscore_oracle against the outputs of the reference's utils/loss.py + fscore.py (dcd.npz)."""
+    G = load_golden("dcd.npz")
+    x, gt = torch.as_tensor(G[f"x_{tag}"]), torch.as_tensor(G[f"gt_{tag}"])
+    for j in range(3):
+        alpha, lam, non_reg = G[f"opts_{tag}{j}"]
+        xr = x.clone().requires_grad_(True)
+        lo, po, to = O.calc_dcd_oracle(xr, gt, float(alpha), float(lam), bool(non_reg))
+        assert np.abs(lo.detach().numpy() - G[f"loss_{tag}{j}"]).max() < 2e-6
+        lo.sum().backward()
+        ref = G[f"gx_{tag}{j}"]
+        assert np.abs(xr.grad.numpy() - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
+        if j == 0:
+            assert np.abs(po.detach().numpy() - G[f"cd_p_{tag}"]).max() < 2e-6 and np.abs(to.detach().numpy() - G[f"cd_t_{tag}"]).max() < 2e-6
+    d1, d2 = torch.as_tensor(G[f"d1_{tag}"]), torch.as_tensor(G[f"d2_{tag}"])
+    for th in (0.001, 0.0001, 0.01):
+        assert np.array_equal(torch.stack(O.fscore_oracle(d1, d2, th)).numpy(), G[f"f_{tag}_{th}"])

@@ -412,12 +412,9 @@ extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float*
     float4* b2 = (float4*)w;
     hipError_t e = hipMemsetAsync(flag, 0, 256, st);
     if (e != hipSuccess) return (int)e;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute((const void*)vnp_chamfer_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHP_BINS * 4);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};
+    e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_chamfer_bin_kernel, CHP_BINS * 4);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B), dim3(1024), (size_t)CHP_BINS * 4, st, xyz1, n, s1, b1, flag);
     hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B), dim3(1024), (size_t)CHP_BINS * 4, st, xyz2, m, s2, b2, flag);
     hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,

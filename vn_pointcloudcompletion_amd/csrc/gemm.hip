@@ -19,27 +19,29 @@
 // four consecutive K values come from ONE 16-byte LDS read.
 #include "gemm_split_kernel.h"
 
-static int g_vnp_gemm_mode = 0;          // 0 = bf16x3 split (fp32-grade), 1 = fp32 MFMA
+// 0 = bf16x3 split (fp32-grade), 1 = fp32 MFMA.  The library's only process-wide setting: an atomic switch that every vnp_gemm*
+// call reads once on entry (a concurrent vnp_gemm_set_mode affects later calls, never a launch in progress).
+static std::atomic<int> g_vnp_gemm_mode{0};
 
 extern "C" int vnp_gemm_set_mode(int mode)
 {
     if (mode != 0 && mode != 1) return VNP_EINVAL;
-    g_vnp_gemm_mode = mode;
+    g_vnp_gemm_mode.store(mode, std::memory_order_relaxed);
     return 0;
 }
 
-extern "C" int vnp_gemm_get_mode(void) { return g_vnp_gemm_mode; }
+extern "C" int vnp_gemm_get_mode(void) { return g_vnp_gemm_mode.load(std::memory_order_relaxed); }
 
 static int vnp_num_cus()
 {
-    static int n = 0;
+    static std::atomic<int> cached{0};             // every GPU of a node is the same part: one value serves all devices
+    int n = cached.load(std::memory_order_relaxed);
     if (!n) {
         int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n = prop.multiProcessorCount;
-        else
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
+        cached.store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -194,7 +196,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
                          (bsa % 4 == 0) && (bsb % 4 == 0);
     const bool fast = aligned && (M % bm == 0) && (N % 128 == 0) && (K % BK == 0) && K > 0;
     // resident workgroups per CU: 2 for the 192-row tiles (~240 VGPRs), 3 for the aligned 128-row weight-gradient kernel (151)
-    const bool split = g_vnp_gemm_mode == 0;
+    const bool split = vnp_gemm_get_mode() == 0;
     const long long cap = (long long)vnp_num_cus() * ((!split && bm == 128 && fast && op_b == 1) ? 3 : 2);
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
 #define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                                    \
@@ -261,7 +263,7 @@ extern "C" int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, cons
 {
     if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0) return VNP_EINVAL;
     const long long M = G * gs * 3;
-    if (g_vnp_gemm_mode != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || M > 2147483647LL ||
+    if (vnp_gemm_get_mode() != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || M > 2147483647LL ||
         (uintptr_t)x % 16 || (uintptr_t)Wcat % 16 || G > 65535)
         return VNP_EINVAL;
     const long long nslot = G * (gs / 32) * (long long)C;
@@ -323,7 +325,7 @@ extern "C" int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const floa
                                  const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws)
 {
     if (!A || !B || !C || !part1024 || !ws || M <= 0 || N <= 0 || K <= 0 || stats_cols <= 0) return VNP_EINVAL;
-    if (g_vnp_gemm_mode != 0 || M % 3072 || N % 128 || K % 32 || stats_cols % 64 || stats_cols > N || lda % 4 || ldb % 4 ||
+    if (vnp_gemm_get_mode() != 0 || M % 3072 || N % 128 || K % 32 || stats_cols % 64 || stats_cols > N || lda % 4 || ldb % 4 ||
         (uintptr_t)A % 16 || (uintptr_t)B % 16 || (bias && rows_per_group <= 0) || (bias && rows_per_group % 3))
         return VNP_EINVAL;
     VnpGemmArgs p{};

@@ -206,12 +206,9 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
     if (!ref || !qry || !idx || !ws || B <= 0 || D <= 0 || Nr <= 0 || Nq <= 0 || k <= 0 || k > Nr || B > 65535 || Nr > 16384) return VNP_EINVAL;
     if (vnp_cdiv(Nq, KD_T) > 65535 || (long long)B * Nq > 2147483647LL) return VNP_EINVAL;
     hipLaunchKernelGGL(vnp_knn_dist_kernel, dim3(vnp_cdiv(Nr, KD_T), vnp_cdiv(Nq, KD_T), B), dim3(256), 0, st, ref, Nr, qry, Nq, D, ws);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)vnp_knn_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> lds_ok{0};
+    hipError_t e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_knn_select_kernel, 16384 * 4);
+    if (e != hipSuccess) return (int)e;
     const dim3 rows((unsigned)((long long)B * Nq));
     if (Nr <= 512)       hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<8>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
     else if (Nr <= 1024) hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<16>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
@@ -250,7 +247,10 @@ extern "C" int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, c
 #define FPS_MAX_PER_THREAD 16   // N <= 16384
 // FPS_PER_THREAD = ceil(N / 1024) rounded up to 2, 4, 8 or 16: the per-round update loop is fully unrolled, so a 2048-point
 // cloud must not pay for 16 slots
-template <int FPS_PER_THREAD>
+// SKIP: the convention of the package the reference calls (pointnet2_ops furthest_point_sampling_kernel: `if (mag <= 1e-3)
+// continue;`): a candidate with |p|^2 <= 1e-3 is neither selected nor has its running distance updated; point 0 is still the
+// first sample, and if every candidate is skipped the pick is index 0.
+template <int FPS_PER_THREAD, bool SKIP>
 __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __restrict__ xyz, int N, int M, int* __restrict__ out)
 {
     __shared__ float sv[FPS_THREADS / 64];
@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __res
         const int i = tid + u * FPS_THREADS;
         if (i < N) { px[u] = p[i * 3]; py[u] = p[i * 3 + 1]; pz[u] = p[i * 3 + 2]; md[u] = 1e10f; }
         else { px[u] = py[u] = pz[u] = 0.f; md[u] = -1.f; }
+        if (SKIP && i < N && px[u] * px[u] + py[u] * py[u] + pz[u] * pz[u] <= 1e-3f) md[u] = -1.f;     // never a candidate
     }
     int cur = 0;
     if (tid == 0) out[(size_t)b * M] = 0;
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __res
             if (i < N) {
                 const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
                 const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                md[u] = fminf(md[u], d);
+                md[u] = fminf(md[u], d);                          // a skipped point stays at -1 (d >= 0)
                 if (md[u] > best) { best = md[u]; bi = i; }       // ascending i within a thread: first max kept
             }
         }
@@ -294,22 +295,35 @@ __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __res
                 const float ov = __shfl_xor(v, o); const int oi = __shfl_xor(i, o);
                 if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
             }
-            if (tid == 0) { pick = i; out[(size_t)b * M + r] = i; }
+            if (tid == 0) { if (i == 0x7fffffff) i = 0; pick = i; out[(size_t)b * M + r] = i; }
         }
         __syncthreads();
         cur = pick;
     }
 }
 
-// furthest_point_sample(xyz[B,N,3], M) -> idx [B][M]; N <= 16384
+template <bool SKIP>
+static int vnp_fps_launch(hipStream_t st, int B, int N, const float* xyz, int M, int* idx)
+{
+    if (N <= 2 * FPS_THREADS)      hipLaunchKernelGGL((vnp_fps_kernel<2, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    else if (N <= 4 * FPS_THREADS) hipLaunchKernelGGL((vnp_fps_kernel<4, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    else if (N <= 8 * FPS_THREADS) hipLaunchKernelGGL((vnp_fps_kernel<8, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    else                           hipLaunchKernelGGL((vnp_fps_kernel<16, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
+    return vnp_last_error();
+}
+
+// furthest_point_sample(xyz[B,N,3], M) -> idx [B][M]; N <= 16384.  Plain FPS: every point is a candidate.
 extern "C" int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx)
 {
     if (!xyz || !idx || B <= 0 || N <= 0 || M <= 0 || M > N || N > FPS_THREADS * FPS_MAX_PER_THREAD) return VNP_EINVAL;
-    if (N <= 2 * FPS_THREADS)      hipLaunchKernelGGL(vnp_fps_kernel<2>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
-    else if (N <= 4 * FPS_THREADS) hipLaunchKernelGGL(vnp_fps_kernel<4>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
-    else if (N <= 8 * FPS_THREADS) hipLaunchKernelGGL(vnp_fps_kernel<8>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
-    else                           hipLaunchKernelGGL(vnp_fps_kernel<16>, dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
-    return vnp_last_error();
+    return vnp_fps_launch<false>(st, B, N, xyz, M, idx);
+}
+
+// flags bit 0 (VNP_FPS_SKIP_NEAR_ORIGIN): pointnet2_ops' convention — candidates with |p|^2 <= 1e-3 are never selected
+extern "C" int vnp_fps_ex(hipStream_t st, int B, int N, const float* xyz, int M, int* idx, int flags)
+{
+    if (!xyz || !idx || B <= 0 || N <= 0 || M <= 0 || M > N || N > FPS_THREADS * FPS_MAX_PER_THREAD || (flags & ~1)) return VNP_EINVAL;
+    return (flags & 1) ? vnp_fps_launch<true>(st, B, N, xyz, M, idx) : vnp_fps_launch<false>(st, B, N, xyz, M, idx);
 }
 
 // ------------------------------------------------------------------------------------------------ gathers

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define VNP_OK 0
 #define VNP_EINVAL (-1)
@@ -15,6 +16,20 @@ static inline int vnp_last_error() {
 }
 
 static inline int vnp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute belongs to the current device's code object).  Thread-safe
+// and re-entrant: the call is idempotent, `done` (one bit per device ordinal) only avoids repeating it on every launch.
+static inline hipError_t vnp_allow_dynamic_lds(std::atomic<unsigned long long>& done, const void* kernel, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 typedef float vnp_f4 __attribute__((ext_vector_type(4)));
 typedef float vnp_f16 __attribute__((ext_vector_type(16)));

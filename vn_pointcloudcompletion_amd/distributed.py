@@ -18,6 +18,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 # VNP_FORCE_COLLECTIVES=1: create the process group and issue every collective even when there is a single rank — the only way
@@ -77,6 +78,71 @@ def shard_batch(global_batch: int):
     return r * per, (r + 1) * per
 
 
+class ShardedBatchSampler(torch.utils.data.Sampler):
+    """Batch sampler of the data-parallel loops: the GLOBAL batches are those of a single-process run (``batch_size`` indices
+    in an order derived from ``seed + epoch``, identical on every rank), and each rank yields only ITS contiguous slice of
+    each global batch — so a rank reads and decodes 1/world of the data instead of the whole batch.
+
+    A global batch of b samples is split as evenly as b allows (rank r gets [r*b//world, (r+1)*b//world): the reference's
+    batch_size 12 on 8 GPUs gives shards of 1 or 2 samples); ``weight(i)`` is the factor a rank must apply to its mean loss of
+    batch i so that the all-reduce AVERAGE of the gradients equals the gradient of the global-batch mean.  When a batch has
+    fewer samples than ranks (a short final batch), ``mode='train'`` replicates it on every rank (weight 1: same step on all
+    ranks, the collectives stay aligned) and ``mode='eval'`` gives it to the first ranks only (no collectives inside an
+    evaluation loop, sums are all-reduced once at the end).
+    """
+
+    def __init__(self, n, batch_size, shuffle, seed=0, rank=None, world=None, mode="train"):
+        self.n, self.batch_size, self.shuffle, self.seed, self.mode = n, batch_size, shuffle, seed, mode
+        self.rank = get_rank() if rank is None else rank
+        self.world = world_size() if world is None else world
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def global_batches(self):
+        order = (torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)) if self.shuffle
+                 else torch.arange(self.n)).tolist()
+        return [order[s:s + self.batch_size] for s in range(0, self.n, self.batch_size)]
+
+    def _slice(self, b):
+        return self.rank * b // self.world, (self.rank + 1) * b // self.world
+
+    def weight(self, i):
+        b = min(self.batch_size, self.n - i * self.batch_size)
+        if b < self.world:
+            return 1.0
+        lo, hi = self._slice(b)
+        return (hi - lo) * self.world / b
+
+    def __iter__(self):
+        for idx in self.global_batches():
+            b = len(idx)
+            if b < self.world:
+                if self.mode == "train":
+                    yield idx
+                elif self.rank < b:
+                    yield [idx[self.rank]]
+                continue
+            lo, hi = self._slice(b)
+            yield idx[lo:hi]
+
+    def __len__(self):
+        nb = (self.n + self.batch_size - 1) // self.batch_size
+        if self.mode != "train":
+            last = self.n - (nb - 1) * self.batch_size
+            if last < self.world and self.rank >= last:
+                return nb - 1
+        return nb
+
+
+def allreduce_sum_(t: torch.Tensor):
+    """In-place SUM of a small tensor over all ranks (evaluation totals)."""
+    if collectives_on():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 def broadcast_tensors(tensors, src=0):
     if collectives_on():
         for t in tensors:
@@ -112,33 +178,62 @@ class OverlappedGradReducer:
     post-accumulate-grad hook; when the last live parameter of a bucket has its gradient, and every later bucket has
     already been launched (collectives are issued in the same fixed order on every rank), the bucket's slice is
     all-reduced with ``async_op=True``: RCCL's stream waits for the compute queued so far, later compute does not wait
-    for RCCL.  ``finish()`` launches whatever is left (first step; buckets holding never-used parameters) and waits.
-    Parameters whose hook did not fire in the first backward are treated as never receiving a gradient from then on (the
-    set is static for this model family); if one of them later does fire after its bucket was sent, ``finish`` raises.
+    for RCCL.  ``finish()`` launches whatever is left and waits.
+
+    Parameters whose hook did not fire in the first backward never receive a gradient (the set is static for this model
+    family: the arg-max pools' ``map_to_dir``, and in ``vn_pointr`` the 26 M parameters of modules ``forward`` never runs,
+    SURVEY.md §8e).  After the first step the buckets are re-cut over the LIVE parameters only: never-live ranges leave the
+    wire (config 5: 130 MB -> 26 MB per step; config 2: 90 -> 72 MB), except gaps below ``gap_bytes`` inside a bucket, which
+    travel as zeros because one larger collective beats two small ones.  The first step ships everything.  If a never-live
+    parameter later does receive a gradient, or any parameter receives one after its bucket was sent, ``finish`` completes the
+    step's collectives (so the other ranks are not left waiting inside theirs) and then raises.
     """
 
-    def __init__(self, fb, bucket_bytes=32 << 20, transport=None):
+    def __init__(self, fb, bucket_bytes=32 << 20, transport=None, gap_bytes=64 << 10):
         """``transport(flat_slice) -> work-or-None`` replaces the default asynchronous all-reduce (tests: a host-staged
         collective); it must leave the AVERAGE in ``flat_slice`` once the returned work (if any) has been waited for."""
         self.fb = fb
         self.transport = transport
-        n = len(fb.params)
-        ends = list(fb.offsets[1:]) + [fb.numel]
-        self.buckets = []                      # (first param index, last+1, element lo, element hi), launch order
-        hi_i = n
-        while hi_i > 0:
-            lo_i = hi_i - 1
-            while lo_i > 0 and (ends[hi_i - 1] - fb.offsets[lo_i]) * 4 < bucket_bytes:
-                lo_i -= 1
-            self.buckets.append((lo_i, hi_i, fb.offsets[lo_i], ends[hi_i - 1]))
-            hi_i = lo_i
-        self.bucket_of = {}
-        for b, (lo_i, hi_i, _, _) in enumerate(self.buckets):
-            for i in range(lo_i, hi_i):
-                self.bucket_of[id(fb.params[i])] = b
+        self.bucket_bytes = bucket_bytes
+        self.gap_bytes = gap_bytes
+        self._idx = {id(q): i for i, q in enumerate(fb.params)}
         self.live = None                        # set of id(param) that fired in the first backward
+        self._cut_buckets()
         self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in fb.params]
         self._begin()
+
+    def _cut_buckets(self):
+        """(first param index, last+1, element lo, element hi) in launch order, over the live parameters (all of them until
+        the first backward has shown which are live)."""
+        fb = self.fb
+        n = len(fb.params)
+        ends = list(fb.offsets[1:]) + [fb.numel]
+        alive = [self.live is None or id(p) in self.live for p in fb.params]
+        self.buckets = []
+        i = n
+        while i > 0:
+            if not alive[i - 1]:
+                i -= 1
+                continue
+            hi_i = lo_i = i                     # bucket = params [lo_i, hi_i), grown downwards from a live parameter
+            lo_i -= 1
+            j = lo_i
+            while j > 0 and (ends[hi_i - 1] - fb.offsets[lo_i]) * 4 < self.bucket_bytes:
+                j -= 1
+                if alive[j]:
+                    lo_i = j                    # dead parameters between j and the old lo_i ride along (gap <= gap_bytes)
+                elif (fb.offsets[lo_i] - fb.offsets[j]) * 4 > self.gap_bytes:
+                    break                       # a large never-live range: cut here, it stays off the wire
+            self.buckets.append((lo_i, hi_i, fb.offsets[lo_i], ends[hi_i - 1]))
+            i = lo_i
+        self.bucket_of = {}
+        for b, (lo_i, hi_i, _, _) in enumerate(self.buckets):
+            for k in range(lo_i, hi_i):
+                self.bucket_of[id(fb.params[k])] = b
+
+    def wire_bytes(self):
+        """Bytes each rank contributes to the all-reduces of one step with the current bucket layout."""
+        return sum((hi - lo) * 4 for _, _, lo, hi in self.buckets)
 
     def _begin(self):
         self.fired = set()
@@ -169,9 +264,14 @@ class OverlappedGradReducer:
     def _hook(self, p):
         if not collectives_on():
             return
-        b = self.bucket_of[id(p)]
+        b = self.bucket_of.get(id(p))
+        if b is None:
+            self.late = True                                 # a never-live parameter (off the wire) received a gradient
+            return
         if id(p) in self.fired:
-            return                                           # a second accumulation into the same parameter
+            if b < self.launched:
+                self.late = True                             # a second accumulation after the bucket went on the wire
+            return
         self.fired.add(id(p))
         if p.grad is not None and p.grad.data_ptr() != self.fb.flat_grad.data_ptr() + self.fb.offsets[self._index(p)] * 4:
             self.fb.view(self.fb.flat_grad, self._index(p)).copy_(p.grad)        # autograd replaced the view: re-home it
@@ -179,22 +279,19 @@ class OverlappedGradReducer:
         if b < self.launched:
             self.late = True                                 # its bucket is already on the wire
             return
-        if self.pending is not None and id(p) in self.live:
-            self.pending[b] -= 1
-            self._launch_ready()
+        if self.pending is not None:
+            if id(p) in self.live:
+                self.pending[b] -= 1
+                self._launch_ready()
+            else:
+                self.late = True                             # never-live parameter riding in a bucket's gap turned live
 
     def _index(self, p):
-        if not hasattr(self, "_idx"):
-            self._idx = {id(q): i for i, q in enumerate(self.fb.params)}
         return self._idx[id(p)]
 
     def finish(self):
         """Call after backward: send the remaining buckets, wait for all of them, re-arm for the next step."""
         if collectives_on():
-            if self.late:
-                self._begin()
-                raise RuntimeError("a parameter received its gradient after its bucket had been all-reduced: the set of "
-                                   "parameters that receive gradients changed; build a new OverlappedGradReducer")
             self.fb.check_views()
             while self.launched < len(self.buckets):
                 self._launch(self.launched)
@@ -204,8 +301,16 @@ class OverlappedGradReducer:
                     work.wait()
                 if flat is not None:
                     flat.mul_(1.0 / w)
+            if self.late:
+                # every collective of this step has been issued and completed on this rank, so the peers finish their
+                # step too instead of hanging inside an all-reduce; the averaged gradients are incomplete -> stop here
+                self._begin()
+                raise RuntimeError("a parameter received its gradient after its bucket had been all-reduced (or a parameter "
+                                   "that never had a gradient got one): the set of parameters that receive gradients "
+                                   "changed; build a new OverlappedGradReducer")
             if self.live is None:
                 self.live = set(self.fired)
+                self._cut_buckets()                          # from now on only live ranges travel
         self._begin()
 
     def remove(self):

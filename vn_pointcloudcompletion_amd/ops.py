@@ -36,6 +36,17 @@ POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (variant, flops, start_event, end_event)
 GEMM_PROFILE = None
+# tests set this to a dict to learn which code paths a forward pass took: path name -> launch count, and under "pool_idx" the
+# arg-max index tensors of the VNMaxPool calls in call order (tests/test_gpu_fullres_parity.py)
+TRACE = None
+
+
+def _trace(name, idx=None):
+    tr = TRACE
+    if tr is not None:
+        tr[name] = tr.get(name, 0) + 1
+        if idx is not None:
+            tr.setdefault("pool_idx", []).append(idx)
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -138,8 +149,10 @@ def gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, want_stats):
           and C % 64 == 0 and _ld(x) % 4 == 0 and x.data_ptr() % 16 == 0 and Wcat.is_contiguous() and Wcat.data_ptr() % 16 == 0
           and (bias is None or (rows_per_group > 0 and rows_per_group % 3 == 0)))
     if not ok:
+        _trace("pd_gemm_plain")
         gemm(x, Wcat, out=pd, bias=bias, rows_per_group=rows_per_group, nsplit=1)
         return None
+    _trace("pd_gemm_stats_epilogue")
     part = torch.empty((R // 3072, C, 2), device=x.device, dtype=torch.float32)
     ws = torch.empty(_lib.lib().vnp_gemm_vn_stats_ws_floats(R, C), device=x.device, dtype=torch.float32)
     prof = GEMM_PROFILE
@@ -362,6 +375,7 @@ class VNLinearLeakyOutFn(Function):
         w = w_out.reshape(-1).contiguous()
         coarse = coarse.contiguous()
         fine = torch.empty(R, device=dev, dtype=torch.float32)
+        _trace("decoder_tail_fused")
         call("vnp_vn_bn_leaky_rowdot_fwd", ptr(p), _ld(p), ptr(d), _ld(d), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
              ptr(w), ptr(coarse), S, ptr(fine))
         ctx.save_for_backward(x, Wcat, gamma, beta, pd, mean, rstd, w)
@@ -449,6 +463,7 @@ class VNMaxPoolFn(Function):
         idx = torch.empty((G, C), device=x.device, dtype=torch.int32)
         out = torch.empty((G * 3, C), device=x.device, dtype=torch.float32)
         call("vnp_vn_pool_fwd", ptr(x), _ld(x), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        _trace("pool_unfused", idx)
         ctx.save_for_backward(idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
@@ -506,6 +521,7 @@ class VNLinearMaxPoolFn(Function):
             ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
             ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
             call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        _trace("linear_pool_fused_epilogue" if fused else "linear_pool_unfused", idx)
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
@@ -572,6 +588,7 @@ class FoldFn(Function):
         out = torch.empty((B * Mc * S * 3, W), device=bias.device, dtype=torch.float32)
         call("vnp_fold_fwd", ptr(bias), _ld(bias), ptr(wseed), ptr(wcoarse), ptr(seed), batched, ptr(coarse), B, Mc, S, W,
              ptr(out), W)
+        _trace("fold_layer0_unfused")
         ctx.save_for_backward(wcoarse, seed, coarse)
         ctx.cfg = (B, Mc, S, W, batched)
         return out
@@ -631,6 +648,7 @@ class FoldBnLeakyFn(Function):
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
             call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
         out = torch.empty((P * 3, C), device=dev, dtype=torch.float32)
+        _trace("fold_layer0_fused")
         call("vnp_fold_fused", 1, *args, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns, ptr(out), C, None, 0, None, None, 0,
              None, None)
         ctx.save_for_backward(bias, wseed, wcoarse, seed, coarse, gamma, beta, mean, rstd)
@@ -733,7 +751,9 @@ class ChamferFn(Function):
             # dense clouds: pruned exact search (same bits as the brute-force kernel; tests/test_gpu_chamfer.py)
             ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
             call("vnp_chamfer_fwd_pruned", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
+            _trace("chamfer_pruned")
         else:
+            _trace("chamfer_brute")
             ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
             call("vnp_chamfer_fwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
@@ -773,13 +793,21 @@ def knn_indices(ref, query, k, return_dist=False):
     return (idx, dist) if return_dist else idx
 
 
-def fps_indices(xyz, m):
+# pointnet2_ops' furthest_point_sampling_kernel skips candidates with |p|^2 <= 1e-3 (`if (mag <= 1e-3) continue;`): on clouds
+# centred at the origin ~0.3 points per 2048 fall inside that ball and would be picked by plain FPS but never by the package the
+# reference calls.  Default: the package's convention (so reference checkpoints see the centres they were trained with);
+# VNP_FPS_PLAIN=1 (or skip_near_origin=False) selects plain FPS.  PARITY UNPINNED either way (third-party source absent).
+FPS_SKIP_NEAR_ORIGIN = os.environ.get("VNP_FPS_PLAIN", "0") != "1"
+
+
+def fps_indices(xyz, m, skip_near_origin=None):
     """furthest_point_sample(xyz[B,N,3], m) -> idx [B,m] int32 (starts at 0).  Replaces pointnet2_ops (models/pcn.py:7)."""
     _lib.require_gpu(xyz)
     xyz = xyz.contiguous().float()
     B, N, _ = xyz.shape
     idx = torch.empty((B, m), device=xyz.device, dtype=torch.int32)
-    call("vnp_fps", B, N, ptr(xyz), m, ptr(idx))
+    skip = FPS_SKIP_NEAR_ORIGIN if skip_near_origin is None else bool(skip_near_origin)
+    call("vnp_fps_ex", B, N, ptr(xyz), m, ptr(idx), 1 if skip else 0)
     return idx
 
 

@@ -7,7 +7,13 @@ Differences from the reference, all on purpose:
     iteration (train.py:168,175-176,184-186);
   * scalars go to ``<exp_dir>/{train,val}/scalars.jsonl`` (tensorboardX is not required); the per-epoch PNG
     (visualization/, matplotlib) is not produced;
-  * under torch.distributed every rank trains on its shard of each batch, rank 0 logs / validates / checkpoints.
+  * under torch.distributed every rank loads and trains on its shard of each global batch (ShardedBatchSampler: uneven
+    shards are loss-weighted so the averaged gradient is the global-batch gradient), validation is sharded the same way and
+    its sums all-reduced, rank 0 logs and checkpoints;
+  * the shuffle order of epoch e is a function of (seed, e), so a resumed run continues the uninterrupted run's data order
+    instead of replaying epoch 0's (the reference's generator is unseeded);
+  * on --resume the StepLR schedule continues at the absolute epoch (lr at epoch e is that of an uninterrupted run); the
+    reference builds a fresh StepLR after loading the optimizer (train.py:93), which restarts the 50-epoch count at the resume point.
 """
 from __future__ import annotations
 
@@ -60,13 +66,25 @@ def compute_losses(config, coarse_pred, dense_pred, c):
     return loss1 + loss2, loss1, loss2
 
 
-def train_step(config, model, optimizer, p, c, trot=None):
+def make_scheduler(optimizer, start_epoch=0):
+    """train.py:93 — StepLR(step_size=50, gamma=0.8) — positioned at ``start_epoch`` WITHOUT touching the learning rate:
+    ``optimizer.load_state_dict`` has already restored the decayed ``lr`` (and ``initial_lr``), so replaying the schedule would
+    decay it a second time.  Decay boundaries stay at absolute multiples of 50 epochs, as in an uninterrupted run."""
+    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=50, gamma=0.8, last_epoch=-1)
+    if start_epoch:
+        scheduler.last_epoch = start_epoch
+        scheduler._last_lr = [g["lr"] for g in optimizer.param_groups]
+    return scheduler
+
+
+def train_step(config, model, optimizer, p, c, trot=None, loss_weight=1.0):
     """One iteration of the hot loop (train.py:140-173): zero_grad, forward, losses, backward, gradient all-reduce
-    (world > 1), Adam.  Returns the three loss tensors (on device, no host sync)."""
+    (world > 1), Adam.  Returns the three loss tensors (on device, no host sync).  ``loss_weight`` scales the gradient of an
+    uneven data-parallel shard (ShardedBatchSampler.weight); the returned losses are unscaled."""
     optimizer.zero_grad()
     coarse_pred, dense_pred = model(p, trot)
     loss, loss1, loss2 = compute_losses(config, coarse_pred, dense_pred, c)
-    loss.backward()
+    (loss if loss_weight == 1.0 else loss * loss_weight).backward()
     D.allreduce_gradients(optimizer)
     optimizer.step()
     return loss.detach(), loss1.detach(), loss2.detach()
@@ -83,9 +101,13 @@ def train(config, args):
     log_dataset.info("Loading Data...")
     train_dataset = make_dataset(config, "train", config.category)
     val_dataset = make_dataset(config, "valid", config.category)
-    train_loader = DataLoader(train_dataset, batch_size=config.batch_size, shuffle=True, num_workers=config.num_workers,
-                              generator=torch.Generator().manual_seed(0))
-    val_loader = DataLoader(val_dataset, batch_size=config.batch_size, shuffle=False, num_workers=config.num_workers)
+    seed = int(getattr(config, "seed", 0))
+    train_sampler = D.ShardedBatchSampler(len(train_dataset), config.batch_size, shuffle=True, seed=seed, mode="train")
+    val_sampler = D.ShardedBatchSampler(len(val_dataset), config.batch_size, shuffle=False, mode="eval")
+    if world > 1 and config.batch_size % world:
+        log.warning(f"batch_size {config.batch_size} is not a multiple of the world size {world}: shards are uneven "
+                    f"({config.batch_size // world} or {config.batch_size // world + 1} samples per rank, loss-weighted)"
+                    + ("; batches smaller than the world size are replicated on every rank" if config.batch_size < world else ""))
     log_dataset.info("Dataset loaded!")
 
     model = PCNNet(config, enc_type=config.enc_type, dec_type=config.dec_type)
@@ -116,9 +138,11 @@ def train(config, args):
                      "not existant. Train from start")
     else:
         log.info(f"Start a brand new experiment: {config.run_name}")
-    scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=50, gamma=0.8, last_epoch=-1)
-    for _ in range(start_epoch):
-        scheduler.step()
+    scheduler = make_scheduler(optimizer, start_epoch)
+    # worker seeds derive from this generator: tie them to (seed, start_epoch) so a resumed run does not replay epoch 0's
+    train_loader = DataLoader(train_dataset, batch_sampler=train_sampler, num_workers=config.num_workers,
+                              generator=torch.Generator().manual_seed(seed + start_epoch))
+    val_loader = DataLoader(val_dataset, batch_sampler=val_sampler, num_workers=config.num_workers)
 
     n_batches = len(train_loader)
     step = max(n_batches // config.log_frequency, 1)
@@ -128,14 +152,14 @@ def train(config, args):
 
     for epoch in range(start_epoch, config.max_epochs + 1):
         model.train()
+        train_sampler.set_epoch(epoch)
         sums = torch.zeros(3, device=config.device)          # total, coarse, dense — accumulated on the device
-        for i, (p, c) in enumerate(train_loader):
-            lo, hi = D.shard_batch(p.shape[0]) if world > 1 and p.shape[0] % world == 0 else (0, p.shape[0])
-            p, c = p[lo:hi].to(config.device), c[lo:hi].to(config.device)
+        for i, (p, c) in enumerate(train_loader):             # this rank's shard of global batch i
+            p, c = p.to(config.device), c.to(config.device)
             trot = make_rotation(config.rotation, p.shape[0], config.device)
             if trot is not None:
                 p, c = trot.transform_points(p), trot.transform_points(c)
-            loss, loss1, loss2 = train_step(config, model, optimizer, p, c, trot)
+            loss, loss1, loss2 = train_step(config, model, optimizer, p, c, trot, train_sampler.weight(i))
             sums += torch.stack([loss, loss1, loss2])
             if is_main and (i + 1) % step == 0:
                 l, l1, l2 = loss.item(), loss1.item(), loss2.item()
@@ -155,20 +179,23 @@ def train(config, args):
             train_writer.add_scalar("Loss/Epoch/Dense", de * 1e3, epoch)
             train_writer.add_scalar("Loss/Epoch/Total", tot * 1e3, epoch)
 
-        # evaluation (train.py:198-250) — rank 0 only; replicas are identical after the all-reduced step
+        # evaluation (train.py:198-250): replicas are identical after the all-reduced step, so every rank evaluates its
+        # shard of each validation batch and the per-sample sums are all-reduced once (no rank idles in a barrier while
+        # rank 0 walks the whole validation set — that wait used to be bounded only by the NCCL watchdog)
+        model.eval()
+        val = torch.zeros(2, device=config.device)
+        with torch.no_grad():
+            for p, c in val_loader:
+                p, c = p.to(config.device), c.to(config.device)
+                trot = make_rotation(config.val_rotation, p.shape[0], config.device)
+                if trot is not None:
+                    p, c = trot.transform_points(p), trot.transform_points(c)
+                coarse_pred, dense_pred = model(p, trot)
+                val[0] += l1_cd(coarse_pred, c)
+                if not config.only_coarse:
+                    val[1] += l1_cd(dense_pred, c)
+        D.allreduce_sum_(val)
         if is_main:
-            model.eval()
-            val = torch.zeros(2, device=config.device)
-            with torch.no_grad():
-                for p, c in val_loader:
-                    p, c = p.to(config.device), c.to(config.device)
-                    trot = make_rotation(config.val_rotation, p.shape[0], config.device)
-                    if trot is not None:
-                        p, c = trot.transform_points(p), trot.transform_points(c)
-                    coarse_pred, dense_pred = model(p, trot)
-                    val[0] += l1_cd(coarse_pred, c)
-                    if not config.only_coarse:
-                        val[1] += l1_cd(dense_pred, c)
             vc, vd = (val / len(val_dataset)).tolist()
             vt = vc if config.only_coarse else vc + vd
             val_writer.add_scalar("Loss/Epoch/Coarse", vc * 1e3, epoch)
