@@ -50,8 +50,9 @@ def test_emd_match_invariants(lib_built, n, m):
       * match >= 0;
       * each xyz1 point ships multiL = max(1, m/n) units and each xyz2 point receives multiR = max(1, n/m) units — after
         the final level-0 pass (exp(0) = 1: all remaining mass is spread) both marginals are met to 1e-3;
-      * relabelling the points of either cloud permutes the plan and leaves the cost unchanged (up to fp32 summation
-        order: 1e-4 relative on the plan's marginals and on the cost)."""
+      * relabelling the points of either cloud permutes the plan and leaves the cost unchanged up to fp32 summation order —
+        which the 30 dependent passes (each subtracting what the previous one shipped from `remain`) amplify: measured 4e-4
+        on plan entries (which are <= 1) at 1024 x 1024, bound 2e-3; cost 1e-3 relative."""
     from vn_pointcloudcompletion_amd.emd import EarthMoverDistance
     g = torch.Generator().manual_seed(n * 3 + m)
     a = (torch.rand(2, n, 3, generator=g) - 0.5).cuda()
@@ -64,10 +65,10 @@ def test_emd_match_invariants(lib_built, n, m):
     assert (match.sum(2) - multiR).abs().max().item() < 1e-3            # received by each xyz2 point
     pa, pb = torch.randperm(n, generator=g).cuda(), torch.randperm(m, generator=g).cuda()
     match_p = _approxmatch(a[:, pa].contiguous(), b[:, pb].contiguous())
-    assert (match_p - match[:, pb][:, :, pa]).abs().max().item() < 1e-4 * max(multiL, multiR)
+    assert (match_p - match[:, pb][:, :, pa]).abs().max().item() < 2e-3 * max(multiL, multiR)
     c0 = EarthMoverDistance()(a, b)
     c1 = EarthMoverDistance()(a[:, pa].contiguous(), b[:, pb].contiguous())
-    assert relerr(c1, c0) < 1e-4
+    assert relerr(c1, c0) < 1e-3
     # the cost is the plan's transport cost with SQUARED distances: sum_lk match[l,k] |xyz1_k - xyz2_l|^2  (emd_kernel.cu:224-225)
     d2 = (a[:, None, :, :] - b[:, :, None, :]).pow(2).sum(-1)
     assert relerr(c0, (match.double() * d2.double()).sum((1, 2))) < 1e-4

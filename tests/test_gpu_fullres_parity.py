@@ -28,7 +28,7 @@ B, N, MC, MD = 2, 2048, 1024, 16384
 def _cd_l1_oracle(O, CO, pred, gt):
     """metrics/loss.py:20-31 with the nearest neighbours found by oracle/chamfer_oracle.c (bit-exact restatement of
     chamfer3D.cu) and the distances re-formed differentiably from those indices."""
-    _, _, i1, i2 = CO.chamfer_forward(pred.detach().numpy(), gt.numpy())
+    _, _, i1, i2 = CO.chamfer_forward(pred.detach().float().numpy(), gt.float().numpy())
     d1, d2 = O.chamfer_from_idx(pred, gt, i1, i2)
     return O.cd_loss_l1(d1, d2)
 
@@ -59,19 +59,25 @@ def run(lib_built):
         ops.TRACE = None
     idx1, idx2 = [i.cpu().long() for i in tr["pool_idx"]]
 
-    # ---- oracle, pools teacher-forced with our indices
-    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd0.items()}
-    otr, new_stats = {}, {}
-    co, go = O.vn_pointnet_forward(sd, p, True, new_stats=new_stats, pool_idx=(idx1, idx2), trace=otr)
-    fo = O.vn_foldingnet_forward(sd, co, go, None, True, new_stats=new_stats)
-    with torch.no_grad():
-        # decoder alone on OUR coarse and the oracle's global feature (isolates the decoder from encoder rounding)
-        fo_tf = O.vn_foldingnet_forward(sd0, coarse.detach().cpu(), go.detach(), None, True)
-    l1o, l2o = _cd_l1_oracle(O, CO, co, c), _cd_l1_oracle(O, CO, fo, c)
-    (l1o + l2o).backward()
-    return SimpleNamespace(net=net, tr=tr, otr=otr, idx=(idx1, idx2), coarse=coarse.detach().cpu(), fine=fine.detach().cpu(),
-                           co=co.detach(), fo=fo.detach(), fo_tf=fo_tf, loss=(loss1.item(), loss2.item()),
-                           loss_o=(l1o.item(), l2o.item()), sd=sd, sd0=sd0, new_stats=new_stats, p=p, c=c)
+    # ---- oracle, pools teacher-forced with our indices: in fp32 (the reference's arithmetic) and in fp64 (the yardstick that
+    # tells rounding noise of the fp32 reference apart from error of the HIP path)
+    def oracle(dtype):
+        sd = {k: (v.detach().clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}
+        sd = {k: v.requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+        otr, new_stats = {}, {}
+        pp, cc = p.to(dtype), c.to(dtype)
+        co, go = O.vn_pointnet_forward(sd, pp, True, new_stats=new_stats, pool_idx=(idx1, idx2), trace=otr)
+        fo = O.vn_foldingnet_forward(sd, co, go, None, True, new_stats=new_stats)
+        with torch.no_grad():
+            # decoder alone on OUR coarse and the oracle's global feature (isolates the decoder from encoder rounding)
+            fo_tf = O.vn_foldingnet_forward(sd, coarse.detach().cpu().to(dtype), go.detach(), None, True)
+        l1o, l2o = _cd_l1_oracle(O, CO, co, cc), _cd_l1_oracle(O, CO, fo, cc)
+        (l1o + l2o).backward()
+        return SimpleNamespace(otr=otr, co=co.detach(), fo=fo.detach(), fo_tf=fo_tf, loss=(l1o.item(), l2o.item()), sd=sd,
+                               new_stats=new_stats)
+    o32, o64 = oracle(torch.float32), oracle(torch.float64)
+    return SimpleNamespace(net=net, tr=tr, idx=(idx1, idx2), coarse=coarse.detach().cpu(), fine=fine.detach().cpu(),
+                           loss=(loss1.item(), loss2.item()), o32=o32, o64=o64, sd0=sd0, p=p, c=c)
 
 
 def test_benchmark_code_paths_were_taken(run):
@@ -85,32 +91,44 @@ def test_benchmark_code_paths_were_taken(run):
 
 def test_pool_choices_are_maxima_of_the_oracle_scores(run):
     for name, idx in (("1", run.idx[0]), ("2", run.idx[1])):
-        dot = run.otr["dot" + name]                                        # [B, C, N] oracle scores
+        dot = run.o64.otr["dot" + name]                                    # [B, C, N] oracle scores (fp64: exact ranking)
         chosen = dot.gather(-1, idx.unsqueeze(-1)).squeeze(-1)
         best, lo = dot.max(-1)[0], dot.min(-1)[0]
         gap = ((best - chosen) / (best - lo).clamp_min(1e-20)).max().item()
-        agree = (run.otr["idx" + name] == idx).float().mean().item()
+        agree = (run.o32.otr["idx" + name] == idx).float().mean().item()      # vs the fp32 oracle's own arg-max
         print(f"pool{name}: identical indices {agree:.4%}, worst (best - chosen)/range {gap:.2e}")
         assert gap <= 2e-6, (name, gap)
         assert agree >= 0.99, (name, agree)
 
 
+def _maxerr(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
 def test_outputs_and_chamfer_l1_match_oracle(run):
-    ec = (run.coarse - run.co).abs().max().item()
-    ef = (run.fine - run.fo).abs().max().item()
-    ef_tf = (run.fine - run.fo_tf).abs().max().item()
-    d1, d2 = abs(run.loss[0] - run.loss_o[0]), abs(run.loss[1] - run.loss_o[1])
-    print(f"|coarse - oracle| {ec:.2e}  |fine - oracle| {ef:.2e} (decoder alone on our coarse: {ef_tf:.2e})  "
-          f"CD-L1 coarse {run.loss[0]:.7f} vs {run.loss_o[0]:.7f} (diff {d1:.1e}), dense {run.loss[1]:.7f} vs {run.loss_o[1]:.7f} (diff {d2:.1e})")
-    assert ec < 1e-5                 # coarse coordinates are O(0.3): ~3e-5 relative after three K = 2048 contractions
-    assert ef < 5e-5 and ef_tf < 5e-5
-    assert d1 < 1e-5 and d2 < 1e-5   # the north-star criterion, on both heads, at full resolution
+    o32, o64 = run.o32, run.o64
+    ec, ec64, ref_c = _maxerr(run.coarse, o32.co), _maxerr(run.coarse, o64.co), _maxerr(o32.co, o64.co)
+    ef, ef64, ref_f = _maxerr(run.fine, o32.fo), _maxerr(run.fine, o64.fo), _maxerr(o32.fo, o64.fo)
+    tf64, ref_tf = _maxerr(run.fine, o64.fo_tf), _maxerr(o32.fo_tf, o64.fo_tf)
+    d1, d2 = abs(run.loss[0] - o32.loss[0]), abs(run.loss[1] - o32.loss[1])
+    e1, e2 = abs(run.loss[0] - o64.loss[0]), abs(run.loss[1] - o64.loss[1])
+    print(f"coarse: |ours-o32| {ec:.2e} |ours-o64| {ec64:.2e} (|o32-o64| {ref_c:.2e});  fine: |ours-o32| {ef:.2e} |ours-o64| {ef64:.2e} "
+          f"(|o32-o64| {ref_f:.2e});  decoder alone on our coarse: |ours-o64| {tf64:.2e} (|o32-o64| {ref_tf:.2e})")
+    print(f"CD-L1 coarse {run.loss[0]:.7f} vs o32 {o32.loss[0]:.7f} (diff {d1:.1e}) vs o64 {o64.loss[0]:.7f} (diff {e1:.1e}); "
+          f"dense {run.loss[1]:.7f} vs o32 {o32.loss[1]:.7f} (diff {d2:.1e}) vs o64 {o64.loss[1]:.7f} (diff {e2:.1e})")
+    # the north-star criterion on both heads at full resolution, against the fp32 oracle AND the exact (fp64) value
+    assert d1 < 1e-5 and d2 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
+    # clouds: no further from the exact result than 1.5x the fp32 reference arithmetic itself is (+ 2e-6 absolute)
+    assert ec64 <= 1.5 * ref_c + 2e-6, (ec64, ref_c)
+    assert ef64 <= 1.5 * ref_f + 2e-6, (ef64, ref_f)
+    assert tf64 <= 1.5 * ref_tf + 2e-6, (tf64, ref_tf)
+    assert ec < 1e-5 and ef < 1e-4                # and absolutely close to the fp32 oracle (coordinates are O(0.3))
 
 
 def test_running_statistics_match_oracle(run):
     sd = run.net.state_dict()
-    for k, v in run.new_stats.items():
-        ours = sd[k].detach().cpu()
+    for k, v in run.o64.new_stats.items():
+        ours = sd[k].detach().cpu().double()
         err = ((ours - v.detach()).abs().max() / v.detach().abs().max().clamp_min(1e-12)).item()
         assert err < 1e-5, (k, err)
         assert int(sd[k.rsplit(".", 1)[0] + ".num_batches_tracked"]) == 1
@@ -118,22 +136,22 @@ def test_running_statistics_match_oracle(run):
 
 def test_parameter_gradients_match_oracle(run):
     """Every parameter's gradient against the oracle's autograd through the same (teacher-forced) network: relative L2 error
-    of the whole tensor.  Bound 2e-3: the decoder's BatchNorm layers amplify fp32 rounding (both sides are fp32 here)."""
-    worst = []
+    of the whole tensor against the fp64 oracle, bounded by 2x the fp32 oracle's own error against fp64 (+ 1e-4): the HIP
+    path must be as accurate as the reference's arithmetic, tensor by tensor."""
+    rows = []
     for k, prm in run.net.named_parameters():
-        go = run.sd[k].grad
+        g32, g64 = run.o32.sd[k].grad, run.o64.sd[k].grad
         if "maxpool" in k:
-            assert go is None and (prm.grad is None or prm.grad.abs().max().item() == 0.0), k
+            assert g64 is None and (prm.grad is None or prm.grad.abs().max().item() == 0.0), k
             continue
         gm = prm.grad.detach().cpu().double()
-        go = go.double()
-        rel = ((gm - go).norm() / go.norm().clamp_min(1e-30)).item()
-        nrm = abs(gm.norm().item() - go.norm().item()) / go.norm().item()
-        worst.append((rel, nrm, k))
-    worst.sort(reverse=True)
-    for rel, nrm, k in worst[:6]:
-        print(f"grad {k}: rel L2 err {rel:.2e}, norm diff {nrm:.2e}")
-    assert worst[0][0] < 2e-3, worst[:3]
+        den = g64.norm().clamp_min(1e-30)
+        rows.append((((gm - g64).norm() / den).item(), ((g32.double() - g64).norm() / den).item(), k))
+    rows.sort(reverse=True)
+    for ours, ref, k in rows[:6]:
+        print(f"grad {k}: rel L2 err vs fp64 oracle: ours {ours:.2e}, fp32 oracle {ref:.2e}")
+    for ours, ref, k in rows:
+        assert ours <= 2.0 * ref + 1e-4, (k, ours, ref)
 
 
 def test_pruned_chamfer_16384_squared_bit_exact_vs_c_oracle(lib_built):
