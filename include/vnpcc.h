@@ -141,6 +141,15 @@ int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long long batch_str
 long long vnp_linear_pool_ws_bytes(long long G, int gs, int C);
 int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
                         int K, int* idx, float* out, int ldo, void* ws);
+/* The same operator — same arguments, same restrictions, same results BIT FOR BIT — with an exact screened arg-max: a 3-product
+ * pass (half the MFMA work) brackets every score between rigorous bounds, the ~1-2 surviving candidates per (group, channel) are
+ * evaluated exactly as diagonals of MFMA tiles with the full kernels' product sequence, and a predicated launch of the full
+ * kernel takes over if the candidate list overflows or a bound is not finite (NaN / Inf inputs, massive exact ties).
+ * ws: vnp_linear_pool_screened_ws_bytes(G, gs, C) bytes; afterwards its first three ints are {candidates evaluated,
+ * fallback flag, candidate capacity} (diagnostics). */
+long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C);
+int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
+                                 int K, int* idx, float* out, int ldo, void* ws);
 int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int ldd, long long G, int gs, int C,
                     int* idx, float* out, int ldo, float* ws_val, int* ws_idx);
 int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Step time of the other BASELINE configs (3, 4, 5) at their full sizes on ONE MI355X — parity-test cases, not the bench
-line (bench.py measures config 2); this table is what DESIGN.md §6 quotes.  usage: python scripts/bench_configs.py [3 4 5]"""
+line (bench.py measures config 2); this table is what DESIGN.md §6 quotes.  usage: python scripts/bench_configs.py [3 4 5] [--steps N]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from types import SimpleNamespace
@@ -15,7 +15,11 @@ CONFIGS = {
     4: dict(enc="vn_pointnet", dec="attention_vn_foldingnet", B=16, latent=2048, loss="emd", mc=1024),
     5: dict(enc="vn_pointr", dec="vn_foldingnet", B=32, latent=1024, loss="cd", mc=1024),   # B = 256 over 8 GPUs
 }
-which = [int(a) for a in sys.argv[1:]] or [3, 4, 5]
+argv = sys.argv[1:]
+nsteps = 5
+if "--steps" in argv:                       # profiling runs use fewer timed steps
+    i = argv.index("--steps"); nsteps = int(argv[i + 1]); del argv[i:i + 2]
+which = [int(a) for a in argv] or [3, 4, 5]
 for cid in which:
     c = CONFIGS[cid]
     cfg = SimpleNamespace(num_coarse=c["mc"], latent_dim=c["latent"], only_coarse=False, enc_pretrained="none", device="cuda:0",
@@ -31,7 +35,7 @@ for cid in which:
         train_step(cfg, net, opt, p, gt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 5
+    n = nsteps
     for _ in range(n):
         loss, _, _ = train_step(cfg, net, opt, p, gt)
     torch.cuda.synchronize()

@@ -4,7 +4,7 @@ oracle finishes in well under a minute.
 
 Why a second end-to-end test beside test_gpu_e2e.py (config 1, 256 -> 64 -> 1024): at fixture size the layers have
 R = 1536 rows, so the code paths the benchmark actually runs — BatchNorm statistics in the GEMM epilogue (needs whole
-1024-point chunks), the arg-max pool fused into the GEMM epilogue, the fused FoldingNet layer 0 and decoder tail, the
+1024-point chunks), the exact screened arg-max pool fused into the GEMM epilogue, the fused FoldingNet layer 0 and decoder tail, the
 pruned Chamfer search — are never taken there.  This test asserts (ops.TRACE) that they ARE taken here.
 
 The two arg-max pools are discontinuous: two points whose scores agree to ~1e-7 relative swap under any change of
@@ -83,7 +83,7 @@ def run(lib_built):
 def test_benchmark_code_paths_were_taken(run):
     tr = run.tr
     assert tr.get("pd_gemm_stats_epilogue", 0) == 2 and tr.get("pd_gemm_plain", 0) == 1, tr    # second_conv[0], final_conv[1]; first_conv[0] has K = 1
-    assert tr.get("linear_pool_fused_epilogue", 0) == 1 and "linear_pool_unfused" not in tr, tr
+    assert tr.get("linear_pool_screened", 0) == 1 and "linear_pool_unfused" not in tr and "linear_pool_fused_epilogue" not in tr, tr
     assert tr.get("fold_layer0_fused", 0) == 1 and "fold_layer0_unfused" not in tr, tr
     assert tr.get("decoder_tail_fused", 0) == 1, tr
     assert tr.get("chamfer_pruned", 0) == 1 and tr.get("chamfer_brute", 0) == 1, tr             # dense loss / coarse loss

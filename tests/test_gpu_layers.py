@@ -155,34 +155,112 @@ def test_vnstdfeature(G, nf):
     assert relerr(y, G[f"{tag}_y"]) < 1e-4 and relerr(z, G[f"{tag}_z"]) < 1e-4
 
 
-@pytest.mark.parametrize("G,gs,C,K", [(3, 64, 128, 64), (2, 2048, 256, 96), (1, 96, 64, 32), (5, 32, 192, 160)])
-def test_linear_pool_fused_epilogue_equals_unfused(lib_built, G, gs, C, K):
-    """VNLinear -> VNMaxPool with the pool in the GEMM epilogue (vnp_linear_pool_fwd: x and d never written) against the
-    two-GEMM + pool-kernel path: same arg-max indices and pooled vectors, bit for bit, including exact ties (duplicated
-    points: the lowest index wins) — and the same gradients, since backward only needs the indices."""
+def _pool_three_ways(f, W, Wd, G, gs, stats=None):
+    """(out, idx, grad f, grad W) of VNLinear -> VNMaxPool through the screened search, the full fused epilogue and the two-GEMM +
+    pool-kernel path."""
     from vn_pointcloudcompletion_amd import ops
+    res = {}
+    for name, fused, screened in (("screened", True, True), ("fused", True, False), ("unfused", False, False)):
+        ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED = fused, screened
+        ops.POOL_SCREEN_STATS = stats if name == "screened" else None
+        try:
+            fx, Wx = f.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
+            out, idx = ops.VNLinearMaxPoolFn.apply(fx, Wx, Wd.cuda(), G, gs)
+            (out * torch.arange(out.numel(), device="cuda").reshape(out.shape).cos()).sum().backward()
+            res[name] = (out.detach(), idx, fx.grad, Wx.grad)
+        finally:
+            ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED, ops.POOL_SCREEN_STATS = True, True, None
+    return res
+
+
+def _assert_pool_bits_equal(res):
+    for name in ("screened", "fused"):
+        assert torch.equal(res[name][1], res["unfused"][1]), name                                  # indices
+        assert torch.equal(res[name][0].view(torch.int32), res["unfused"][0].view(torch.int32)), name   # pooled vectors, bit patterns
+        assert torch.equal(res[name][2], res["unfused"][2]) and torch.equal(res[name][3], res["unfused"][3]), name
+
+
+@pytest.mark.parametrize("G,gs,C,K", [(3, 64, 128, 64), (2, 2048, 256, 96), (1, 96, 64, 32), (5, 32, 192, 160), (2, 2048, 128, 1024)])
+def test_linear_pool_fused_epilogue_equals_unfused(lib_built, G, gs, C, K):
+    """VNLinear -> VNMaxPool with the pool in the GEMM epilogue — the exact screened search (vnp_linear_pool_screened_fwd, the
+    default) and the full 6-product epilogue (vnp_linear_pool_fwd) — against the two-GEMM + pool-kernel path: same arg-max indices
+    and pooled vectors, bit for bit, including exact ties (duplicated points: the lowest index wins) — and the same gradients,
+    since backward only needs the indices."""
     g = torch.Generator().manual_seed(G * 100 + gs + C + K)
     f = torch.randn(G * gs * 3, K, generator=g)
     f[3 * (gs // 2):3 * (gs // 2) + 3] = f[0:3]                  # point gs/2 duplicates point 0 (group 0): exact ties
     f[3 * (gs - 1):3 * gs] = f[3:6]                              # and the last point duplicates point 1
     W = (torch.randn(C, K, generator=g) / K ** 0.5)
     Wd = (torch.randn(C, C, generator=g) / C ** 0.5)
-    res = {}
-    for fused in (True, False):
-        ops.POOL_FUSED_EPILOGUE = fused
-        try:
-            fx, Wx = f.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
-            out, idx = ops.VNLinearMaxPoolFn.apply(fx, Wx, Wd.cuda(), G, gs)
-            (out * torch.arange(out.numel(), device="cuda").reshape(out.shape).cos()).sum().backward()
-            res[fused] = (out.detach(), idx, fx.grad, Wx.grad)
-        finally:
-            ops.POOL_FUSED_EPILOGUE = True
-    assert torch.equal(res[True][1], res[False][1])
-    assert torch.equal(res[True][0], res[False][0])
-    assert torch.equal(res[True][2], res[False][2]) and torch.equal(res[True][3], res[False][3])
+    stats = []
+    res = _pool_three_ways(f, W, Wd, G, gs, stats)
+    _assert_pool_bits_equal(res)
     # the ties really occurred and were resolved to the lower index
-    i0 = res[True][1][0]
+    i0 = res["screened"][1][0]
     assert (i0 != gs // 2).all() and (i0 != gs - 1).all()
+    if stats:                                                    # shapes the fused kernels do not cover take the unfused path
+        cand, flag, cap = stats[0].tolist()
+        print(f"screened pool G={G} gs={gs} C={C} K={K}: {cand} candidates for {G * C} (group, channel) pairs, fallback flag {flag}")
+        assert flag == 0 and G * C <= cand <= cap
+    else:
+        assert (G * gs * 3) % 192 != 0
+
+
+def test_screened_pool_adversarial_near_ties(lib_built):
+    """Scores that differ in their last bits only: every point is a tiny perturbation (1e-7 relative: single ulps of the
+    features) of one of four base points, so each channel has hundreds of candidates inside any error bound and the decision rests
+    entirely on the exact candidate evaluation reproducing the full kernels' bits (and on the fallback when the list overflows)."""
+    g = torch.Generator().manual_seed(5)
+    G, gs, C, K = 2, 256, 128, 256
+    base = torch.randn(4, 3, K, generator=g)
+    pick = torch.randint(0, 4, (G * gs,), generator=g)
+    f = base[pick] * (1.0 + 1.2e-7 * torch.randint(-2, 3, (G * gs, 3, K), generator=g).float())
+    f = f.reshape(G * gs * 3, K).contiguous()
+    W = torch.randn(C, K, generator=g) / K ** 0.5
+    Wd = torch.randn(C, C, generator=g) / C ** 0.5
+    # three near-tied points that dominate the pool (3x the norm of the rest: their scores are ~9x larger), so that the
+    # candidate list does NOT overflow and the exact candidate evaluation — not the fallback — decides between last-bit differences
+    few = torch.randn(G * gs, 3, K, generator=g)
+    dom = 3.0 * torch.randn(1, 3, K, generator=g)
+    for b in range(G):
+        for n in (5, 70, 140):                                   # in three different 32-point blocks (two in one block would make
+            few[b * gs + n] = dom[0] * (1.0 + 1.2e-7 * torch.randint(-2, 3, (3, K), generator=g).float())   # the whole block a candidate)
+    few = few.reshape(G * gs * 3, K).contiguous()
+    for cap_note, ff in (("three dominant near-tied points", few), ("near ties", f), ("all points identical", base[0].reshape(1, 3, K).expand(G * gs, 3, K).reshape(G * gs * 3, K).contiguous())):
+        stats = []
+        res = _pool_three_ways(ff, W, Wd, G, gs, stats)
+        _assert_pool_bits_equal(res)
+        cand, flag, cap = stats[0].tolist()
+        print(f"{cap_note}: {cand} candidates (capacity {cap}), fallback flag {flag}")
+        if cap_note == "three dominant near-tied points":
+            assert flag == 0 and cand > 1.5 * G * C              # several candidates per pair, all evaluated exactly
+            win = res["screened"][1]
+            assert ((win == 5) | (win == 70) | (win == 140)).float().mean().item() > 0.3
+        if cap_note == "all points identical":
+            assert flag == 1                                     # 256 exact ties per channel > 8 per pair: the predicated full kernel ran
+            assert (res["screened"][1] == 0).all()               # and the lowest index won everywhere
+
+
+def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
+    g = torch.Generator().manual_seed(6)
+    G, gs, C, K = 2, 64, 64, 64
+    f = torch.randn(G * gs * 3, K, generator=g)
+    f[17, 3] = float("nan")
+    f[250, 9] = float("inf")
+    W = torch.randn(C, K, generator=g) / K ** 0.5
+    Wd = torch.randn(C, C, generator=g) / C ** 0.5
+    from vn_pointcloudcompletion_amd import ops
+    stats = []
+    out = {}
+    for name, screened in (("screened", True), ("fused", False)):
+        ops.POOL_SCREENED, ops.POOL_SCREEN_STATS = screened, (stats if screened else None)
+        try:
+            out[name] = ops.VNLinearMaxPoolFn.apply(f.cuda(), W.cuda(), Wd.cuda(), G, gs)
+        finally:
+            ops.POOL_SCREENED, ops.POOL_SCREEN_STATS = True, None
+    assert stats[0][1].item() == 1
+    assert torch.equal(out["screened"][1], out["fused"][1])
+    assert torch.equal(out["screened"][0].view(torch.int32), out["fused"][0].view(torch.int32))
 
 
 @pytest.mark.parametrize("nb,n,W", [(3, 1248, 40), (2, 2048, 64), (2, 1031, 16), (1, 7, 5), (4, 4992, 24)])

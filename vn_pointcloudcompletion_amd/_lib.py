@@ -83,6 +83,7 @@ _SIGNATURES = {
     "vnp_vn_bn_bwd2": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll],
     "vnp_reduce_rows": [_vp, _i, _ll, _i, _ll, _i, _vp, _ll],
     "vnp_linear_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _i, _vp],
+    "vnp_linear_pool_screened_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _i, _vp],
     "vnp_vn_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _i, _vp, _vp],
     "vnp_vn_pool_bwd": [_vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_pool_lin_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i],
@@ -111,8 +112,10 @@ _SIGNATURES = {
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
 _NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
-              "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_gemm_vn_stats_ws_floats": [_ll, _i]}
-_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_gemm_vn_stats_ws_floats": _ll}
+              "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i],
+              "vnp_gemm_vn_stats_ws_floats": [_ll, _i]}
+_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,
+            "vnp_gemm_vn_stats_ws_floats": _ll}
 
 
 def exported_symbols():

@@ -170,7 +170,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         }
     }
     constexpr int BK = 32;
-    VnpGemmArgs p;
+    VnpGemmArgs p{};
     p.A = A; p.B = B; p.bias = bias;
     p.M = M; p.N = N; p.K = K;
     p.lda = lda; p.ldb = ldb; p.ldbias = ldbias;
@@ -230,8 +230,10 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
 // ---- VNLinear + VNMaxPool in one pass (models/pcn.py:173-174: second_conv[1] -> maxpool2) -------------------------------
 // Stage 2 of the fused pool: reduce the per-32-point partials of a group (ascending order keeps the first maximum).
 __global__ void vnp_pool_fused_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx, const float* __restrict__ px,
-                                            int nparts, int C, int* __restrict__ idx, float* __restrict__ out, int ldo)
+                                            int nparts, int C, int* __restrict__ idx, float* __restrict__ out, int ldo,
+                                            const int* __restrict__ pred)
 {
+    if (pred && *pred == 0) return;                       // predicated launch (see VnpGemmArgs::pred)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const long long g = blockIdx.y;
@@ -283,7 +285,282 @@ extern "C" int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, cons
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
     hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 1>), grid, block, 0, st, p);
     hipLaunchKernelGGL(vnp_pool_fused_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
-                       (const float*)p.pool_val, (const int*)p.pool_idx, (const float*)p.pool_x, gs / 32, C, idx, out, ldo);
+                       (const float*)p.pool_val, (const int*)p.pool_idx, (const float*)p.pool_x, gs / 32, C, idx, out, ldo,
+                       (const int*)nullptr);
+    return vnp_last_error();
+}
+
+// ---- the same pool with an exact SCREENED arg-max ---------------------------------------------------------------------------
+// The 6-product GEMM above spends 1.65 TFLOP (config 2) to pick ONE point per (sample, channel).  Here a 3-product pass (half
+// the MFMA work, no l plane) brackets every score s6(n, c) = <x6, d6> the 6-product kernels would produce between rigorous
+// bounds (EPI = 3 epilogue); a point can only be the arg-max if its upper bound reaches the largest lower bound of its group,
+// which leaves ~1-2 candidates per (sample, channel); the candidates — (point, channel) PAIRS, not tiles — are then evaluated
+// exactly: 16 pairs per wave as the DIAGONAL of a 16x16 MFMA tile whose A rows are the pairs' feature rows and whose B rows are
+// the pairs' weight rows, with the 6-product sequence and K order of vnp_gemm_split_kernel, so every x6 / d6 / score has the bits
+// the full kernels produce (an MFMA output element depends only on its own A row, B row and accumulator).  The arg-max over the
+// candidates (ties to the lowest point) is therefore the arg-max of the full computation: indices and pooled vectors are
+// bit-identical to vnp_linear_pool_fwd and to vnp_gemm + vnp_vn_pool_fwd (tests/test_gpu_layers.py).  If the candidate list
+// overflows or any bound is not finite (NaN / Inf inputs), a device-side flag is raised and the full kernel — enqueued
+// unconditionally behind it as a predicated launch — recomputes everything; without the flag it exits at once (~10 us).
+
+// upper bound of |row|_2 for rows of K floats (one wave per row); inflated past its own fp32 rounding
+__global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restrict__ x, int ld, long long rows, int K, float* __restrict__ out)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = x + (size_t)r * ld;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const vnp_f4 v = __builtin_nontemporal_load((const vnp_f4*)(src + k));
+        s = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], s))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[r] = sqrtf(s) * (1.0f + 2.0f * (float)K * 5.97e-8f) * 1.0001f;
+}
+
+struct VnpScreenHead { int count; int flag; int cap; int pad; };     // head of the workspace (device memory)
+
+__global__ void vnp_pool_screen_init_kernel(VnpScreenHead* head, int cap) { head->count = 0; head->flag = 0; head->cap = cap; head->pad = 0; }
+
+// per (group, channel): L = largest lower bound; every block whose largest upper bound reaches L contributes its top point —
+// or all 32 of its points when its second-largest upper bound reaches L too.  A workgroup = 64 channels x 4 quarters of the
+// group's 32-point blocks; each thread keeps its quarter's slots in registers (one pass over memory), the four quarters meet in
+// LDS, and the workgroup appends ALL its pairs with one atomicAdd, so the candidates of neighbouring channels are contiguous in
+// the list (coalesced reads in the exact and final passes).  grid (C/64, G), 256 threads; nparts <= 4 * SEL_MAXQ.
+#define SEL_MAXQ 16
+__global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float4* __restrict__ slots, int nparts, int C, int gs,
+                                                                     VnpScreenHead* __restrict__ head, int2* __restrict__ seg, int2* __restrict__ list)
+{
+    __shared__ float sL[4][64];
+    __shared__ int sbad[4][64], scnt[4][64], sbase;
+    const int cx = threadIdx.x & 63, qy = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long g = blockIdx.y;
+    const int per = (nparts + 3) / 4, k0 = qy * per, k1 = min(nparts, k0 + per);
+    const float4* sl = slots + (size_t)g * nparts * C + c;
+    float4 v[SEL_MAXQ];
+    float L = -INFINITY;
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < SEL_MAXQ; ++j) {
+        if (k0 + j < k1) {
+            v[j] = sl[(size_t)(k0 + j) * C];
+            L = fmaxf(L, v[j].x);
+            bad |= !(v[j].x < INFINITY) || !(v[j].y < INFINITY) || !(v[j].z < INFINITY);
+        }
+    }
+    sL[qy][cx] = L; sbad[qy][cx] = bad;
+    __syncthreads();
+    L = fmaxf(fmaxf(sL[0][cx], sL[1][cx]), fmaxf(sL[2][cx], sL[3][cx]));
+    bad = sbad[0][cx] | sbad[1][cx] | sbad[2][cx] | sbad[3][cx];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SEL_MAXQ; ++j)
+        if (k0 + j < k1 && v[j].y >= L) cnt += (v[j].z >= L) ? 32 : 1;
+    scnt[qy][cx] = cnt;
+    __syncthreads();
+    // exclusive prefix over (channel, quarter) in channel-major order: thread (cx, qy) starts after all pairs of channels < cx and
+    // of quarters < qy of its own channel
+    int before = 0, total = 0, mine_total = 0;
+    for (int cc = 0; cc < 64; ++cc) {
+        const int t = scnt[0][cc] + scnt[1][cc] + scnt[2][cc] + scnt[3][cc];
+        if (cc < cx) before += t;
+        if (cc == cx) mine_total = t;
+        total += t;
+    }
+    for (int q = 0; q < qy; ++q) before += scnt[q][cx];
+    int anybad = bad;
+    anybad = __syncthreads_or(anybad || mine_total <= 0);
+    if (threadIdx.x == 0) {
+        int base = -1;
+        if (anybad) atomicOr(&head->flag, 1);
+        else {
+            base = atomicAdd(&head->count, total);
+            if (base + total > head->cap) { atomicOr(&head->flag, 1); base = -1; }
+        }
+        sbase = base;
+    }
+    __syncthreads();
+    const int base = sbase;
+    if (qy == 0) seg[(size_t)g * C + c] = base < 0 ? make_int2(0, 0) : make_int2(base + before, mine_total);
+    if (base < 0) return;
+    int w = base + before;
+    const int pbase = (int)(g * gs);
+#pragma unroll
+    for (int j = 0; j < SEL_MAXQ; ++j) {
+        if (k0 + j < k1 && v[j].y >= L) {
+            if (v[j].z >= L) { for (int i = 0; i < 32; ++i) list[w++] = make_int2(pbase + (k0 + j) * 32 + i, c); }
+            else list[w++] = make_int2(pbase + __float_as_int(v[j].w), c);
+        }
+    }
+}
+
+// one wave = 16 candidate pairs: x6_t = <f[(pt, t)], W_c>, d6_t = <f[(pt, t)], W'_c> as diagonals of 16x16x32 bf16 MFMA tiles with
+// the product sequence of vnp_gemm_split_kernel (K-tiles ascending; per K-tile (l h)(h l)(m m)(m h)(h m)(h h)), then the score in the
+// pool kernels' fmaf form.  Operands go global -> registers -> MFMA (a lane's fragment IS row lane&15, k = 8 (lane>>4) .. +7).
+__global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Wcat, int ldw,
+                                                                    int K, const VnpScreenHead* __restrict__ head, const int2* __restrict__ list,
+                                                                    float4* __restrict__ res)
+{
+    const int count = head->flag ? 0 : head->count;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 16 >= count) return;
+    const int mine = min(tile * 16 + l16, count - 1);
+    const int2 pc = list[mine];
+    const float* f0 = x + (size_t)pc.x * 3 * ldx + lq * 8;
+    const float* w0 = Wcat + (size_t)((pc.y >> 5) * 64 + (pc.y & 31)) * ldw + lq * 8;
+    const float* w1 = w0 + (size_t)32 * ldw;
+    vnp_f4 ax[3], ad[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ax[t][e] = 0.f; ad[t][e] = 0.f; }
+    auto planes = [](const vnp_f4 v0, const vnp_f4 v1, vnp_bf8 (&pl)[3]) {
+        unsigned h[4], m[4], l[4];
+        vnp_split_pair(v0[0], v0[1], h[0], m[0], l[0]);
+        vnp_split_pair(v0[2], v0[3], h[1], m[1], l[1]);
+        vnp_split_pair(v1[0], v1[1], h[2], m[2], l[2]);
+        vnp_split_pair(v1[2], v1[3], h[3], m[3], l[3]);
+        pl[0] = __builtin_bit_cast(vnp_bf8, vnp_u4{h[0], h[1], h[2], h[3]});
+        pl[1] = __builtin_bit_cast(vnp_bf8, vnp_u4{m[0], m[1], m[2], m[3]});
+        pl[2] = __builtin_bit_cast(vnp_bf8, vnp_u4{l[0], l[1], l[2], l[3]});
+    };
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    const float* src[5] = {f0, f0 + ldx, f0 + 2 * (size_t)ldx, w0, w1};
+    vnp_f4 cur[5][2], nxt[5][2];
+#pragma unroll
+    for (int o = 0; o < 5; ++o) { cur[o][0] = *(const vnp_f4*)src[o]; cur[o][1] = *(const vnp_f4*)(src[o] + 4); }
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        if (k0 + 32 < K) {                          // next K-step's operands in flight during this step's MFMAs
+#pragma unroll
+            for (int o = 0; o < 5; ++o) { nxt[o][0] = *(const vnp_f4*)(src[o] + k0 + 32); nxt[o][1] = *(const vnp_f4*)(src[o] + k0 + 36); }
+        }
+        vnp_bf8 a[3][3], bw[3], bd[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) planes(cur[t][0], cur[t][1], a[t]);
+        planes(cur[3][0], cur[3][1], bw);
+        planes(cur[4][0], cur[4][1], bd);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                ax[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][PA[q]], bw[PB[q]], ax[t], 0, 0, 0);
+                ad[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][PA[q]], bd[PB[q]], ad[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int o = 0; o < 5; ++o) { cur[o][0] = nxt[o][0]; cur[o][1] = nxt[o][1]; }
+    }
+    // C layout: lane holds column lane&15, rows 4 (lane>>4) + e: the diagonal element of pair i sits in lane (i>>2)*16 + i, e = i&3
+    if (lq == (l16 >> 2) && tile * 16 + l16 < count) {
+        const int e = l16 & 3;
+        float xv[3], dv[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            xv[t] = e == 0 ? ax[t][0] : e == 1 ? ax[t][1] : e == 2 ? ax[t][2] : ax[t][3];
+            dv[t] = e == 0 ? ad[t][0] : e == 1 ? ad[t][1] : e == 2 ? ad[t][2] : ad[t][3];
+        }
+        float4 o;
+        o.x = xv[0]; o.y = xv[1]; o.z = xv[2];
+        o.w = fmaf(xv[2], dv[2], fmaf(xv[1], dv[1], xv[0] * dv[0]));      // the pool kernels' score form
+        res[tile * 16 + l16] = o;
+    }
+}
+
+// per (group, channel): arg-max over its candidates' exact scores (strictly greater wins, ties to the lowest point: the first maximum
+// of an ascending scan, as vnp_vn_pool_fwd), index and pooled vector out.  Skipped when the flag is up (the fallback writes them).
+__global__ void vnp_pool_screen_final_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ seg, const int2* __restrict__ list,
+                                             const float4* __restrict__ res, int C, int gs, int* __restrict__ idx, float* __restrict__ out, int ldo)
+{
+    if (head->flag) return;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y;
+    const int2 sg = seg[(size_t)g * C + c];
+    float best = 0.f; int bp = 0x7fffffff; float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = sg.x; i < sg.x + sg.y; ++i) {
+        const float4 r = res[i];
+        const int pt = list[i].x;
+        if (bp == 0x7fffffff || r.w > best || (r.w == best && pt < bp)) { best = r.w; bp = pt; bx = r; }
+    }
+    idx[(size_t)g * C + c] = bp - (int)(g * gs);
+    out[((size_t)g * 3 + 0) * ldo + c] = bx.x;
+    out[((size_t)g * 3 + 1) * ldo + c] = bx.y;
+    out[((size_t)g * 3 + 2) * ldo + c] = bx.z;
+}
+
+static inline long long vnp_align256(long long v) { return (v + 255) / 256 * 256; }
+
+// candidate capacity: 8 per (group, channel) on average (measured mean 1.7 at config 2 with random-init weights)
+static inline long long vnp_screen_cap(long long G, int C) { long long c = 8 * G * C; return c > 2000000000LL ? 2000000000LL : c; }
+
+extern "C" long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C)
+{
+    if (G <= 0 || gs <= 0 || C <= 0 || gs % 32) return 0;
+    const long long nslot = G * (gs / 32) * (long long)C, cap = vnp_screen_cap(G, C);
+    return 256 + vnp_align256(G * gs * 3 * 4) + vnp_align256(2LL * C * 4) + vnp_align256(nslot * 16) + vnp_align256(G * C * 8) +
+           vnp_align256(cap * 8) + vnp_align256(cap * 16) + vnp_align256(vnp_linear_pool_ws_bytes(G, gs, C));
+}
+
+// Same contract, arguments and results (bit for bit) as vnp_linear_pool_fwd; ws: vnp_linear_pool_screened_ws_bytes(G, gs, C) bytes.
+// After the call ws begins with {int candidates, int fallback_flag, int capacity} (diagnostics; device memory).
+extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
+                                            int K, int* idx, float* out, int ldo, void* ws)
+{
+    if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0) return VNP_EINVAL;
+    const long long M = G * gs * 3;
+    if (vnp_gemm_get_mode() != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || M > 2147483647LL ||
+        (uintptr_t)x % 16 || (uintptr_t)Wcat % 16 || G > 65535 || G * gs > 2147483647LL || gs / 32 > 4 * SEL_MAXQ)
+        return VNP_EINVAL;
+    const long long nslot = G * (gs / 32) * (long long)C, cap = vnp_screen_cap(G, C);
+    char* w = (char*)ws;
+    VnpScreenHead* head = (VnpScreenHead*)w;       w += 256;
+    float* rnorm = (float*)w;                      w += vnp_align256(M * 4);
+    float* cnorm = (float*)w;                      w += vnp_align256(2LL * C * 4);
+    float4* slots = (float4*)w;                    w += vnp_align256(nslot * 16);
+    int2* seg = (int2*)w;                          w += vnp_align256(G * C * 8);
+    int2* list = (int2*)w;                         w += vnp_align256(cap * 8);
+    float4* res = (float4*)w;                      w += vnp_align256(cap * 16);
+    void* ws_full = (void*)w;
+    hipLaunchKernelGGL(vnp_pool_screen_init_kernel, dim3(1), dim3(1), 0, st, head, (int)cap);
+    hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(M, 4)), dim3(256), 0, st, x, ldx, M, K, rnorm);
+    hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(2LL * C, 4)), dim3(256), 0, st, Wcat, ldw, 2LL * C, K, cnorm);
+    VnpGemmArgs p{};
+    p.A = x; p.B = Wcat; p.C = nullptr; p.bias = nullptr;
+    p.M = (int)M; p.N = 2 * C; p.K = K;
+    p.lda = ldx; p.ldb = ldw; p.ldc = 0; p.rows_per_group = 1;
+    p.tiles_per_split = K / 32; p.nsplit = 1; p.nbatch = 1;
+    p.pool_val = (float*)slots; p.pool_gs = gs; p.col_group = 8;
+    p.row_norm = rnorm; p.col_norm = cnorm;
+    // E: dropped products (h l)+(l h)+(m m)+... <= 3.05 * 2^-18 of |w||f| per term, plus the worst-case fp32 rounding of BOTH
+    // accumulations in any summation order (3K and 6K terms, unit roundoff 2^-24, terms <= 1.01 |w||f|)
+    p.screen_eps = 1.17e-5f + 9.2f * (float)K * 5.9605e-8f;
+    const long long items = (M / 192) * (2LL * C / 128);
+    if (items > 2147483647LL) return VNP_EINVAL;
+    const long long capwg = (long long)vnp_num_cus() * 2;
+    dim3 grid((unsigned)(items < capwg ? items : capwg)), block(256);
+    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 3>), grid, block, 0, st, p);
+    hipLaunchKernelGGL(vnp_pool_screen_select_kernel, dim3(C / 64, (unsigned)G), dim3(256), 0, st,
+                       (const float4*)slots, gs / 32, C, gs, head, seg, list);
+    hipLaunchKernelGGL(vnp_pool_screen_exact_kernel, dim3((unsigned)vnp_cdiv(cap, 64)), dim3(256), 0, st, x, ldx, Wcat, ldw, K,
+                       (const VnpScreenHead*)head, (const int2*)list, res);
+    hipLaunchKernelGGL(vnp_pool_screen_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
+                       (const VnpScreenHead*)head, (const int2*)seg, (const int2*)list, (const float4*)res, C, gs, idx, out, ldo);
+    // predicated fallback: the full 6-product pool, runs only if the flag was raised
+    VnpGemmArgs q{};
+    q.A = x; q.B = Wcat; q.M = (int)M; q.N = 2 * C; q.K = K; q.lda = ldx; q.ldb = ldw; q.rows_per_group = 1;
+    q.tiles_per_split = K / 32; q.nsplit = 1; q.nbatch = 1; q.col_group = 8; q.pool_gs = gs;
+    q.pool_val = (float*)ws_full;
+    q.pool_idx = (int*)((char*)ws_full + nslot * 4);
+    q.pool_x = (float*)((char*)ws_full + nslot * 8);
+    q.pred = &head->flag;
+    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 1>), grid, block, 0, st, q);
+    hipLaunchKernelGGL(vnp_pool_fused_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
+                       (const float*)q.pool_val, (const int*)q.pool_idx, (const float*)q.pool_x, gs / 32, C, idx, out, ldo,
+                       (const int*)&head->flag);
     return vnp_last_error();
 }
 

@@ -109,7 +109,7 @@ __device__ __forceinline__ void vnp_split_load_generic(vnp_f4 (&reg)[NV], const 
 
 // fp32 registers -> packed bf16 plane registers: pl[u][plane] holds 4 consecutive k of one row (u = float4 index j for a
 // K-contiguous operand, row-in-block e for a row-contiguous one, whose 4(k) x 4(row) block is transposed here)
-template <bool KC, int NV>
+template <bool KC, int NV, int NPL = 3>
 __device__ __forceinline__ void vnp_split_convert(const vnp_f4 (&reg)[NV], vnp_u2 (&pl)[NV][3])
 {
     static_assert(KC || NV == 4, "row-contiguous operands: 4 k-rows x 4 rows per thread");
@@ -123,12 +123,13 @@ __device__ __forceinline__ void vnp_split_convert(const vnp_f4 (&reg)[NV], vnp_u
             vnp_split_pair(reg[0][u], reg[1][u], h0, m0, l0);
             vnp_split_pair(reg[2][u], reg[3][u], h1, m1, l1);
         }
-        pl[u][0] = vnp_u2{h0, h1}; pl[u][1] = vnp_u2{m0, m1}; pl[u][2] = vnp_u2{l0, l1};
+        pl[u][0] = vnp_u2{h0, h1}; pl[u][1] = vnp_u2{m0, m1};
+        if (NPL == 3) pl[u][2] = vnp_u2{l0, l1};          // NPL = 2 (screening pass): the l plane is dead code and is never formed
     }
 }
 
 // plane registers -> LDS.  plane stride = R * 64 bytes.
-template <int R, bool KC, int NV>
+template <int R, bool KC, int NV, int NPL = 3>
 __device__ __forceinline__ void vnp_split_write(const vnp_u2 (&pl)[NV][3], char* S, int tid)
 {
     if (KC) {
@@ -137,7 +138,7 @@ __device__ __forceinline__ void vnp_split_write(const vnp_u2 (&pl)[NV][3], char*
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *(vnp_u2*)(S + base + j * 32 * 64 + q * R * 64) = pl[j][q];
+            for (int q = 0; q < NPL; ++q) *(vnp_u2*)(S + base + j * 32 * 64 + q * R * 64) = pl[j][q];
     } else {
         const int kq = vnp_split_kq(tid), r4 = vnp_split_m4(tid) * 4;       // k = 4 kq .. 4 kq + 3 -> slot kq >> 1, half kq & 1
 #pragma unroll
@@ -181,6 +182,9 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     vnp_split_offsets<BM, AKC>(oa, sa, p.lda, tid);
     vnp_split_offsets<BN, BKC>(ob, sb, p.ldb, tid);
     static_assert(EPI == 0 || (BM == 192 && BN == 128 && AKC && BKC && FAST), "the VN epilogues need the aligned 192x128 NT kernel");
+    constexpr int NPL = EPI == 3 ? 2 : 3;          // planes staged through LDS: the screening pass never touches the l plane
+    constexpr int T0 = EPI == 3 ? 3 : 0;           // first of the six products issued: EPI = 3 keeps (m h), (h m), (h h)
+    if (p.pred && *p.pred == 0) return;            // predicated launch (wave-uniform)
     int perm_off[AV];                       // EPI >= 1: element offset of the global row that LDS row tid/8 + 32 j holds
     if (EPI >= 1) {
 #pragma unroll
@@ -226,12 +230,12 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     };
     vnp_u2 pa[AV][3], pb[BV][3];
     auto convert = [&]() {
-        vnp_split_convert<AKC, AV>(ra, pa);
-        vnp_split_convert<BKC, BV>(rb, pb);
+        vnp_split_convert<AKC, AV, NPL>(ra, pa);
+        vnp_split_convert<BKC, BV, NPL>(rb, pb);
     };
     auto write = [&]() {
-        vnp_split_write<BM, AKC, AV>(pa, As, tid);
-        vnp_split_write<BN, BKC, BV>(pb, Bs, tid);
+        vnp_split_write<BM, AKC, AV, NPL>(pa, As, tid);
+        vnp_split_write<BN, BKC, BV, NPL>(pb, Bs, tid);
     };
 
     // fragment read offsets (v_mfma_f32_16x16x32_bf16 operand: lane l holds row l & 15, k = 8 (l >> 4) .. + 7 = 16-byte slot l >> 4)
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NPL; ++pl)
                         b[j][pl] = __builtin_bit_cast(vnp_bf8, *(const vnp_u4*)(Bs + pl * BPL + b_rd[j]));
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
                 constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -286,10 +290,10 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                 for (int i = 0; i < TM; ++i) {
                     vnp_bf8 a[3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NPL; ++pl)
                         a[pl] = __builtin_bit_cast(vnp_bf8, *(const vnp_u4*)(As + pl * APL + a_rd[i]));
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
+                    for (int t = T0; t < 6; ++t)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
@@ -334,6 +338,78 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                     p.pool_val[slot] = bv;
                     p.pool_idx[slot] = loc0 + bi;
                     p.pool_x[3 * slot + 0] = bx0; p.pool_x[3 * slot + 1] = bx1; p.pool_x[3 * slot + 2] = bx2;
+                }
+            }
+        } else if (EPI == 3) {
+            // Screening pass of the exact screened arg-max pool.  acc holds the 3-product values x~, d~ in the layout of EPI = 1.
+            // For every (point, channel): s~ = <x~, d~> and a rigorous bound err >= |s6 - s~| on its distance to the value s6 the
+            // 6-product kernels compute for the same pair:  |x6_t - x~_t| <= E |W_c| |f_(n,t)| =: ex_t (Cauchy-Schwarz on the
+            // dropped products and on both accumulations' fp32 rounding; E = p.screen_eps, norms = upper bounds), same for d, so
+            //   |s6 - s~| <= sum_t (|x~_t| ed_t + |d~_t| ex_t + ex_t ed_t) + 2^-21 sum_t |x~_t d~_t|   (last term: the two fmaf chains).
+            // Per 32-point block: the largest lower bound, the largest upper bound with its point, and the second-largest upper
+            // bound.  A non-finite bound poisons the slot with +Inf, which makes the selection pass raise the fallback flag.
+            const int pt0 = m0 / 3 + wm * 32;
+            const int grp = pt0 / 32;
+            const int loc0 = pt0 % p.pool_gs;
+            const int Cch = p.N >> 1;
+            const int rbase = m0 + wm * 96;
+            float nf[2][4][3];
+#pragma unroll
+            for (int i3 = 0; i3 < 2; ++i3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) nf[i3][e][t] = p.row_norm[rbase + (16 * i3 + 4 * lq + e) * 3 + t];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int colx = n0 + wn * 64 + jj * 16 + l16;
+                const float Ex = p.screen_eps * p.col_norm[colx], Ed = p.screen_eps * p.col_norm[colx + 32];
+                float lmax = -INFINITY, u1 = -INFINITY, u2 = -INFINITY;
+                int i1 = 0;
+                bool bad = false;
+#pragma unroll
+                for (int i3 = 0; i3 < 2; ++i3)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = acc[3 * i3][jj][e], x1 = acc[3 * i3 + 1][jj][e], x2 = acc[3 * i3 + 2][jj][e];
+                        const float d0 = acc[3 * i3][jj + 2][e], d1 = acc[3 * i3 + 1][jj + 2][e], d2 = acc[3 * i3 + 2][jj + 2][e];
+                        const float st = fmaf(x2, d2, fmaf(x1, d1, x0 * d0));
+                        float err = 0.f, mag = 0.f;
+                        {
+                            const float ex0 = Ex * nf[i3][e][0], ed0 = Ed * nf[i3][e][0];
+                            const float ex1 = Ex * nf[i3][e][1], ed1 = Ed * nf[i3][e][1];
+                            const float ex2 = Ex * nf[i3][e][2], ed2 = Ed * nf[i3][e][2];
+                            err = fmaf(fabsf(x0), ed0, fmaf(fabsf(d0), ex0, ex0 * ed0));
+                            err += fmaf(fabsf(x1), ed1, fmaf(fabsf(d1), ex1, ex1 * ed1));
+                            err += fmaf(fabsf(x2), ed2, fmaf(fabsf(d2), ex2, ex2 * ed2));
+                            mag = fabsf(x0 * d0) + fabsf(x1 * d1) + fabsf(x2 * d2);
+                        }
+                        err = fmaf(mag, 4.8e-7f, err) * 1.001f + 1e-37f;        // + the fmaf chains' rounding; inflated for its own rounding
+                        bad = bad || !(err < INFINITY) || !(fabsf(st) < INFINITY);
+                        const float lo = st - err, up = st + err;
+                        lmax = fmaxf(lmax, lo);
+                        if (up > u1) { u2 = u1; u1 = up; i1 = 16 * i3 + 4 * lq + e; }
+                        else u2 = fmaxf(u2, up);
+                    }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float ol = __shfl_xor(lmax, o), ou1 = __shfl_xor(u1, o), ou2 = __shfl_xor(u2, o);
+                    const int oi = __shfl_xor(i1, o);
+                    const bool ob = __shfl_xor((int)bad, o) != 0;
+                    lmax = fmaxf(lmax, ol);
+                    const bool take = ou1 > u1 || (ou1 == u1 && oi < i1);
+                    const float lose = take ? u1 : ou1;
+                    if (take) { u1 = ou1; i1 = oi; }
+                    u2 = fmaxf(fmaxf(u2, ou2), lose);
+                    bad = bad || ob;
+                }
+                if (lq == 0) {
+                    const int ch = (n0 >> 1) + wn * 32 + jj * 16 + l16;
+                    const size_t slot = (size_t)grp * Cch + ch;
+                    float4 o4;
+                    o4.x = bad ? INFINITY : lmax; o4.y = bad ? INFINITY : u1; o4.z = bad ? INFINITY : u2;
+                    o4.w = __int_as_float(loc0 + i1);
+                    ((float4*)p.pool_val)[slot] = o4;
                 }
             }
         } else if (EPI == 2) {

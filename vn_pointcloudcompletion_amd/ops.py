@@ -32,6 +32,11 @@ STATS_IN_EPILOGUE = _os.environ.get("VNP_STATS_UNFUSED", "0") != "1"
 # VNLinear -> VNMaxPool: fuse the pool into the GEMM epilogue (vnp_linear_pool_fwd) when shapes allow; VNP_POOL_UNFUSED=1 keeps
 # the two GEMMs + pool kernels
 POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
+# ... and pick the arg-max with the exact SCREENED search (vnp_linear_pool_screened_fwd: a 3-product bracketing pass + exact
+# evaluation of the surviving candidates; same bits, half the MFMA work); VNP_POOL_SCREEN=0 keeps the full 6-product epilogue
+POOL_SCREENED = _os.environ.get("VNP_POOL_SCREEN", "1") != "0"
+# tests set this to a list to receive the screened pool's diagnostics tensor (int32 [3]: candidates, fallback flag, capacity)
+POOL_SCREEN_STATS = None
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (variant, flops, start_event, end_event)
@@ -498,16 +503,21 @@ class VNLinearMaxPoolFn(Function):
             # one GEMM over the interleaved [W ; Wd W] rows whose epilogue does the arg-max pool: y and d are never written
             Wp = gemm(Wd, W, op_b=1)
             Wcat = torch.stack([_rows(W).view(C // 32, 32, K), Wp.view(C // 32, 32, K)], dim=1).reshape(2 * C, K)
-            nb = _lib.lib().vnp_linear_pool_ws_bytes(G, gs, C)
+            screened = POOL_SCREENED and gs <= 2048            # the selection pass keeps a group's 32-point blocks in registers
+            entry = "vnp_linear_pool_screened_fwd" if screened else "vnp_linear_pool_fwd"
+            nb = (_lib.lib().vnp_linear_pool_screened_ws_bytes if screened else _lib.lib().vnp_linear_pool_ws_bytes)(G, gs, C)
             ws = torch.empty((nb + 7) // 8, device=x.device, dtype=torch.int64)
             prof = GEMM_PROFILE
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            call("vnp_linear_pool_fwd", ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
+            call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
             if prof is not None:
                 e1.record()
-                prof.append(("NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
+                # algorithmic work of the pool: both products over every point; the screened search EXECUTES about half of it
+                prof.append(("NT-pool-screened" if screened else "NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
+            if screened and POOL_SCREEN_STATS is not None:
+                POOL_SCREEN_STATS.append(ws[:2].view(torch.int32)[:3].clone())
         else:
             y = gemm(x, W, nsplit=1)
             if POOL_DIRECTION_REASSOCIATE:
@@ -521,7 +531,7 @@ class VNLinearMaxPoolFn(Function):
             ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
             ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
             call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
-        _trace("linear_pool_fused_epilogue" if fused else "linear_pool_unfused", idx)
+        _trace(("linear_pool_screened" if (POOL_SCREENED and gs <= 2048) else "linear_pool_fused_epilogue") if fused else "linear_pool_unfused", idx)
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
