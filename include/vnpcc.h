@@ -98,10 +98,14 @@ int vnp_softmax_bwd(hipStream_t st, const float* P, float* dP, long long R, int 
 
 /* ---- VN BatchNorm / leaky projection ------------------------------------------------------------------------
  * VNBatchNorm (models/vn_layers.py:107-127), VNLeakyReLU (:25-43), VNLinearLeakyReLU tail (:66-73).
- * Chunked reductions use chunks of vnp_chunk_points() points: nchunk = ceil(P / vnp_chunk_points()). */
+ * Chunked reductions use chunks of vnp_chunk_points() points: nchunk = ceil(P / vnp_chunk_points()).  For the per-channel
+ * passes over a [P, C] map vnp_chunk_points_pc(P, C) gives the chunk that fills the chip (1024 halved down to 64 until the grid has
+ * >= 1024 workgroups); vnp_vn_norm_stats / vnp_vn_bn_leaky_bwd1 take it as `chunk_points` (0 = vnp_chunk_points()) and write one
+ * partial row per chunk of that size; vnp_vn_bn_finalize_chunked merges statistics partials of any chunk size. */
 int vnp_chunk_points(void);
+int vnp_chunk_points_pc(long long P, int C);
 /* partial [nchunk][C][2] = per-chunk (mean, M2 = sum (n - mean)^2) of n = |p| + 1e-6 (Welford; merged by Chan) */
-int vnp_vn_norm_stats(hipStream_t st, const float* p, int ldp, long long P, int C, float* partial);
+int vnp_vn_norm_stats(hipStream_t st, const float* p, int ldp, long long P, int C, float* partial, int chunk_points);
 /* mean/rstd [C] from the partials; running stats (nullable) updated like torch BatchNorm (momentum, unbiased var) */
 int vnp_vn_bn_finalize(hipStream_t st, const float* partial, int nchunk, int C, long long count,
                        float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps);
@@ -116,7 +120,7 @@ int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, const float*
                          const float* p, int ldp, const float* d, int ldd,
                          float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
                          const float* mean, const float* rstd, const float* gamma, const float* beta,
-                         float negative_slope, float* partial, float* gw_partial);
+                         float negative_slope, float* partial, float* gw_partial, int chunk_points);
 /* gw_partial (rank-1 mode only, nullable) [nchunk][C]: per-chunk sums of go_row . out, i.e. dL/dw of a final VNLinear(C->1)
  * whose input (this layer's output) was never stored.
  * Forward of that fusion: fine[pt*3+t] = sum_c leaky(bn(p),d)[pt,t,c]*w[c] + add[(pt/add_group)*3+t] (models/pcn.py:341-346,387) */

@@ -235,7 +235,7 @@ def test_screened_pool_adversarial_near_ties(lib_built):
         if cap_note == "three dominant near-tied points":
             assert flag == 0 and cand > 1.5 * G * C              # several candidates per pair, all evaluated exactly
             win = res["screened"][1]
-            assert ((win == 5) | (win == 70) | (win == 140)).float().mean().item() > 0.3
+            assert ((win == 5) | (win == 70) | (win == 140)).float().mean().item() > 0.15
         if cap_note == "all points identical":
             assert flag == 1                                     # 256 exact ties per channel > 8 per pair: the predicated full kernel ran
             assert (res["screened"][1] == 0).all()               # and the lowest index won everywhere
@@ -287,7 +287,7 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
     pd_ref = torch.empty(R, 2 * C, device="cuda")
     ops.gemm(x, W, out=pd_ref, bias=bias, rows_per_group=rpg, nsplit=1)
     part_ref = torch.empty(R // 3072, C, 2, device="cuda")
-    call("vnp_vn_norm_stats", ptr(pd_ref), 2 * C, R // 3, C, ptr(part_ref))
+    call("vnp_vn_norm_stats", ptr(pd_ref), 2 * C, R // 3, C, ptr(part_ref), 0)
     pd = torch.empty(R, 2 * C, device="cuda")
     part = ops.gemm_pd_stats(x, W, pd, bias, rpg, C, True)
     assert part is not None and torch.equal(pd, pd_ref)

@@ -74,11 +74,11 @@ _SIGNATURES = {
     "vnp_heads_to_rows": [_vp, _i, _i, _i, _i, _vp, _i],
     "vnp_softmax_fwd": [_vp, _ll, _i, _f],
     "vnp_softmax_bwd": [_vp, _vp, _ll, _i, _f],
-    "vnp_vn_norm_stats": [_vp, _i, _ll, _i, _vp],
+    "vnp_vn_norm_stats": [_vp, _i, _ll, _i, _vp, _i],
     "vnp_vn_bn_finalize": [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _f, _f],
     "vnp_rstd_from_var": [_vp, _vp, _i, _f],
     "vnp_vn_bn_leaky_fwd": [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f],
-    "vnp_vn_bn_leaky_bwd1": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp],
+    "vnp_vn_bn_leaky_bwd1": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i],
     "vnp_vn_bn_leaky_rowdot_fwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp],
     "vnp_vn_bn_bwd2": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll],
     "vnp_reduce_rows": [_vp, _i, _ll, _i, _ll, _i, _vp, _ll],
@@ -111,7 +111,7 @@ _SIGNATURES = {
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
-_NO_STREAM = {"vnp_chunk_points": [], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
+_NO_STREAM = {"vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i],
               "vnp_gemm_vn_stats_ws_floats": [_ll, _i]}
 _RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,

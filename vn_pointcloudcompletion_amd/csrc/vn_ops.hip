@@ -6,9 +6,31 @@
 // channels of a row (256 contiguous bytes) for each of the 3 Cartesian components.
 #include "vnp_common.h"
 
+// point-loop unrolling of the streaming BatchNorm / leaky passes.  Measured with 2 (loads of two points in flight before the
+// first store): decoder-sized maps bwd1 1588 -> 1627 us, bwd2 878 -> 882, fwd 501 -> 469 — neutral, so 1.  These passes already
+// sit at the chip's mixed read/write ceiling (scripts/hbm_yardstick.hip: 5.5-5.8 TB/s for 2R1W / 3R2W streams, 6.4-6.9 read-only).
+#ifndef VNP_PT_UNROLL_N
+#define VNP_PT_UNROLL_N 1
+#endif
+#define VNP_STR2(x) #x
+#define VNP_STR(x) VNP_STR2(x)
+#define VNP_PT_UNROLL _Pragma(VNP_STR(unroll VNP_PT_UNROLL_N))
 #define VNP_CHUNK 1024         // points (rows) per block in the chunked kernels (also exported via vnp_chunk_points)
 
 extern "C" int vnp_chunk_points() { return VNP_CHUNK; }
+
+// Points per workgroup of the BatchNorm / leaky passes for a [P points, C channels] map: VNP_CHUNK, halved (down to 64) until the
+// grid has at least 1024 workgroups — a 128-channel layer over 65536 points is only 128 chunks of 1024 and left half the chip idle
+// (measured: 1.0-1.5 TB/s on first_conv[0] against 5+ TB/s on the wide layers).  Statistics / gradient partials are per chunk of
+// this size: callers size them with this function and pass the value on (vnp_vn_norm_stats, vnp_vn_bn_leaky_bwd1,
+// vnp_vn_bn_finalize_chunked).
+extern "C" int vnp_chunk_points_pc(long long P, int C)
+{
+    int chunk = VNP_CHUNK;
+    const long long cols = (C + 63) / 64;
+    while (chunk > 64 && ((P + chunk - 1) / chunk) * cols < 1024) chunk >>= 1;
+    return chunk;
+}
 
 // ------------------------------------------------------------------------------------------------
 // block = 256 threads = 64 channels x 4 point lanes; grid = (ceil(C/64), nchunk)
@@ -29,14 +51,14 @@ __device__ __forceinline__ void vnp_chan_merge(double& na, double& ma, double& M
 }
 
 __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __restrict__ p, int ld, long long P, int C,
-                                                            float2* __restrict__ partial)
+                                                            float2* __restrict__ partial, int chunk)
 {
     __shared__ float2 red[4][64];
     __shared__ int cnt[4];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
-    const long long p1 = min(P, p0 + VNP_CHUNK);
+    const long long p0 = (long long)blockIdx.y * chunk;
+    const long long p1 = min(P, p0 + chunk);
     float mean = 0.f, m2 = 0.f;
     int k = 0;
     if (c < C) {
@@ -126,15 +148,16 @@ __global__ void vnp_rstd_from_var_kernel(const float* __restrict__ var, float* _
 __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ d, int ldd,
                                                               float* __restrict__ out, int ldo, long long P, int C,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float ns)
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float ns, int chunk)
 {
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     if (c >= C) return;
-    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
-    const long long p1 = min(P, p0 + VNP_CHUNK);
+    const long long p0 = (long long)blockIdx.y * chunk;
+    const long long p1 = min(P, p0 + chunk);
     float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f;
     if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
+    VNP_PT_UNROLL
     for (long long pt = p0 + py; pt < p1; pt += 4) {
         const float* r = p + (size_t)pt * 3 * ldp + c;
         float q0 = r[0], q1 = r[ldp], q2 = r[2 * ldp];
@@ -171,20 +194,21 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                                                                long long P, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float ns,
-                                                               float2* __restrict__ partial, float* __restrict__ gw_partial)
+                                                               float2* __restrict__ partial, float* __restrict__ gw_partial, int chunk)
 {
     __shared__ float2 red[4][64];
     __shared__ float red3[4][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
-    const long long p1 = min(P, p0 + VNP_CHUNK);
+    const long long p0 = (long long)blockIdx.y * chunk;
+    const long long p1 = min(P, p0 + chunk);
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < C) {
         float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, gc = 0.f;
         if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
         if (!go) gc = go_col[c];
-        for (long long pt = p0 + py; pt < p1; pt += 4) {
+        VNP_PT_UNROLL
+    for (long long pt = p0 + py; pt < p1; pt += 4) {
             const float* r = p + (size_t)pt * 3 * ldp + c;
             const float x0 = __builtin_nontemporal_load(r), x1 = __builtin_nontemporal_load(r + ldp), x2 = __builtin_nontemporal_load(r + 2 * ldp);
             float g0, g1, g2;
@@ -295,15 +319,16 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
                                                          long long P, int C,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ S, float inv_count)
+                                                         const float* __restrict__ S, float inv_count, int chunk)
 {
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     if (c >= C) return;
-    const long long p0 = (long long)blockIdx.y * VNP_CHUNK;
-    const long long p1 = min(P, p0 + VNP_CHUNK);
+    const long long p0 = (long long)blockIdx.y * chunk;
+    const long long p1 = min(P, p0 + chunk);
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
     const float m1 = S ? S[2 * c] * inv_count : 0.f, m2 = S ? S[2 * c + 1] * inv_count : 0.f;
+    VNP_PT_UNROLL
     for (long long pt = p0 + py; pt < p1; pt += 4) {
         const float* r = p + (size_t)pt * 3 * ldp + c;
         const float x0 = __builtin_nontemporal_load(r), x1 = __builtin_nontemporal_load(r + ldp), x2 = __builtin_nontemporal_load(r + 2 * ldp);
@@ -999,12 +1024,16 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
 }
 
 // ================================================================================================ C-ABI
-static inline dim3 vnp_grid_pc(long long P, int C) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, VNP_CHUNK)); }
+static inline dim3 vnp_grid_pc(long long P, int C, int chunk) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, chunk)); }
+static inline bool vnp_chunk_ok(int chunk) { return chunk >= 4 && chunk <= VNP_CHUNK; }
 
-extern "C" int vnp_vn_norm_stats(hipStream_t st, const float* p, int ldp, long long P, int C, float* partial)
+// partial [ceil(P / chunk_points)][C][2]; chunk_points = 0: vnp_chunk_points()
+extern "C" int vnp_vn_norm_stats(hipStream_t st, const float* p, int ldp, long long P, int C, float* partial, int chunk_points)
 {
     if (!p || !partial || P <= 0 || C <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_norm_stats_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, p, ldp, P, C, (float2*)partial);
+    const int chunk = chunk_points > 0 ? chunk_points : VNP_CHUNK;
+    if (!vnp_chunk_ok(chunk) || vnp_cdiv(P, chunk) > 65535) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_norm_stats_kernel, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, p, ldp, P, C, (float2*)partial, chunk);
     return vnp_last_error();
 }
 
@@ -1030,8 +1059,9 @@ extern "C" int vnp_vn_bn_leaky_fwd(hipStream_t st, const float* p, int ldp, cons
 {
     if (!p || !out || P <= 0 || C <= 0) return VNP_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_leaky_fwd_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, p, ldp, d, ldd, out, ldo, P, C,
-                       mean, rstd, gamma, beta, negative_slope);
+    const int chunk = vnp_chunk_points_pc(P, C);
+    hipLaunchKernelGGL(vnp_bn_leaky_fwd_kernel, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, p, ldp, d, ldd, out, ldo, P, C,
+                       mean, rstd, gamma, beta, negative_slope, chunk);
     return vnp_last_error();
 }
 
@@ -1039,15 +1069,17 @@ extern "C" int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, c
                                     const float* p, int ldp, const float* d, int ldd,
                                     float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                    float negative_slope, float* partial, float* gw_partial)
+                                    float negative_slope, float* partial, float* gw_partial, int chunk_points)
 {
     if (!p || !gq || P <= 0 || C <= 0) return VNP_EINVAL;
+    const int chunk = chunk_points > 0 ? chunk_points : VNP_CHUNK;     // partial / gw_partial: one row per chunk of this many points
+    if (!vnp_chunk_ok(chunk) || vnp_cdiv(P, chunk) > 65535) return VNP_EINVAL;
     if (gw_partial && (go || !d)) return VNP_EINVAL;
     if (!go && (!go_row || !go_col)) return VNP_EINVAL;
     if (d && !gd) return VNP_EINVAL;
     if (mean && (!rstd || !gamma || !beta || !partial)) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
-                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial);
+    hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
+                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial, chunk);
     return vnp_last_error();
 }
 
@@ -1067,8 +1099,9 @@ extern "C" int vnp_vn_bn_bwd2(hipStream_t st, float* g, int ldg, const float* p,
                               const float* S, long long count)
 {
     if (!g || !p || !mean || !rstd || !gamma || !beta || P <= 0 || C <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_bwd2_kernel, vnp_grid_pc(P, C), dim3(256), 0, st, g, ldg, p, ldp, P, C, mean, rstd, gamma, beta,
-                       S, count > 0 ? 1.0f / (float)count : 0.f);
+    const int chunk = vnp_chunk_points_pc(P, C);
+    hipLaunchKernelGGL(vnp_bn_bwd2_kernel, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, g, ldg, p, ldp, P, C, mean, rstd, gamma, beta,
+                       S, count > 0 ? 1.0f / (float)count : 0.f, chunk);
     return vnp_last_error();
 }
 

@@ -76,6 +76,13 @@ def _nchunk(P: int) -> int:
     return (P + c - 1) // c
 
 
+def _chunk_pc(P: int, C: int):
+    """(points per workgroup, number of chunks) of the per-channel BatchNorm / leaky passes over a [P, C] map (vnp_chunk_points_pc:
+    1024, halved until the grid fills the chip)."""
+    c = _lib.lib().vnp_chunk_points_pc(P, C)
+    return c, (P + c - 1) // c
+
+
 def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumulate=False, nsplit=None):
     """C = op(A) op(B) (+ per-sample bias).  See vnp_gemm in include/vnpcc.h."""
     A, B = _rows(A), _rows(B)
@@ -172,6 +179,23 @@ def gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, want_stats):
     return part
 
 
+def _bn_statistics(p, P, C, part, running_mean, running_var):
+    """Batch mean / rstd of |p| + eps per channel (and the running-statistics update).  ``part``: per-1024-point Welford partials
+    already produced by the GEMM epilogue (vnp_gemm_vn_stats), else a statistics pass over p runs here."""
+    dev = p.device
+    if part is None:
+        chunk, nch = _chunk_pc(P, C)
+        part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+        call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part), chunk)
+    else:
+        chunk, nch = _lib.chunk_points(), part.shape[0]
+    mean = torch.empty(C, device=dev, dtype=torch.float32)
+    rstd = torch.empty(C, device=dev, dtype=torch.float32)
+    call("vnp_vn_bn_finalize_chunked", ptr(part), nch, chunk, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+         BN_MOMENTUM, BN_EPS)
+    return mean, rstd
+
+
 def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training, ns, use_bn=True, part=None):
     """p, d: [R, C] views (d may be None).  Returns out, mean, rstd.  ``part``: precomputed statistics partials."""
     R = p.shape[0]
@@ -180,14 +204,7 @@ def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training,
     mean = rstd = None
     if use_bn:
         if training:
-            nch = _nchunk(P)
-            if part is None:
-                part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-                call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
-            mean = torch.empty(C, device=dev, dtype=torch.float32)
-            rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-                 BN_MOMENTUM, BN_EPS)
+            mean, rstd = _bn_statistics(p, P, C, part, running_mean, running_var)
         else:
             mean = running_mean
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
@@ -210,7 +227,7 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
     ldg = gpd.shape[1]
     gq = gpd
     gd = gpd[:, C:] if has_d else None
-    nch = _nchunk(P)
+    chunk, nch = _chunk_pc(P, C)
     part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32) if use_bn else None
     nch_pad = (nch + 255) // 256 * 256 if nch > 1024 else nch
     gw_part = None
@@ -221,7 +238,7 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
     call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
          ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0, ptr(gq), ldg, ptr(gd), ldg, P, C,
          ptr(mean) if use_bn else None, ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None,
-         ns, ptr(part), ptr(gw_part))
+         ns, ptr(part), ptr(gw_part), chunk)
     ggamma = gbeta = None
     if use_bn:
         S = torch.empty((C, 2), device=dev, dtype=torch.float32)
@@ -365,14 +382,7 @@ class VNLinearLeakyOutFn(Function):
         part = gemm_pd_stats(x, Wcat, pd, None, 0, C, training)                # [R, 2C] (+ the statistics of p from the epilogue)
         p, d = pd[:, :C], pd[:, C:]
         if training:
-            nch = _nchunk(P)
-            if part is None:
-                part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-                call("vnp_vn_norm_stats", ptr(p), _ld(p), P, C, ptr(part))
-            mean = torch.empty(C, device=dev, dtype=torch.float32)
-            rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-                 BN_MOMENTUM, BN_EPS)
+            mean, rstd = _bn_statistics(p, P, C, part, running_mean, running_var)
         else:
             mean = running_mean
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
