@@ -158,6 +158,10 @@ int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int
                     int* idx, float* out, int ldo, float* ws_val, int* ws_idx);
 int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
                     float* gx, int ldgx);
+/* same scatter ADDED into an existing gx (not zero-filled): the pooled tensor's other consumer has already written its gradient
+ * there (encoder first_conv[1] feeds maxpool1 and second_conv[0], models/pcn.py:169-172) */
+int vnp_vn_pool_bwd_acc(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
+                        float* gx, int ldgx);
 /* Backward of VNLinear followed by VNMaxPool (models/pcn.py:169-170,173-174) without the dense gradient of the linear output:
  * gW[Co][Ci] = sum_{g,t} gout[g*3+t][o] x[(g*gs+idx[g][o])*3+t][:]   (NULL: skip)
  * gx[G*gs*3][Ci] (zero-filled here) gets, for every selected point, sum_{o: idx[g][o]==n} gout[g*3+t][o] W[o][:]   (NULL: skip)

@@ -263,6 +263,41 @@ def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
     assert torch.equal(out["screened"][0].view(torch.int32), out["fused"][0].view(torch.int32))
 
 
+def test_pool_tap_adds_into_the_other_consumers_gradient(lib_built):
+    """VNMaxPoolTapFn (encoder maxpool1: the pooled tensor also feeds second_conv[0]) against the plain pool + autograd's own sum of
+    the two gradients: same pooled output and indices, same gradient for the shared input (one writer per element: bit-equal)."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(8)
+    G, gs, C, K = 3, 128, 64, 32
+    a = torch.randn(G * gs * 3, K, generator=g).cuda()
+    W = (torch.randn(C, K, generator=g) / K ** 0.5).cuda()
+    Wd = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    W2 = (torch.randn(48, C, generator=g) / C ** 0.5).cuda()
+    cot1, cot2 = torch.randn(G * 3, C, generator=g).cuda(), torch.randn(G * gs * 3, 48, generator=g).cuda()
+    res = {}
+    for tap in (False, True):
+        ar = a.clone().requires_grad_(True)
+        f = ops.VNLinearFn.apply(ar, W, None, 0)
+        if tap:
+            f2, pooled, idx = ops.VNMaxPoolTapFn.apply(f, Wd, G, gs, ar.detach(), W)
+        else:
+            pooled, idx = ops.VNMaxPoolFn.apply(f, Wd, G, gs, ar.detach(), W)
+            f2 = f
+        y = ops.VNLinearFn.apply(f2, W2, None, 0)                      # the other consumer
+        ((pooled * cot1).sum() + (y * cot2).sum()).backward()
+        res[tap] = (pooled.detach(), idx, ar.grad)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.allclose(res[True][2], res[False][2], rtol=1e-6, atol=1e-6)
+    # pooled alone (no other consumer): the dense fallback inside the tap
+    ar = a.clone().requires_grad_(True)
+    _, pooled, _ = ops.VNMaxPoolTapFn.apply(ops.VNLinearFn.apply(ar, W, None, 0), Wd, G, gs)
+    (pooled * cot1).sum().backward()
+    br = a.clone().requires_grad_(True)
+    pooled2, _ = ops.VNMaxPoolFn.apply(ops.VNLinearFn.apply(br, W, None, 0), Wd, G, gs)
+    (pooled2 * cot1).sum().backward()
+    assert torch.allclose(ar.grad, br.grad, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("nb,n,W", [(3, 1248, 40), (2, 2048, 64), (2, 1031, 16), (1, 7, 5), (4, 4992, 24)])
 def test_reduce_rows_any_count(lib_built, nb, n, W):
     """Partial-sum reduction for counts that are not multiples of 256 (config 5 folds 1248 coarse points) and for primes."""

@@ -433,6 +433,19 @@ __global__ void vnp_pool_bwd_kernel(const float* __restrict__ gout, int ldgo, co
     for (int t = 0; t < 3; ++t) gx[(row + t) * ldgx + c] = gout[((size_t)g * 3 + t) * ldgo + c];
 }
 
+// gx [(g*gs + idx[g][c])*3 + t][c] += gout[g*3+t][c]: the pool's gradient added into an existing gradient of its input (each
+// (row, channel) target has exactly one writer: no atomics)
+__global__ void vnp_pool_bwd_acc_kernel(const float* __restrict__ gout, int ldgo, const int* __restrict__ idx, int gs, int C,
+                                        float* __restrict__ gx, int ldgx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long g = blockIdx.y;
+    const size_t row = ((size_t)g * gs + idx[(size_t)g * C + c]) * 3;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) gx[(row + t) * ldgx + c] += gout[((size_t)g * 3 + t) * ldgo + c];
+}
+
 // mean over groups of gs consecutive points (vn_layers.py:170-171 on the neighbour axis); grid (ceil(C/256), G*3)
 __global__ void vnp_mean_pool_fwd_kernel(const float* __restrict__ x, int ldx, int gs, int C, float* __restrict__ out, int ldo)
 {
@@ -1150,6 +1163,19 @@ extern "C" int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, cons
     for (long long g0 = 0; g0 < G; g0 += 65535) {
         const int ng = (int)((G - g0) < 65535 ? (G - g0) : 65535);
         hipLaunchKernelGGL(vnp_pool_bwd_kernel, dim3(vnp_cdiv(C, 256), ng), dim3(256), 0, st,
+                           gout + (size_t)g0 * 3 * ldgo, ldgo, idx + (size_t)g0 * C, gs, C, gx + (size_t)g0 * gs * 3 * ldgx, ldgx);
+    }
+    return vnp_last_error();
+}
+
+// gx [G*gs*3, ldgx] += the pool's gradient (NOT zero-filled: gx already holds the gradient from the input's other consumer)
+extern "C" int vnp_vn_pool_bwd_acc(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
+                                   float* gx, int ldgx)
+{
+    if (!gout || !idx || !gx || G <= 0 || gs <= 0 || C <= 0) return VNP_EINVAL;
+    for (long long g0 = 0; g0 < G; g0 += 65535) {
+        const int ng = (int)((G - g0) < 65535 ? (G - g0) : 65535);
+        hipLaunchKernelGGL(vnp_pool_bwd_acc_kernel, dim3(vnp_cdiv(C, 256), ng), dim3(256), 0, st,
                            gout + (size_t)g0 * 3 * ldgo, ldgo, idx + (size_t)g0 * C, gs, C, gx + (size_t)g0 * gs * 3 * ldgx, ldgx);
     }
     return vnp_last_error();

@@ -495,6 +495,48 @@ class VNMaxPoolFn(Function):
         return gx, None, None, None, None, None
 
 
+class VNMaxPoolTapFn(Function):
+    """VNMaxPool of a tensor that has a SECOND consumer (encoder: first_conv[1]'s output feeds maxpool1 and, concatenated with the
+    pooled feature, second_conv[0]; models/pcn.py:169-172).  Returns (x, pooled, idx): the caller hands the returned x to the other
+    consumer, so that in backward this node receives that consumer's gradient and ADDS the pool's one-row-per-channel gradient
+    into it in place (vnp_vn_pool_bwd_acc) — instead of materialising a dense, mostly-zero [P*3, C] gradient and letting autograd
+    sum two 400 MB tensors (zero-fill + scatter + add: 0.3 ms per step of config 2)."""
+
+    @staticmethod
+    def forward(ctx, x, Wd, G, gs, x_prev=None, W_prev=None):
+        xr = _rows(x)
+        C = xr.shape[1]
+        if x_prev is not None and POOL_DIRECTION_REASSOCIATE:
+            d = gemm(_rows(x_prev), gemm(Wd, W_prev, op_b=1), nsplit=1)
+        else:
+            d = gemm(xr, Wd, nsplit=1)
+        nch = _nchunk(gs)
+        ws_val = torch.empty((G, nch, C), device=xr.device, dtype=torch.float32)
+        ws_idx = torch.empty((G, nch, C), device=xr.device, dtype=torch.int32)
+        idx = torch.empty((G, C), device=xr.device, dtype=torch.int32)
+        out = torch.empty((G * 3, C), device=xr.device, dtype=torch.float32)
+        call("vnp_vn_pool_fwd", ptr(xr), _ld(xr), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        _trace("pool_tap", idx)
+        ctx.save_for_backward(idx)
+        ctx.cfg = (G, gs, C)
+        ctx.mark_non_differentiable(idx)
+        return x, out, idx                      # x as-is: autograd hands back an alias whose gradient flows through this node
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx, gout, _gidx):
+        (idx,) = ctx.saved_tensors
+        G, gs, C = ctx.cfg
+        gout = _rows(gout)
+        if gx is None or gx.dim() != 2 or gx.stride(1) != 1 or gx.shape != (G * gs * 3, C):
+            dense = torch.empty((G * gs * 3, C), device=gout.device, dtype=torch.float32)
+            call("vnp_vn_pool_bwd", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(dense), C)
+            return (dense if gx is None else gx + dense), None, None, None, None, None
+        # gx is the other consumer's freshly computed gradient (this node is its only user): accumulate in place
+        call("vnp_vn_pool_bwd_acc", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(gx), _ld(gx))
+        return gx, None, None, None, None, None
+
+
 class VNLinearMaxPoolFn(Function):
     """VNLinear followed by VNMaxPool when the pool is the linear output's ONLY consumer (encoder second_conv[1] ->
     maxpool2, models/pcn.py:173-174).  Forward: y = x W^T, d = y Wd^T, arg-max pool (y and d are dropped afterwards).

@@ -59,7 +59,8 @@ class VN_PointNet(nn.Module):
         x = xyz.contiguous().float().reshape(B * N * 3, 1)                       # rows layout with C = 1 IS xyz
         a1 = self.first_conv[0].forward_rows(x)
         f = self.first_conv[1].forward_rows(a1)                                 # [B*N*3, 512]
-        g1 = self.maxpool1.forward_rows(f, B, N, producer=(a1, self.first_conv[1]))   # [B*3, 512]
+        # f feeds maxpool1 AND second_conv[0]: the pool hands f back so that its sparse gradient is added into second_conv[0]'s
+        f, g1 = self.maxpool1.forward_rows_tap(f, B, N, producer=(a1, self.first_conv[1]))   # g1 [B*3, 512]
         f = self.second_conv[0].forward_rows(f, global_rows=g1, rows_per_group=N * 3)
         # second_conv[1] + maxpool2 fused: the linear output has no other consumer, so its (one-point-per-channel)
         # gradient is never materialised (ops.VNLinearMaxPoolFn)

@@ -189,6 +189,13 @@ class VNMaxPool(nn.Module):
         out, idx = ops.VNMaxPoolFn.apply(rows, self.map_to_dir.weight.detach(), groups, group_size, xp, wp)
         return (out, idx) if return_index else out
 
+    def forward_rows_tap(self, rows, groups, group_size, producer=None):
+        """Pool a tensor that has another consumer: returns (rows, pooled).  Feed the RETURNED rows to that consumer — the pool's
+        gradient is then added into its gradient in place (ops.VNMaxPoolTapFn)."""
+        xp, wp = (producer[0].detach(), producer[1].map_to_feat.weight.detach()) if producer is not None else (None, None)
+        rows2, out, _ = ops.VNMaxPoolTapFn.apply(rows, self.map_to_dir.weight.detach(), groups, group_size, xp, wp)
+        return rows2, out
+
     def forward(self, x):
         rows, (B, tail, nflat) = to_rows(x)
         gs = tail[-1]
