@@ -8,7 +8,10 @@ golden fixtures), this oracle and the HIP path.
 
 Parity status: PINNED — every function here is checked against the imported
 reference by ``tests/golden/make_golden.py`` (run in the build container) and against
-the committed fixtures by ``tests/test_oracle_golden.py``.
+the committed fixtures by ``tests/test_oracle_golden.py`` (layers, both networks, Chamfer,
+and since round 2 calc_dcd / fscore against the reference's utils/loss.py + fscore.py:
+tests/golden/dcd.npz) — EXCEPT ``knn_torch`` / ``fps_torch``, which stand for third-party
+CUDA packages whose sources are absent: PARITY UNPINNED, conventions stated at each function.
 """
 from __future__ import annotations
 
