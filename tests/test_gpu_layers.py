@@ -263,6 +263,36 @@ def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
     assert torch.equal(out["screened"][0].view(torch.int32), out["fused"][0].view(torch.int32))
 
 
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("rank1", [False, True])
+def test_bn_backward_two_pass_equals_bwd1_bwd2(lib_built, training, rank1):
+    """vnp_vn_bn_leaky_bwd_pass (sums, then final gradients with phase 2 applied on the fly) against vnp_vn_bn_leaky_bwd1 ->
+    vnp_vn_bn_bwd2: the same arithmetic term for term, so dL/dp, dL/dd, dL/dgamma, dL/dbeta (and dL/dw_out in the rank-1 form of the
+    fused decoder tail) agree to the last bits of fp32 contraction (1e-6 relative)."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(31)
+    P, C = 3000, 96
+    pd = torch.randn(P * 3, 2 * C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    _, mean, rstd = ops._bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, rm, rv, True, 0.2)
+    go = torch.randn(P * 3, C, generator=g).cuda()
+    grow, gcol = torch.randn(P * 3, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    res = {}
+    for two in (True, False):
+        ops.BN_BWD_TWO_PASS = two
+        try:
+            if rank1:
+                res[two] = ops._bn_leaky_backward(None, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2,
+                                                  go_row=grow, go_col=gcol, want_gw=True)
+            else:
+                res[two] = ops._bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2)
+        finally:
+            ops.BN_BWD_TWO_PASS = True
+    for a, b in zip(res[True], res[False]):
+        assert relerr(a, b) < 2e-6
+
+
 def test_pool_tap_adds_into_the_other_consumers_gradient(lib_built):
     """VNMaxPoolTapFn (encoder maxpool1: the pooled tensor also feeds second_conv[0]) against the plain pool + autograd's own sum of
     the two gradients: same pooled output and indices, same gradient for the shared input (one writer per element: bit-equal)."""

@@ -187,6 +187,12 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
 // go[r][c] = go_row[r] * go_col[c] (gradient of the final VNLinear(C->1), models/pcn.py:346).
 // Writes gq = dL/dq (q = bn(p)) and gd = dL/dd, and the per-chunk partial sums S1 = sum g_nhat, S2 = sum g_nhat*xhat
 // (= dL/dbeta, dL/dgamma).  Without BatchNorm (mean == nullptr) gq is already dL/dp.
+// MODE 0: as described above (gq = dL/dq, finished by vnp_bn_bwd2_kernel).  The two-pass form reads the inputs twice and never
+// writes dL/dq:  MODE 1 = sums only (partial, gw_partial; nothing else is written);  MODE 2 = final gradients: with the reduced
+// sums S ([C][2]; nullptr in eval mode) it applies phase 2 on the fly and writes gq = dL/dp and gd.  Against bwd1 + bwd2 this
+// trades a written-then-re-read map for a second read of the inputs: 6 maps instead of 7 in the rank-1 form (2R + 2R2W against
+// 2R2W + 2R1W), 8 = 8 in the matrix form but with 6 reads / 2 writes instead of 5 / 3 (reads stream faster: hbm_yardstick).
+template <int MODE>
 __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __restrict__ go, int ldgo,
                                                                const float* __restrict__ go_row, const float* __restrict__ go_col,
                                                                const float* __restrict__ p, int ldp, const float* __restrict__ d, int ldd,
@@ -194,7 +200,8 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                                                                long long P, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float ns,
-                                                               float2* __restrict__ partial, float* __restrict__ gw_partial, int chunk)
+                                                               float2* __restrict__ partial, float* __restrict__ gw_partial, int chunk,
+                                                               const float* __restrict__ S, float inv_count)
 {
     __shared__ float2 red[4][64];
     __shared__ float red3[4][64];
@@ -207,6 +214,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
         float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, gc = 0.f;
         if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
         if (!go) gc = go_col[c];
+        const float m1 = (MODE == 2 && S) ? S[2 * c] * inv_count : 0.f, m2 = (MODE == 2 && S) ? S[2 * c + 1] * inv_count : 0.f;
         VNP_PT_UNROLL
     for (long long pt = p0 + py; pt < p1; pt += 4) {
             const float* r = p + (size_t)pt * 3 * ldp + c;
@@ -230,7 +238,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                 const float d0 = __builtin_nontemporal_load(rd), d1 = __builtin_nontemporal_load(rd + ldd), d2 = __builtin_nontemporal_load(rd + 2 * ldd);
                 const float dot = q0 * d0 + q1 * d1 + q2 * d2;
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f;
-                if (gw_partial) {
+                if (MODE != 2 && gw_partial) {
                     // layer output (q or its projection) against the upstream gradient: d(loss)/d(w_out) of the fused
                     // final VNLinear(C -> 1)
                     float o0 = q0, o1 = q1, o2 = q2;
@@ -252,18 +260,32 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                     e2 = -cc * (a * g2 + gdd * (q2 * inv - 2.f * a * inv * d2));
                     g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;
                 }
-                float* wd = gd + (size_t)pt * 3 * ldgd + c;
-                __builtin_nontemporal_store(e0, wd); __builtin_nontemporal_store(e1, wd + ldgd); __builtin_nontemporal_store(e2, wd + 2 * ldgd);
+                if (MODE != 1) {
+                    float* wd = gd + (size_t)pt * 3 * ldgd + c;
+                    __builtin_nontemporal_store(e0, wd); __builtin_nontemporal_store(e1, wd + ldgd); __builtin_nontemporal_store(e2, wd + 2 * ldgd);
+                }
             }
-            float* wq = gq + (size_t)pt * 3 * ldgq + c;
-            __builtin_nontemporal_store(g0, wq); __builtin_nontemporal_store(g1, wq + ldgq); __builtin_nontemporal_store(g2, wq + 2 * ldgq);
-            if (mean) {
+            if (MODE == 2 && mean) {
+                // phase 2 on the fly (the arithmetic of vnp_bn_bwd2_kernel, term for term): g = dL/dq -> dL/dp
+                const float pn = n - VNP_EPS;
+                const float nh = xh * ga + be;
+                const float gs = g0 * x0 + g1 * x1 + g2 * x2;
+                const float gnh = gs / n;
+                const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
+                const float k = pn > 0.f ? gn / pn : 0.f;
+                g0 = s * g0 + k * x0; g1 = s * g1 + k * x1; g2 = s * g2 + k * x2;
+            }
+            if (MODE != 1) {
+                float* wq = gq + (size_t)pt * 3 * ldgq + c;
+                __builtin_nontemporal_store(g0, wq); __builtin_nontemporal_store(g1, wq + ldgq); __builtin_nontemporal_store(g2, wq + 2 * ldgq);
+            }
+            if (MODE != 2 && mean) {
                 const float gnh = (g0 * x0 + g1 * x1 + g2 * x2) / n;     // dL/dnhat = (gq . p) / n
                 s1 += gnh; s2 += gnh * xh;
             }
         }
     }
-    if (partial || gw_partial) {
+    if (MODE != 2 && (partial || gw_partial)) {
         red[py][cx] = make_float2(s1, s2);
         red3[py][cx] = s3;
         __syncthreads();
@@ -1091,8 +1113,39 @@ extern "C" int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, c
     if (!go && (!go_row || !go_col)) return VNP_EINVAL;
     if (d && !gd) return VNP_EINVAL;
     if (mean && (!rstd || !gamma || !beta || !partial)) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
-                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial, chunk);
+    hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel<0>, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
+                       gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial, chunk,
+                       (const float*)nullptr, 0.f);
+    return vnp_last_error();
+}
+
+// Two-pass backward of BatchNorm-over-norms + leaky projection (see vnp_bn_leaky_bwd1_kernel).
+//   pass 1: partial [nchunk][C][2] (and gw_partial) only — gq / gd are not touched and may be NULL;
+//   pass 2: gq = dL/dp (phase 2 applied with the reduced sums S [C][2], NULL = eval mode: no batch terms) and gd; no partials.
+// mean must be non-NULL (without BatchNorm there is no phase 2: use vnp_vn_bn_leaky_bwd1).
+extern "C" int vnp_vn_bn_leaky_bwd_pass(hipStream_t st, int pass, const float* go, int ldgo, const float* go_row, const float* go_col,
+                                        const float* p, int ldp, const float* d, int ldd,
+                                        float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
+                                        const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                        float negative_slope, float* partial, float* gw_partial, int chunk_points,
+                                        const float* S, long long count)
+{
+    if (!p || P <= 0 || C <= 0 || (pass != 1 && pass != 2)) return VNP_EINVAL;
+    if (!mean || !rstd || !gamma || !beta) return VNP_EINVAL;
+    if (!go && (!go_row || !go_col)) return VNP_EINVAL;
+    if (pass == 1 && (!partial || (gw_partial && (go || !d)))) return VNP_EINVAL;
+    if (pass == 2 && (!gq || (d && !gd))) return VNP_EINVAL;
+    const int chunk = chunk_points > 0 ? chunk_points : VNP_CHUNK;
+    if (!vnp_chunk_ok(chunk) || vnp_cdiv(P, chunk) > 65535) return VNP_EINVAL;
+    const float inv = count > 0 ? 1.0f / (float)count : 0.f;
+    if (pass == 1)
+        hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel<1>, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
+                           gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial, chunk,
+                           (const float*)nullptr, 0.f);
+    else
+        hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel<2>, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
+                           gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)nullptr, (float*)nullptr, chunk,
+                           S, inv);
     return vnp_last_error();
 }
 

@@ -35,6 +35,9 @@ POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
 # ... and pick the arg-max with the exact SCREENED search (vnp_linear_pool_screened_fwd: a 3-product bracketing pass + exact
 # evaluation of the surviving candidates; same bits, half the MFMA work); VNP_POOL_SCREEN=0 keeps the full 6-product epilogue
 POOL_SCREENED = _os.environ.get("VNP_POOL_SCREEN", "1") != "0"
+# BatchNorm + leaky backward in two read-heavy passes (sums, then final gradients) instead of bwd1 -> reduce -> bwd2, which writes
+# dL/dq and reads it back (VNP_BN_BWD_TWO_PASS=0 keeps that form); same arithmetic term for term
+BN_BWD_TWO_PASS = _os.environ.get("VNP_BN_BWD_TWO_PASS", "1") != "0"
 # tests set this to a list to receive the screened pool's diagnostics tensor (int32 [3]: candidates, fallback flag, capacity)
 POOL_SCREEN_STATS = None
 
@@ -235,17 +238,28 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
         gw_part = (torch.zeros if nch_pad != nch else torch.empty)((nch_pad, C), device=dev, dtype=torch.float32)
     if go is not None:
         go = _rows(go)
-    call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
-         ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0, ptr(gq), ldg, ptr(gd), ldg, P, C,
-         ptr(mean) if use_bn else None, ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None,
-         ns, ptr(part), ptr(gw_part), chunk)
     ggamma = gbeta = None
-    if use_bn:
+    if use_bn and BN_BWD_TWO_PASS:
+        # pass 1: the per-channel sums (read-only);  pass 2: final dL/dp | dL/dd with phase 2 applied on the fly — dL/dq is never
+        # written and re-read (vnp_vn_bn_leaky_bwd_pass)
+        args = (ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col), ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0,
+                ptr(gq), ldg, ptr(gd), ldg, P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
+        call("vnp_vn_bn_leaky_bwd_pass", 1, *args, ptr(part), ptr(gw_part), chunk, None, P)
         S = torch.empty((C, 2), device=dev, dtype=torch.float32)
         call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
-        call("vnp_vn_bn_bwd2", ptr(gq), ldg, ptr(p), _ld(p), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
-             ptr(S) if training else None, P)
+        call("vnp_vn_bn_leaky_bwd_pass", 2, *args, None, None, chunk, ptr(S) if training else None, P)
         gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
+    else:
+        call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
+             ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0, ptr(gq), ldg, ptr(gd), ldg, P, C,
+             ptr(mean) if use_bn else None, ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None,
+             ns, ptr(part), ptr(gw_part), chunk)
+        if use_bn:
+            S = torch.empty((C, 2), device=dev, dtype=torch.float32)
+            call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
+            call("vnp_vn_bn_bwd2", ptr(gq), ldg, ptr(p), _ld(p), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+                 ptr(S) if training else None, P)
+            gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
     if want_gw:
         return gpd, ggamma, gbeta, reduce_rows(gw_part, 1, nch_pad, C)
     return gpd, ggamma, gbeta
