@@ -160,8 +160,9 @@ def _pool_three_ways(f, W, Wd, G, gs, stats=None):
     pool-kernel path."""
     from vn_pointcloudcompletion_amd import ops
     res = {}
-    for name, fused, screened in (("screened", True, True), ("fused", True, False), ("unfused", False, False)):
-        ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED = fused, screened
+    for name, fused, screened, pas in (("screened", True, True, "fp16"), ("screened_bf16x3", True, True, "bf16x3"), ("fused", True, False, "fp16"),
+                                       ("unfused", False, False, "fp16")):
+        ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED, ops.POOL_SCREEN_PASS = fused, screened, pas
         ops.POOL_SCREEN_STATS = stats if name == "screened" else None
         try:
             fx, Wx = f.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
@@ -169,12 +170,12 @@ def _pool_three_ways(f, W, Wd, G, gs, stats=None):
             (out * torch.arange(out.numel(), device="cuda").reshape(out.shape).cos()).sum().backward()
             res[name] = (out.detach(), idx, fx.grad, Wx.grad)
         finally:
-            ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED, ops.POOL_SCREEN_STATS = True, True, None
+            ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED, ops.POOL_SCREEN_STATS, ops.POOL_SCREEN_PASS = True, True, None, "fp16"
     return res
 
 
 def _assert_pool_bits_equal(res):
-    for name in ("screened", "fused"):
+    for name in ("screened", "screened_bf16x3", "fused"):
         assert torch.equal(res[name][1], res["unfused"][1]), name                                  # indices
         assert torch.equal(res[name][0].view(torch.int32), res["unfused"][0].view(torch.int32)), name   # pooled vectors, bit patterns
         assert torch.equal(res[name][2], res["unfused"][2]) and torch.equal(res[name][3], res["unfused"][3]), name

@@ -321,16 +321,18 @@ __global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restri
 }
 
 struct VnpScreenHead { int count; int flag; int cap; int pad; };     // head of the workspace (device memory)
+#define VNP_POOL_SCREEN_FP16 1
 
 __global__ void vnp_pool_screen_init_kernel(VnpScreenHead* head, int cap) { head->count = 0; head->flag = 0; head->cap = cap; head->pad = 0; }
 
-// per (group, channel): L = largest lower bound; every block whose largest upper bound reaches L contributes its top point —
-// or all 32 of its points when its second-largest upper bound reaches L too.  A workgroup = 64 channels x 4 quarters of the
+// per (group, channel): L = largest lower bound; every block whose largest upper bound reaches L contributes its top point, its
+// second point when that one's upper bound reaches L too — or all 32 of its points when even the third-largest does.  A workgroup = 64 channels x 4 quarters of the
 // group's 32-point blocks; each thread keeps its quarter's slots in registers (one pass over memory), the four quarters meet in
 // LDS, and the workgroup appends ALL its pairs with one atomicAdd, so the candidates of neighbouring channels are contiguous in
 // the list (coalesced reads in the exact and final passes).  grid (C/64, G), 256 threads; nparts <= 4 * SEL_MAXQ.
 #define SEL_MAXQ 16
-__global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float4* __restrict__ slots, int nparts, int C, int gs,
+__global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float4* __restrict__ slots, const int* __restrict__ slot_idx,
+                                                                     int nparts, int C, int gs,
                                                                      VnpScreenHead* __restrict__ head, int2* __restrict__ seg, int2* __restrict__ list)
 {
     __shared__ float sL[4][64];
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float
         if (k0 + j < k1) {
             v[j] = sl[(size_t)(k0 + j) * C];
             L = fmaxf(L, v[j].x);
-            bad |= !(v[j].x < INFINITY) || !(v[j].y < INFINITY) || !(v[j].z < INFINITY);
+            bad |= !(v[j].x < INFINITY) || !(v[j].y < INFINITY) || !(v[j].z < INFINITY) || !(v[j].w < INFINITY);
         }
     }
     sL[qy][cx] = L; sbad[qy][cx] = bad;
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < SEL_MAXQ; ++j)
-        if (k0 + j < k1 && v[j].y >= L) cnt += (v[j].z >= L) ? 32 : 1;
+        if (k0 + j < k1 && v[j].y >= L) cnt += (v[j].w >= L) ? 32 : (v[j].z >= L) ? 2 : 1;
     scnt[qy][cx] = cnt;
     __syncthreads();
     // exclusive prefix over (channel, quarter) in channel-major order: thread (cx, qy) starts after all pairs of channels < cx and
@@ -391,8 +393,12 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float
 #pragma unroll
     for (int j = 0; j < SEL_MAXQ; ++j) {
         if (k0 + j < k1 && v[j].y >= L) {
-            if (v[j].z >= L) { for (int i = 0; i < 32; ++i) list[w++] = make_int2(pbase + (k0 + j) * 32 + i, c); }
-            else list[w++] = make_int2(pbase + __float_as_int(v[j].w), c);
+            if (v[j].w >= L) { for (int i = 0; i < 32; ++i) list[w++] = make_int2(pbase + (k0 + j) * 32 + i, c); }
+            else {
+                const int packed = slot_idx[((size_t)g * nparts + k0 + j) * C + c];
+                list[w++] = make_int2(pbase + (packed & 0xffff), c);
+                if (v[j].z >= L) list[w++] = make_int2(pbase + (packed >> 16), c);
+            }
         }
     }
 }
@@ -402,13 +408,15 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float
 // pool kernels' fmaf form.  Operands go global -> registers -> MFMA (a lane's fragment IS row lane&15, k = 8 (lane>>4) .. +7).
 __global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Wcat, int ldw,
                                                                     int K, const VnpScreenHead* __restrict__ head, const int2* __restrict__ list,
-                                                                    float4* __restrict__ res)
+                                                                    const int* __restrict__ order, float4* __restrict__ res)
 {
     const int count = head->flag ? 0 : head->count;
     const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile * 16 >= count) return;
-    const int mine = min(tile * 16 + l16, count - 1);
+    // pairs are visited in point order (order[]: counting sort by point), so the 16 pairs of a wave share a few points and the
+    // feature rows — 12 KB per point, the bulk of this pass's traffic — are fetched once instead of once per pair
+    const int mine = order[min(tile * 16 + l16, count - 1)];
     const int2 pc = list[mine];
     const float* f0 = x + (size_t)pc.x * 3 * ldx + lq * 8;
     const float* w0 = Wcat + (size_t)((pc.y >> 5) * 64 + (pc.y & 31)) * ldw + lq * 8;
@@ -466,30 +474,76 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float*
         float4 o;
         o.x = xv[0]; o.y = xv[1]; o.z = xv[2];
         o.w = fmaf(xv[2], dv[2], fmaf(xv[1], dv[1], xv[0] * dv[0]));      // the pool kernels' score form
-        res[tile * 16 + l16] = o;
+        res[mine] = o;
     }
 }
 
+// ---- counting sort of the candidate pairs by group of 4 consecutive points (3 tiny kernels; the list itself stays grouped by
+// (sample, channel)) ----
+__global__ void vnp_pool_screen_hist_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ list, int* __restrict__ hist)
+{
+    const int count = head->flag ? 0 : head->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) atomicAdd(&hist[list[i].x >> 2], 1);
+}
+
+// in place: hist[n] -> exclusive prefix sums (one workgroup of 1024 threads, contiguous chunks + an LDS scan of the chunk totals)
+__global__ void __launch_bounds__(1024) vnp_pool_screen_scan_kernel(int* __restrict__ hist, int n)
+{
+    __shared__ int tot[1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += hist[i];
+    tot[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? tot[t - o] : 0;
+        __syncthreads();
+        tot[t] += v;
+        __syncthreads();
+    }
+    int run = tot[t] - s;
+    for (int i = lo; i < hi; ++i) { const int v = hist[i]; hist[i] = run; run += v; }
+}
+
+__global__ void vnp_pool_screen_scatter_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ list, int* __restrict__ cursor,
+                                               int* __restrict__ order)
+{
+    const int count = head->flag ? 0 : head->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) order[atomicAdd(&cursor[list[i].x >> 2], 1)] = i;
+}
+
 // per (group, channel): arg-max over its candidates' exact scores (strictly greater wins, ties to the lowest point: the first maximum
-// of an ascending scan, as vnp_vn_pool_fwd), index and pooled vector out.  Skipped when the flag is up (the fallback writes them).
-__global__ void vnp_pool_screen_final_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ seg, const int2* __restrict__ list,
-                                             const float4* __restrict__ res, int C, int gs, int* __restrict__ idx, float* __restrict__ out, int ldo)
+// of an ascending scan, as vnp_vn_pool_fwd), index and pooled vector out.  Eight lanes share a pair (a pair has 1-3 candidates as a rule
+// but a whole 32-point block now and then: one thread per pair made the block wait for its longest loop).  Skipped when the flag is up
+// (the fallback writes the outputs).  grid (ceil(C/32), G), 256 threads = 32 channels x 8 lanes
+__global__ void __launch_bounds__(256) vnp_pool_screen_final_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ seg,
+                                                                    const int2* __restrict__ list, const float4* __restrict__ res, int C, int gs,
+                                                                    int* __restrict__ idx, float* __restrict__ out, int ldo)
 {
     if (head->flag) return;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int sub = threadIdx.x & 7;
+    const int c = blockIdx.x * 32 + (threadIdx.x >> 3);
     const long long g = blockIdx.y;
-    const int2 sg = seg[(size_t)g * C + c];
-    float best = 0.f; int bp = 0x7fffffff; float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = sg.x; i < sg.x + sg.y; ++i) {
+    const bool live = c < C;
+    const int2 sg = live ? seg[(size_t)g * C + c] : make_int2(0, 0);
+    float best = 0.f; int bp = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
+    for (int i = sg.x + sub; i < sg.x + sg.y; i += 8) {
         const float4 r = res[i];
         const int pt = list[i].x;
-        if (bp == 0x7fffffff || r.w > best || (r.w == best && pt < bp)) { best = r.w; bp = pt; bx = r; }
+        if (bp == 0x7fffffff || r.w > best || (r.w == best && pt < bp)) { best = r.w; bp = pt; bx = r.x; by = r.y; bz = r.z; }
     }
-    idx[(size_t)g * C + c] = bp - (int)(g * gs);
-    out[((size_t)g * 3 + 0) * ldo + c] = bx.x;
-    out[((size_t)g * 3 + 1) * ldo + c] = bx.y;
-    out[((size_t)g * 3 + 2) * ldo + c] = bx.z;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        const float ob = __shfl_xor(best, o), ox = __shfl_xor(bx, o), oy = __shfl_xor(by, o), oz = __shfl_xor(bz, o);
+        const int op = __shfl_xor(bp, o);
+        if (op != 0x7fffffff && (bp == 0x7fffffff || ob > best || (ob == best && op < bp))) { best = ob; bp = op; bx = ox; by = oy; bz = oz; }
+    }
+    if (live && sub == 0) {
+        idx[(size_t)g * C + c] = bp - (int)(g * gs);
+        out[((size_t)g * 3 + 0) * ldo + c] = bx;
+        out[((size_t)g * 3 + 1) * ldo + c] = by;
+        out[((size_t)g * 3 + 2) * ldo + c] = bz;
+    }
 }
 
 static inline long long vnp_align256(long long v) { return (v + 255) / 256 * 256; }
@@ -501,16 +555,17 @@ extern "C" long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int 
 {
     if (G <= 0 || gs <= 0 || C <= 0 || gs % 32) return 0;
     const long long nslot = G * (gs / 32) * (long long)C, cap = vnp_screen_cap(G, C);
-    return 256 + vnp_align256(G * gs * 3 * 4) + vnp_align256(2LL * C * 4) + vnp_align256(nslot * 16) + vnp_align256(G * C * 8) +
-           vnp_align256(cap * 8) + vnp_align256(cap * 16) + vnp_align256(vnp_linear_pool_ws_bytes(G, gs, C));
+    return 256 + vnp_align256(G * gs * 3 * 4) + vnp_align256(2LL * C * 4) + vnp_align256(nslot * 16) + vnp_align256(nslot * 4) + vnp_align256(G * C * 8) +
+           vnp_align256(cap * 8) + vnp_align256(cap * 16) + vnp_align256(G * gs * 4) + vnp_align256(cap * 4) +
+           vnp_align256(vnp_linear_pool_ws_bytes(G, gs, C));
 }
 
 // Same contract, arguments and results (bit for bit) as vnp_linear_pool_fwd; ws: vnp_linear_pool_screened_ws_bytes(G, gs, C) bytes.
 // After the call ws begins with {int candidates, int fallback_flag, int capacity} (diagnostics; device memory).
 extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
-                                            int K, int* idx, float* out, int ldo, void* ws)
+                                            int K, int* idx, float* out, int ldo, void* ws, int flags)
 {
-    if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0) return VNP_EINVAL;
+    if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0 || (flags & ~1)) return VNP_EINVAL;
     const long long M = G * gs * 3;
     if (vnp_gemm_get_mode() != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || M > 2147483647LL ||
         (uintptr_t)x % 16 || (uintptr_t)Wcat % 16 || G > 65535 || G * gs > 2147483647LL || gs / 32 > 4 * SEL_MAXQ)
@@ -521,9 +576,12 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     float* rnorm = (float*)w;                      w += vnp_align256(M * 4);
     float* cnorm = (float*)w;                      w += vnp_align256(2LL * C * 4);
     float4* slots = (float4*)w;                    w += vnp_align256(nslot * 16);
+    int* slot_idx = (int*)w;                       w += vnp_align256(nslot * 4);
     int2* seg = (int2*)w;                          w += vnp_align256(G * C * 8);
     int2* list = (int2*)w;                         w += vnp_align256(cap * 8);
     float4* res = (float4*)w;                      w += vnp_align256(cap * 16);
+    int* hist = (int*)w;                           w += vnp_align256(G * gs * 4);
+    int* order = (int*)w;                          w += vnp_align256(cap * 4);
     void* ws_full = (void*)w;
     hipLaunchKernelGGL(vnp_pool_screen_init_kernel, dim3(1), dim3(1), 0, st, head, (int)cap);
     hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(M, 4)), dim3(256), 0, st, x, ldx, M, K, rnorm);
@@ -533,21 +591,36 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     p.M = (int)M; p.N = 2 * C; p.K = K;
     p.lda = ldx; p.ldb = ldw; p.ldc = 0; p.rows_per_group = 1;
     p.tiles_per_split = K / 32; p.nsplit = 1; p.nbatch = 1;
-    p.pool_val = (float*)slots; p.pool_gs = gs; p.col_group = 8;
+    p.pool_val = (float*)slots; p.pool_idx = slot_idx; p.pool_gs = gs; p.col_group = 8;
     p.row_norm = rnorm; p.col_norm = cnorm;
-    // E: dropped products (h l)+(l h)+(m m)+... <= 3.05 * 2^-18 of |w||f| per term, plus the worst-case fp32 rounding of BOTH
-    // accumulations in any summation order (3K and 6K terms, unit roundoff 2^-24, terms <= 1.01 |w||f|)
-    p.screen_eps = 1.17e-5f + 9.2f * (float)K * 5.9605e-8f;
     const long long items = (M / 192) * (2LL * C / 128);
     if (items > 2147483647LL) return VNP_EINVAL;
     const long long capwg = (long long)vnp_num_cus() * 2;
     dim3 grid((unsigned)(items < capwg ? items : capwg)), block(256);
-    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 3>), grid, block, 0, st, p);
+    if (flags & VNP_POOL_SCREEN_FP16) {
+        // ONE fp16 product per operand pair (11 significant bits against bf16's 8): |w f - w~ f~| <= (2^-10 + 2^-22) |w||f| +
+        // 2^-25 (|w| + |f|) (the second term: operands under fp16's normal range; an operand over 65504 becomes Inf and raises the
+        // fallback flag through a non-finite bound), plus the worst-case fp32 rounding of both accumulations (K and 6K terms)
+        p.screen_eps = 9.78e-4f + 7.2f * (float)K * 5.9605e-8f;
+        p.screen_abs = 3.0e-8f * sqrtf((float)K) * 1.01f;
+        hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, st, p);
+    } else {
+        // THREE bf16 products: dropped (h l)+(l h)+(m m)+... <= 3.05 * 2^-18 of |w||f| per term, plus the worst-case fp32 rounding of
+        // BOTH accumulations in any summation order (3K and 6K terms, unit roundoff 2^-24, terms <= 1.01 |w||f|)
+        p.screen_eps = 1.17e-5f + 9.2f * (float)K * 5.9605e-8f;
+        p.screen_abs = 0.f;
+        hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 3>), grid, block, 0, st, p);
+    }
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)G * gs, st);                  // G*gs/4 bins (gs % 32 == 0)
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vnp_pool_screen_select_kernel, dim3(C / 64, (unsigned)G), dim3(256), 0, st,
-                       (const float4*)slots, gs / 32, C, gs, head, seg, list);
+                       (const float4*)slots, (const int*)slot_idx, gs / 32, C, gs, head, seg, list);
+    hipLaunchKernelGGL(vnp_pool_screen_hist_kernel, dim3(1024), dim3(256), 0, st, (const VnpScreenHead*)head, (const int2*)list, hist);
+    hipLaunchKernelGGL(vnp_pool_screen_scan_kernel, dim3(1), dim3(1024), 0, st, hist, (int)(G * gs / 4));
+    hipLaunchKernelGGL(vnp_pool_screen_scatter_kernel, dim3(1024), dim3(256), 0, st, (const VnpScreenHead*)head, (const int2*)list, hist, order);
     hipLaunchKernelGGL(vnp_pool_screen_exact_kernel, dim3((unsigned)vnp_cdiv(cap, 64)), dim3(256), 0, st, x, ldx, Wcat, ldw, K,
-                       (const VnpScreenHead*)head, (const int2*)list, res);
-    hipLaunchKernelGGL(vnp_pool_screen_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
+                       (const VnpScreenHead*)head, (const int2*)list, (const int*)order, res);
+    hipLaunchKernelGGL(vnp_pool_screen_final_kernel, dim3(vnp_cdiv(C, 32), (unsigned)G), dim3(256), 0, st,
                        (const VnpScreenHead*)head, (const int2*)seg, (const int2*)list, (const float4*)res, C, gs, idx, out, ldo);
     // predicated fallback: the full 6-product pool, runs only if the flag was raised
     VnpGemmArgs q{};

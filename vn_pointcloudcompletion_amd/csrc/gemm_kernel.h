@@ -20,7 +20,7 @@ struct VnpGemmArgs {
     // wave block and channel one float4 {max lower bound, largest upper bound, second-largest upper bound, its local index}
     // goes to pool_val (as float4*).  row_norm[M]: upper bounds of |A row|_2; col_norm[N]: of |B row|_2; screen_eps: the error
     // constant E with |exact - screened| <= E |A row| |B row| per output element.
-    const float* row_norm; const float* col_norm; float screen_eps;
+    const float* row_norm; const float* col_norm; float screen_eps; float screen_abs;
     // when non-null the kernel returns at once unless *pred != 0 (device-side predicated launch: the exact 6-product fallback of
     // the screened pool is enqueued unconditionally and runs only if the screening pass raised its flag)
     const int* pred;

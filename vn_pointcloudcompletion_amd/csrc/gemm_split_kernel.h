@@ -30,8 +30,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 vnp_bf8;
 typedef __attribute__((ext_vector_type(4))) unsigned vnp_u4;
 typedef __attribute__((ext_vector_type(2))) unsigned vnp_u2;
 
-typedef __attribute__((ext_vector_type(2))) __bf16 vnp_bf2;
 typedef __attribute__((ext_vector_type(2))) float vnp_f2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vnp_bf2;
+typedef __attribute__((ext_vector_type(8))) _Float16 vnp_h8;
+typedef __attribute__((ext_vector_type(2))) _Float16 vnp_h2;
+
+// (x0, x1) -> packed fp16 pair, round-to-nearest-even (x0 in the low half-word); |x| > 65504 becomes Inf, |x| < 2^-24 flushes
+// through the subnormals: |x - fp16(x)| <= max(2^-11 |x|, 2^-25)
+__device__ __forceinline__ unsigned vnp_pack_f16(float x0, float x1)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(vnp_f2{x0, x1}, vnp_h2));
+}
 
 // (x0, x1) -> packed bf16 pairs H, M, L with x = h + m + l exactly (x0 in the low half-word: the lower k); each level
 // rounds to nearest-even and the remainders x - h, (x - h) - m are exact fp32 subtractions.  11 VALU ops per pair.
@@ -109,12 +118,17 @@ __device__ __forceinline__ void vnp_split_load_generic(vnp_f4 (&reg)[NV], const 
 
 // fp32 registers -> packed bf16 plane registers: pl[u][plane] holds 4 consecutive k of one row (u = float4 index j for a
 // K-contiguous operand, row-in-block e for a row-contiguous one, whose 4(k) x 4(row) block is transposed here)
-template <bool KC, int NV, int NPL = 3>
+template <bool KC, int NV, int NPL = 3, bool F16 = false>
 __device__ __forceinline__ void vnp_split_convert(const vnp_f4 (&reg)[NV], vnp_u2 (&pl)[NV][3])
 {
     static_assert(KC || NV == 4, "row-contiguous operands: 4 k-rows x 4 rows per thread");
+    static_assert(!F16 || (KC && NPL == 1), "the fp16 screening pass stages one plane of K-contiguous operands");
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
+        if (F16) {                                  // one fp16 plane: the single-product screening pass
+            pl[u][0] = vnp_u2{vnp_pack_f16(reg[u][0], reg[u][1]), vnp_pack_f16(reg[u][2], reg[u][3])};
+            continue;
+        }
         unsigned h0, m0, l0, h1, m1, l1;
         if (KC) {
             vnp_split_pair(reg[u][0], reg[u][1], h0, m0, l0);
@@ -123,7 +137,8 @@ __device__ __forceinline__ void vnp_split_convert(const vnp_f4 (&reg)[NV], vnp_u
             vnp_split_pair(reg[0][u], reg[1][u], h0, m0, l0);
             vnp_split_pair(reg[2][u], reg[3][u], h1, m1, l1);
         }
-        pl[u][0] = vnp_u2{h0, h1}; pl[u][1] = vnp_u2{m0, m1};
+        pl[u][0] = vnp_u2{h0, h1};
+        if (NPL >= 2) pl[u][1] = vnp_u2{m0, m1};
         if (NPL == 3) pl[u][2] = vnp_u2{l0, l1};          // NPL = 2 (screening pass): the l plane is dead code and is never formed
     }
 }
@@ -182,8 +197,11 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     vnp_split_offsets<BM, AKC>(oa, sa, p.lda, tid);
     vnp_split_offsets<BN, BKC>(ob, sb, p.ldb, tid);
     static_assert(EPI == 0 || (BM == 192 && BN == 128 && AKC && BKC && FAST), "the VN epilogues need the aligned 192x128 NT kernel");
-    constexpr int NPL = EPI == 3 ? 2 : 3;          // planes staged through LDS: the screening pass never touches the l plane
-    constexpr int T0 = EPI == 3 ? 3 : 0;           // first of the six products issued: EPI = 3 keeps (m h), (h m), (h h)
+    // EPI = 3: bf16 screening pass, products (m h), (h m), (h h): the l plane is never formed, staged or read.
+    // EPI = 4: fp16 screening pass: ONE plane (fp16, 11 significant bits) and ONE product per operand pair.
+    constexpr bool F16 = EPI == 4;
+    constexpr int NPL = EPI == 3 ? 2 : EPI == 4 ? 1 : 3;          // planes staged through LDS
+    constexpr int T0 = EPI == 3 ? 3 : EPI == 4 ? 5 : 0;           // first of the six products issued
     if (p.pred && *p.pred == 0) return;            // predicated launch (wave-uniform)
     int perm_off[AV];                       // EPI >= 1: element offset of the global row that LDS row tid/8 + 32 j holds
     if (EPI >= 1) {
@@ -230,8 +248,8 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     };
     vnp_u2 pa[AV][3], pb[BV][3];
     auto convert = [&]() {
-        vnp_split_convert<AKC, AV, NPL>(ra, pa);
-        vnp_split_convert<BKC, BV, NPL>(rb, pb);
+        vnp_split_convert<AKC, AV, NPL, F16>(ra, pa);
+        vnp_split_convert<BKC, BV, NPL, F16>(rb, pb);
     };
     auto write = [&]() {
         vnp_split_write<BM, AKC, AV, NPL>(pa, As, tid);
@@ -295,8 +313,13 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
 #pragma unroll
                     for (int t = T0; t < 6; ++t)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) {
+                            if (F16)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vnp_h8, a[0]), __builtin_bit_cast(vnp_h8, b[j][0]),
+                                                                                   acc[i][j], 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+                        }
                 }
             }
             __syncthreads();
@@ -340,14 +363,14 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                     p.pool_x[3 * slot + 0] = bx0; p.pool_x[3 * slot + 1] = bx1; p.pool_x[3 * slot + 2] = bx2;
                 }
             }
-        } else if (EPI == 3) {
+        } else if (EPI == 3 || EPI == 4) {
             // Screening pass of the exact screened arg-max pool.  acc holds the 3-product values x~, d~ in the layout of EPI = 1.
             // For every (point, channel): s~ = <x~, d~> and a rigorous bound err >= |s6 - s~| on its distance to the value s6 the
             // 6-product kernels compute for the same pair:  |x6_t - x~_t| <= E |W_c| |f_(n,t)| =: ex_t (Cauchy-Schwarz on the
             // dropped products and on both accumulations' fp32 rounding; E = p.screen_eps, norms = upper bounds), same for d, so
             //   |s6 - s~| <= sum_t (|x~_t| ed_t + |d~_t| ex_t + ex_t ed_t) + 2^-21 sum_t |x~_t d~_t|   (last term: the two fmaf chains).
-            // Per 32-point block: the largest lower bound, the largest upper bound with its point, and the second-largest upper
-            // bound.  A non-finite bound poisons the slot with +Inf, which makes the selection pass raise the fallback flag.
+            // Per 32-point block: the largest lower bound, the two largest upper bounds with their points, and the third-largest
+            // upper bound (three or more candidates in one block make the whole block a candidate).  A non-finite bound poisons the slot with +Inf, which makes the selection pass raise the fallback flag.
             const int pt0 = m0 / 3 + wm * 32;
             const int grp = pt0 / 32;
             const int loc0 = pt0 % p.pool_gs;
@@ -363,10 +386,18 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int colx = n0 + wn * 64 + jj * 16 + l16;
-                const float Ex = p.screen_eps * p.col_norm[colx], Ed = p.screen_eps * p.col_norm[colx + 32];
-                float lmax = -INFINITY, u1 = -INFINITY, u2 = -INFINITY;
-                int i1 = 0;
+                const float cnx = p.col_norm[colx], cnd = p.col_norm[colx + 32];
+                const float Ex = p.screen_eps * cnx, Ed = p.screen_eps * cnd;
+                // fp16 pass only: operands below fp16's normal range lose absolute, not relative, accuracy: + A (|W_c| + |f|) per output
+                const float Ax = p.screen_abs * cnx, Ad = p.screen_abs * cnd, An = p.screen_abs;
+                float lmax = -INFINITY, u1 = -INFINITY, u2 = -INFINITY, u3 = -INFINITY;     // the three largest upper bounds of the block
+                int i1 = 0, i2 = 0;                                                        // and the points of the first two
                 bool bad = false;
+                auto insert = [&](float up, int ix) {
+                    if (up > u1) { u3 = u2; u2 = u1; i2 = i1; u1 = up; i1 = ix; }
+                    else if (up > u2) { u3 = u2; u2 = up; i2 = ix; }
+                    else u3 = fmaxf(u3, up);
+                };
 #pragma unroll
                 for (int i3 = 0; i3 < 2; ++i3)
 #pragma unroll
@@ -376,9 +407,9 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                         const float st = fmaf(x2, d2, fmaf(x1, d1, x0 * d0));
                         float err = 0.f, mag = 0.f;
                         {
-                            const float ex0 = Ex * nf[i3][e][0], ed0 = Ed * nf[i3][e][0];
-                            const float ex1 = Ex * nf[i3][e][1], ed1 = Ed * nf[i3][e][1];
-                            const float ex2 = Ex * nf[i3][e][2], ed2 = Ed * nf[i3][e][2];
+                            const float ex0 = fmaf(Ex, nf[i3][e][0], fmaf(An, nf[i3][e][0], Ax)), ed0 = fmaf(Ed, nf[i3][e][0], fmaf(An, nf[i3][e][0], Ad));
+                            const float ex1 = fmaf(Ex, nf[i3][e][1], fmaf(An, nf[i3][e][1], Ax)), ed1 = fmaf(Ed, nf[i3][e][1], fmaf(An, nf[i3][e][1], Ad));
+                            const float ex2 = fmaf(Ex, nf[i3][e][2], fmaf(An, nf[i3][e][2], Ax)), ed2 = fmaf(Ed, nf[i3][e][2], fmaf(An, nf[i3][e][2], Ad));
                             err = fmaf(fabsf(x0), ed0, fmaf(fabsf(d0), ex0, ex0 * ed0));
                             err += fmaf(fabsf(x1), ed1, fmaf(fabsf(d1), ex1, ex1 * ed1));
                             err += fmaf(fabsf(x2), ed2, fmaf(fabsf(d2), ex2, ex2 * ed2));
@@ -388,28 +419,26 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                         bad = bad || !(err < INFINITY) || !(fabsf(st) < INFINITY);
                         const float lo = st - err, up = st + err;
                         lmax = fmaxf(lmax, lo);
-                        if (up > u1) { u2 = u1; u1 = up; i1 = 16 * i3 + 4 * lq + e; }
-                        else u2 = fmaxf(u2, up);
+                        insert(up, 16 * i3 + 4 * lq + e);
                     }
 #pragma unroll
                 for (int o = 16; o <= 32; o <<= 1) {
-                    const float ol = __shfl_xor(lmax, o), ou1 = __shfl_xor(u1, o), ou2 = __shfl_xor(u2, o);
-                    const int oi = __shfl_xor(i1, o);
+                    const float ol = __shfl_xor(lmax, o), ou1 = __shfl_xor(u1, o), ou2 = __shfl_xor(u2, o), ou3 = __shfl_xor(u3, o);
+                    const int oi1 = __shfl_xor(i1, o), oi2 = __shfl_xor(i2, o);
                     const bool ob = __shfl_xor((int)bad, o) != 0;
                     lmax = fmaxf(lmax, ol);
-                    const bool take = ou1 > u1 || (ou1 == u1 && oi < i1);
-                    const float lose = take ? u1 : ou1;
-                    if (take) { u1 = ou1; i1 = oi; }
-                    u2 = fmaxf(fmaxf(u2, ou2), lose);
+                    insert(ou1, oi1);
+                    insert(ou2, oi2);
+                    u3 = fmaxf(u3, ou3);
                     bad = bad || ob;
                 }
                 if (lq == 0) {
                     const int ch = (n0 >> 1) + wn * 32 + jj * 16 + l16;
                     const size_t slot = (size_t)grp * Cch + ch;
                     float4 o4;
-                    o4.x = bad ? INFINITY : lmax; o4.y = bad ? INFINITY : u1; o4.z = bad ? INFINITY : u2;
-                    o4.w = __int_as_float(loc0 + i1);
+                    o4.x = bad ? INFINITY : lmax; o4.y = bad ? INFINITY : u1; o4.z = bad ? INFINITY : u2; o4.w = bad ? INFINITY : u3;
                     ((float4*)p.pool_val)[slot] = o4;
+                    p.pool_idx[slot] = (loc0 + i1) | ((loc0 + i2) << 16);          // pool_gs <= 2048: 16 bits each
                 }
             }
         } else if (EPI == 2) {

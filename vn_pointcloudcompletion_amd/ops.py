@@ -35,6 +35,8 @@ POOL_FUSED_EPILOGUE = _os.environ.get("VNP_POOL_UNFUSED", "0") != "1"
 # ... and pick the arg-max with the exact SCREENED search (vnp_linear_pool_screened_fwd: a 3-product bracketing pass + exact
 # evaluation of the surviving candidates; same bits, half the MFMA work); VNP_POOL_SCREEN=0 keeps the full 6-product epilogue
 POOL_SCREENED = _os.environ.get("VNP_POOL_SCREEN", "1") != "0"
+# bracketing pass of the screened pool: "fp16" (default) = one fp16 product per operand pair, "bf16x3" = three bf16 products
+POOL_SCREEN_PASS = _os.environ.get("VNP_POOL_SCREEN_PASS", "fp16")
 # BatchNorm + leaky backward in two read-heavy passes (sums, then final gradients) instead of bwd1 -> reduce -> bwd2, which writes
 # dL/dq and reads it back (VNP_BN_BWD_TWO_PASS=0 keeps that form); same arithmetic term for term
 BN_BWD_TWO_PASS = _os.environ.get("VNP_BN_BWD_TWO_PASS", "1") != "0"
@@ -577,7 +579,12 @@ class VNLinearMaxPoolFn(Function):
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
+            if screened:
+                if POOL_SCREEN_PASS not in ("fp16", "bf16x3"):
+                    raise _lib.VnpError(f"VNP_POOL_SCREEN_PASS must be 'fp16' or 'bf16x3', got {POOL_SCREEN_PASS!r}")
+                call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws), 1 if POOL_SCREEN_PASS == "fp16" else 0)
+            else:
+                call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
             if prof is not None:
                 e1.record()
                 # algorithmic work of the pool: both products over every point; the screened search EXECUTES about half of it
