@@ -192,6 +192,9 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
 // sums S ([C][2]; nullptr in eval mode) it applies phase 2 on the fly and writes gq = dL/dp and gd.  Against bwd1 + bwd2 this
 // trades a written-then-re-read map for a second read of the inputs: 6 maps instead of 7 in the rank-1 form (2R + 2R2W against
 // 2R2W + 2R1W), 8 = 8 in the matrix form but with 6 reads / 2 writes instead of 5 / 3 (reads stream faster: hbm_yardstick).
+// gradients only: v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the ~12-instruction IEEE sequences (the rank-1 form was issue-bound)
+#define BDIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define BSQRT(a) __builtin_amdgcn_sqrtf(a)
 template <int MODE>
 __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __restrict__ go, int ldgo,
                                                                const float* __restrict__ go_row, const float* __restrict__ go_col,
@@ -228,9 +231,9 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
             }
             float n = 1.f, s = 1.f, xh = 0.f;
             if (mean) {
-                n = sqrtf(vnp_sq3(x0, x1, x2)) + VNP_EPS;
+                n = BSQRT(vnp_sq3(x0, x1, x2)) + VNP_EPS;
                 xh = (n - mu) * rs;
-                s = (xh * ga + be) / n;
+                s = BDIV(xh * ga + be, n);
             }
             const float q0 = x0 * s, q1 = x1 * s, q2 = x2 * s;
             if (d) {
@@ -243,14 +246,14 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                     // final VNLinear(C -> 1)
                     float o0 = q0, o1 = q1, o2 = q2;
                     if (dot < 0.f) {
-                        const float al = (1.f - ns) * dot / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                        const float al = BDIV((1.f - ns) * dot, vnp_sq3(d0, d1, d2) + VNP_EPS);
                         o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
                     }
                     s3 += go_row[pt * 3] * o0 + go_row[pt * 3 + 1] * o1 + go_row[pt * 3 + 2] * o2;
                 }
                 if (dot < 0.f) {
                     const float cc = 1.f - ns;
-                    const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                    const float inv = BDIV(1.f, vnp_sq3(d0, d1, d2) + VNP_EPS);
                     const float a = dot * inv;
                     const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
                     const float k1 = cc * gdd * inv;
@@ -270,9 +273,9 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                 const float pn = n - VNP_EPS;
                 const float nh = xh * ga + be;
                 const float gs = g0 * x0 + g1 * x1 + g2 * x2;
-                const float gnh = gs / n;
-                const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
-                const float k = pn > 0.f ? gn / pn : 0.f;
+                const float gnh = BDIV(gs, n);
+                const float gn = ga * rs * (gnh - m1 - xh * m2) - BDIV(gs * nh, n * n);
+                const float k = pn > 0.f ? BDIV(gn, pn) : 0.f;
                 g0 = s * g0 + k * x0; g1 = s * g1 + k * x1; g2 = s * g2 + k * x2;
             }
             if (MODE != 1) {
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                 __builtin_nontemporal_store(g0, wq); __builtin_nontemporal_store(g1, wq + ldgq); __builtin_nontemporal_store(g2, wq + 2 * ldgq);
             }
             if (MODE != 2 && mean) {
-                const float gnh = (g0 * x0 + g1 * x1 + g2 * x2) / n;     // dL/dnhat = (gq . p) / n
+                const float gnh = BDIV(g0 * x0 + g1 * x1 + g2 * x2, n);     // dL/dnhat = (gq . p) / n
                 s1 += gnh; s2 += gnh * xh;
             }
         }
@@ -296,6 +299,8 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
         }
     }
 }
+#undef BDIV
+#undef BSQRT
 
 // fine[pt*3+t] = sum_c leaky(bn(p), d)[pt,t,c] * w[c] + add[((pt / add_group))*3 + t]: the last VNLinearLeakyReLU of the
 // decoder fused with the final VNLinear(C -> 1) and the residual point_feat (models/pcn.py:341-346,387): the [P*3, C]
@@ -758,6 +763,10 @@ struct VnpFoldArgs {
 template <int MODE>
 __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a)
 {
+    // the backward modes (gradients) use v_rcp_f32 / v_sqrt_f32 (1 ulp each) where the forward modes keep IEEE division and sqrtf so that statistics and
+    // outputs stay bit-identical to the unfused path
+#define FDIV(a, b) (MODE >= 2 ? (a) * __builtin_amdgcn_rcpf(b) : (a) / (b))
+#define FSQRT(a) (MODE >= 2 ? __builtin_amdgcn_sqrtf(a) : sqrtf(a))
     __shared__ float red[4][5][2][64];
     __shared__ int cnt[4];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
@@ -793,12 +802,12 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
         for (int s = 0; s < S; ++s) {
             const float e0 = sd[s * 3], e1 = sd[s * 3 + 1], e2 = sd[s * 3 + 2];
             const float x0 = pf[0] + wsf * e0, x1 = pf[1] + wsf * e1, x2 = pf[2] + wsf * e2;
-            const float pn = sqrtf(vnp_sq3(x0, x1, x2)), n = pn + VNP_EPS;
+            const float pn = FSQRT(vnp_sq3(x0, x1, x2)), n = pn + VNP_EPS;
             if (MODE == 0) {
                 if (live) { ++wk; const float dl = n - wmean; wmean += dl / (float)wk; wm2 += dl * (n - wmean); }
                 continue;
             }
-            const float xh = (n - mu) * rs, nh = xh * ga + be, sc = nh / n;
+            const float xh = (n - mu) * rs, nh = xh * ga + be, sc = FDIV(nh, n);
             const float q0 = x0 * sc, q1 = x1 * sc, q2 = x2 * sc;
             const float d0 = pdv[0] + wsd * e0, d1 = pdv[1] + wsd * e1, d2 = pdv[2] + wsd * e2;
             const float dot = q0 * d0 + q1 * d1 + q2 * d2;
@@ -817,7 +826,7 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
             float h0 = 0.f, h1 = 0.f, h2 = 0.f;                    // dL/dd
             if (dot < 0.f) {
                 const float cc = 1.f - a.ns;
-                const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                const float inv = FDIV(1.f, vnp_sq3(d0, d1, d2) + VNP_EPS);
                 const float al = dot * inv;
                 const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
                 const float k1 = cc * gdd * inv;
@@ -827,11 +836,11 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
                 g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;       // now dL/dq
             }
             const float gs = g0 * x0 + g1 * x1 + g2 * x2;
-            const float gnh = gs / n;
+            const float gnh = FDIV(gs, n);
             if (MODE == 2) { s1 += gnh; s2 += gnh * xh; continue; }
             // MODE 3: dL/dp = sc*gq + gn * p/|p|
-            const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
-            const float kk = pn > 0.f ? gn / pn : 0.f;
+            const float gn = ga * rs * (gnh - m1 - xh * m2) - FDIV(gs * nh, n * n);
+            const float kk = pn > 0.f ? FDIV(gn, pn) : 0.f;
             const float r0 = sc * g0 + kk * x0, r1 = sc * g1 + kk * x1, r2 = sc * g2 + kk * x2;
             acc[0][0] += r0; acc[0][1] += r1; acc[0][2] += r2;
             acc[0][3] += r0 * e0 + r1 * e1 + r2 * e2;
@@ -882,6 +891,8 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
         }
     }
 }
+#undef FSQRT
+#undef FDIV
 
 // mode 0: statistics partials; 1: forward; 2: backward sums; 3: backward gradients (see ops.FoldBnLeakyFn).
 // partial: [nchunk][C][2]; part5: [nchunk][5][2C]; gcoarse [B*Mc][3] is zero-filled here in mode 3.  S must divide
