@@ -242,6 +242,23 @@ def test_screened_pool_adversarial_near_ties(lib_built):
             assert (res["screened"][1] == 0).all()               # and the lowest index won everywhere
 
 
+@pytest.mark.parametrize("scale", [3e-6, 1e-3, 3e4])
+def test_screened_pool_fp16_range_edges(lib_built, scale):
+    """The fp16 bracketing pass outside fp16's comfortable range: features of magnitude 3e-6 (fp16 subnormals: the bound's absolute
+    term; the hardware multiplies them exactly, profiles/r02_mfma_f16_subnormals.txt), 1e-3, and 3e4 (products of the direction map
+    overflow fp16's 65504 for some operands: non-finite bound -> fallback).  Whatever the pass does, the result is the exact one."""
+    g = torch.Generator().manual_seed(17)
+    G, gs, C, K = 2, 256, 128, 128
+    f = torch.randn(G * gs * 3, K, generator=g) * scale
+    W = torch.randn(C, K, generator=g) / K ** 0.5
+    Wd = torch.randn(C, C, generator=g) / C ** 0.5
+    stats = []
+    res = _pool_three_ways(f, W, Wd, G, gs, stats)
+    _assert_pool_bits_equal(res)
+    cand, flag, cap = stats[0].tolist()
+    print(f"scale {scale:g}: {cand} candidates (capacity {cap}), fallback flag {flag}")
+
+
 def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
     g = torch.Generator().manual_seed(6)
     G, gs, C, K = 2, 64, 64, 64
