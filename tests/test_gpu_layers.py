@@ -304,7 +304,7 @@ def test_bn_backward_two_pass_equals_bwd1_bwd2(lib_built, training, rank1):
                 res[two] = ops._bn_leaky_backward(None, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2,
                                                   go_row=grow, go_col=gcol, want_gw=True)
             else:
-                res[two] = ops._bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2)
+                res[two] = ops._bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2)     # (matrix form: both take bwd1 -> bwd2 today)
         finally:
             ops.BN_BWD_TWO_PASS = True
     for a, b in zip(res[True], res[False]):

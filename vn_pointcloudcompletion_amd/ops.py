@@ -241,7 +241,7 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
     if go is not None:
         go = _rows(go)
     ggamma = gbeta = None
-    if use_bn and BN_BWD_TWO_PASS:
+    if use_bn and BN_BWD_TWO_PASS and go is None:        # rank-1 (decoder tail) form: 6 maps instead of 7; matrix form: measured no gain
         # pass 1: the per-channel sums (read-only);  pass 2: final dL/dp | dL/dd with phase 2 applied on the fly — dL/dq is never
         # written and re-read (vnp_vn_bn_leaky_bwd_pass)
         args = (ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col), ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0,
