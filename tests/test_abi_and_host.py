@@ -24,6 +24,11 @@ def test_library_exports_every_declared_symbol(lib_built):
         assert hasattr(L, name), f"{name} declared in include/vnpcc.h but not exported by libvnpcc.so"
     assert declared == _lib.exported_symbols(), "ctypes signature table and header disagree"
     assert _lib.chunk_points() > 0
+    # ... and every binding passes as many arguments as the header declares (a stale ctypes signature corrupts the call silently)
+    bound = _lib.lib()
+    for name, params in re.findall(r"^\s*(?:int|long long)\s+(vnp_\w+)\s*\(([^;]*?)\)\s*;", header, flags=re.M | re.S):
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        assert len(getattr(bound, name).argtypes) == n, f"{name}: header declares {n} parameters, ctypes binding has {len(getattr(bound, name).argtypes)}"
 
 
 def test_no_cpu_fallback():
