@@ -49,6 +49,10 @@ __device__ __forceinline__ unsigned vnp_pack_f16(float x0, float x1)
 // (0, -1)); splitting the prefetched tile between the two halves of the MFMA block instead of after it (spills).)
 __device__ __forceinline__ void vnp_split_pair(float x0, float x1, unsigned& H, unsigned& M, unsigned& L)
 {
+#ifdef VNP_EXPERIMENT_CHEAP_SPLIT          // scripts/gemm_variants_probe.hip only: WRONG planes at ~3 ops per pair, to price the conversion
+    H = (__float_as_uint(x0) >> 16) | (__float_as_uint(x1) & 0xffff0000u); M = H ^ 0x00010001u; L = H ^ 0x00020002u;
+    return;
+#endif
     H = __builtin_bit_cast(unsigned, __builtin_convertvector(vnp_f2{x0, x1}, vnp_bf2));        // v_cvt_pk_bf16_f32 (RNE)
     const float r0 = x0 - __uint_as_float(H << 16);
     const float r1 = x1 - __uint_as_float(H & 0xffff0000u);
