@@ -259,6 +259,49 @@ def test_screened_pool_fp16_range_edges(lib_built, scale):
     print(f"scale {scale:g}: {cand} candidates (capacity {cap}), fallback flag {flag}")
 
 
+def test_screened_pool_random_shapes_and_magnitudes(lib_built):
+    """Fuzz: 24 random problems — group counts, group sizes (one to 64 blocks of 32 points), channel counts, contraction lengths,
+    feature / weight magnitudes over 6 decades, random duplicated points, heavy-tailed features — both bracketing passes against the full
+    six-product epilogue (itself tested against the two-GEMM path above): indices and pooled vectors bit for bit."""
+    from vn_pointcloudcompletion_amd import ops
+    rng = torch.Generator().manual_seed(2024)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=rng).item())
+    flags = 0
+    for trial in range(24):
+        G = ri(1, 6)
+        gs = 32 * ri(1, 64) if trial % 3 else 32 * [1, 2, 64][ri(0, 2)]
+        while (G * gs * 3) % 192:                                   # shapes the fused kernels cover
+            G += 1
+        C, K = 64 * ri(1, 5), 32 * ri(1, 40)
+        fs, ws = 10.0 ** (ri(-30, 30) / 10.0), 10.0 ** (ri(-20, 10) / 10.0)
+        f = torch.randn(G * gs * 3, K, generator=rng) * fs
+        if trial % 4 == 1:
+            f = f * torch.randn(G * gs * 3, 1, generator=rng).pow(4)          # heavy tails: a few dominant points
+        if trial % 4 == 2 and gs > 32:
+            src = torch.randint(0, G * gs, (G * gs // 8,), generator=rng)      # duplicated points: exact ties
+            dst = torch.randint(0, G * gs, (G * gs // 8,), generator=rng)
+            f.view(G * gs, 3, K)[dst] = f.view(G * gs, 3, K)[src]
+        W = torch.randn(C, K, generator=rng) * ws / K ** 0.5
+        Wd = torch.randn(C, C, generator=rng) / C ** 0.5
+        out = {}
+        for name, screened, pas in (("fp16", True, "fp16"), ("bf16x3", True, "bf16x3"), ("full", False, "fp16")):
+            ops.POOL_SCREENED, ops.POOL_SCREEN_PASS = screened, pas
+            st = []
+            ops.POOL_SCREEN_STATS = st if screened else None
+            try:
+                out[name] = ops.VNLinearMaxPoolFn.apply(f.cuda(), W.cuda(), Wd.cuda(), G, gs)
+            finally:
+                ops.POOL_SCREENED, ops.POOL_SCREEN_PASS, ops.POOL_SCREEN_STATS = True, "fp16", None
+            if st:
+                flags += int(st[0][1].item())
+        for name in ("fp16", "bf16x3"):
+            assert torch.equal(out[name][1], out["full"][1]), (trial, name, G, gs, C, K, fs, ws)
+            assert torch.equal(out[name][0].view(torch.int32), out["full"][0].view(torch.int32)), (trial, name, G, gs, C, K, fs, ws)
+    print(f"fallback flag raised in {flags} of 48 screened calls")
+
+
 def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
     g = torch.Generator().manual_seed(6)
     G, gs, C, K = 2, 64, 64, 64
