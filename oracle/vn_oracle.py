@@ -250,8 +250,9 @@ def vn_graph_feature(x, idx):
     return torch.cat([feat - xc, xc], dim=3).permute(0, 3, 4, 1, 2)
 
 
-def vn_dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats=None):
-    """models/dgcnn.py:282-324 (VN_DGCNN_fps.forward, num_coarse != 224).  x [B,N,3] -> (coarse [B,Mc,3], global [B,512,3,1])."""
+def vn_dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats=None, pool_idx=None, trace=None):
+    """models/dgcnn.py:282-324 (VN_DGCNN_fps.forward, num_coarse != 224).  x [B,N,3] -> (coarse [B,Mc,3], global [B,512,3,1]).
+    ``pool_idx`` [B,512] teacher-forces pool5's arg-max (full-resolution parity tests); ``trace`` receives its scores / own arg-max."""
     p = prefix
     B, N, _ = x.shape
     coor = x                                                       # [B,N,3]
@@ -273,7 +274,10 @@ def vn_dgcnn_fps_forward(sd, x, training=True, k=16, prefix="encoder", new_stats
     f = conv("conv5", f, cq)
     cq, fq = down(cq, f, 128)
     f = conv("conv6", fq, cq)
-    g = vn_max_pool(f, sd[f"{p}.pool5.map_to_dir.weight"]).unsqueeze(-1)
+    g, _, dot5 = vn_max_pool(f, sd[f"{p}.pool5.map_to_dir.weight"], True, pool_idx)
+    g = g.unsqueeze(-1)
+    if trace is not None:
+        trace.update(dot5=dot5.detach(), idx5=dot5.detach().argmax(-1))
     h = _lin_leaky(sd, f"{p}.conv7.0", g, training, new_stats)
     h = vn_linear(h, sd[f"{p}.conv7.1.map_to_feat.weight"])
     return h.squeeze(-1).contiguous(), g
