@@ -123,13 +123,14 @@ int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, const float*
                          float negative_slope, float* partial, float* gw_partial, int chunk_points);
 /* The same backward in two read-only-heavy passes that never write dL/dq (6 maps instead of 7 in rank-1 form):
  * pass 1: partial (+ gw_partial) only;  pass 2: gq = dL/dp — phase 2 applied on the fly with the reduced sums S [C][2]
- * (NULL: eval mode) — and gd.  BatchNorm is mandatory here (mean non-NULL). */
+ * (NULL: eval mode) — and gd; optionally colsum [nchunk][3][2C] = per-chunk sums over points of (dL/dp | dL/dd) per component (the
+ * per-sample bias gradient of a layer with de-duplicated broadcast channels).  BatchNorm is mandatory here (mean non-NULL). */
 int vnp_vn_bn_leaky_bwd_pass(hipStream_t st, int pass, const float* go, int ldgo, const float* go_row, const float* go_col,
                              const float* p, int ldp, const float* d, int ldd,
                              float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
                              const float* mean, const float* rstd, const float* gamma, const float* beta,
                              float negative_slope, float* partial, float* gw_partial, int chunk_points,
-                             const float* S, long long count);
+                             const float* S, long long count, float* colsum);
 /* gw_partial (rank-1 mode only, nullable) [nchunk][C]: per-chunk sums of go_row . out, i.e. dL/dw of a final VNLinear(C->1)
  * whose input (this layer's output) was never stored.
  * Forward of that fusion: fine[pt*3+t] = sum_c leaky(bn(p),d)[pt,t,c]*w[c] + add[(pt/add_group)*3+t] (models/pcn.py:341-346,387) */

@@ -354,6 +354,33 @@ def test_bn_backward_two_pass_equals_bwd1_bwd2(lib_built, training, rank1):
         assert relerr(a, b) < 2e-6
 
 
+@pytest.mark.parametrize("P,rpg", [(4096, 2048 * 3), (3000, 1500 * 3), (6144, 3072 * 3)])
+def test_bn_backward_fused_per_sample_colsum(lib_built, P, rpg):
+    """The per-sample bias gradient (column sums of dL/dp | dL/dd per sample and component) taken inside the final-gradient pass
+    (vnp_vn_bn_leaky_bwd_pass, colsum) against the separate pass over the gradient; P = 3000: a sample is not a whole number of chunks,
+    so the separate pass is used on both sides."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(P)
+    C = 96
+    pd = torch.randn(P * 3, 2 * C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    _, mean, rstd = ops._bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, rm, rv, True, 0.2)
+    go = torch.randn(P * 3, C, generator=g).cuda()
+    res = {}
+    for two in (True, False):
+        ops.BN_BWD_TWO_PASS = two
+        try:
+            res[two] = ops._bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, True, 0.2, colsum_rows_per_group=rpg)
+        finally:
+            ops.BN_BWD_TWO_PASS = True
+    assert len(res[True]) == 4 and res[True][3].shape == (P * 3 // rpg * 3, 2 * C)
+    for a, b in zip(res[True], res[False]):
+        assert relerr(a, b) < 5e-6
+    ref = res[False][0].double().reshape(P * 3 // rpg, rpg // 3, 3, 2 * C).sum(1).reshape(-1, 2 * C)
+    assert relerr(res[True][3], ref) < 1e-5
+
+
 def test_pool_tap_adds_into_the_other_consumers_gradient(lib_built):
     """VNMaxPoolTapFn (encoder maxpool1: the pooled tensor also feeds second_conv[0]) against the plain pool + autograd's own sum of
     the two gradients: same pooled output and indices, same gradient for the shared input (one writer per element: bit-equal)."""

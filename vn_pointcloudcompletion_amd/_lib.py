@@ -80,7 +80,7 @@ _SIGNATURES = {
     "vnp_vn_bn_leaky_fwd": [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f],
     "vnp_vn_bn_leaky_bwd1": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i],
     "vnp_vn_bn_leaky_bwd_pass": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i,
-                                 _vp, _ll],
+                                 _vp, _ll, _vp],
     "vnp_vn_bn_leaky_rowdot_fwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp],
     "vnp_vn_bn_bwd2": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll],
     "vnp_reduce_rows": [_vp, _i, _ll, _i, _ll, _i, _vp, _ll],

@@ -204,10 +204,12 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float ns,
                                                                float2* __restrict__ partial, float* __restrict__ gw_partial, int chunk,
-                                                               const float* __restrict__ S, float inv_count)
+                                                               const float* __restrict__ S, float inv_count, float* __restrict__ colsum)
 {
     __shared__ float2 red[4][64];
     __shared__ float red3[4][64];
+    __shared__ float red6[4][6][64];
+    float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // MODE 2 + colsum: sums over the chunk's points of (dL/dp, dL/dd) per component
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const long long p0 = (long long)blockIdx.y * chunk;
@@ -267,6 +269,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                     float* wd = gd + (size_t)pt * 3 * ldgd + c;
                     __builtin_nontemporal_store(e0, wd); __builtin_nontemporal_store(e1, wd + ldgd); __builtin_nontemporal_store(e2, wd + 2 * ldgd);
                 }
+                if (MODE == 2 && colsum) { cs[3] += e0; cs[4] += e1; cs[5] += e2; }
             }
             if (MODE == 2 && mean) {
                 // phase 2 on the fly (the arithmetic of vnp_bn_bwd2_kernel, term for term): g = dL/dq -> dL/dp
@@ -282,9 +285,25 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                 float* wq = gq + (size_t)pt * 3 * ldgq + c;
                 __builtin_nontemporal_store(g0, wq); __builtin_nontemporal_store(g1, wq + ldgq); __builtin_nontemporal_store(g2, wq + 2 * ldgq);
             }
+            if (MODE == 2 && colsum) { cs[0] += g0; cs[1] += g1; cs[2] += g2; }
             if (MODE != 2 && mean) {
                 const float gnh = BDIV(g0 * x0 + g1 * x1 + g2 * x2, n);     // dL/dnhat = (gq . p) / n
                 s1 += gnh; s2 += gnh * xh;
+            }
+        }
+    }
+    if (MODE == 2 && colsum) {
+        // colsum[chunk][t][2C]: the per-sample bias gradient of a layer with de-duplicated broadcast channels is the sum of these
+        // rows over the sample's chunks (no second pass over the 2C-wide gradient)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) red6[py][q][cx] = cs[q];
+        __syncthreads();
+        if (py == 0 && c < C) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float* dst = colsum + ((size_t)blockIdx.y * 3 + t) * 2 * C;
+                dst[c] = (red6[0][t][cx] + red6[1][t][cx]) + (red6[2][t][cx] + red6[3][t][cx]);
+                dst[C + c] = (red6[0][3 + t][cx] + red6[1][3 + t][cx]) + (red6[2][3 + t][cx] + red6[3][3 + t][cx]);
             }
         }
     }
@@ -1126,20 +1145,21 @@ extern "C" int vnp_vn_bn_leaky_bwd1(hipStream_t st, const float* go, int ldgo, c
     if (mean && (!rstd || !gamma || !beta || !partial)) return VNP_EINVAL;
     hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel<0>, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
                        gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial, chunk,
-                       (const float*)nullptr, 0.f);
+                       (const float*)nullptr, 0.f, (float*)nullptr);
     return vnp_last_error();
 }
 
 // Two-pass backward of BatchNorm-over-norms + leaky projection (see vnp_bn_leaky_bwd1_kernel).
 //   pass 1: partial [nchunk][C][2] (and gw_partial) only — gq / gd are not touched and may be NULL;
-//   pass 2: gq = dL/dp (phase 2 applied with the reduced sums S [C][2], NULL = eval mode: no batch terms) and gd; no partials.
+//   pass 2: gq = dL/dp (phase 2 applied with the reduced sums S [C][2], NULL = eval mode: no batch terms) and gd; no partials;
+//           colsum (nullable, needs d) [nchunk][3][2C]: per-chunk sums over points of (dL/dp | dL/dd) per component.
 // mean must be non-NULL (without BatchNorm there is no phase 2: use vnp_vn_bn_leaky_bwd1).
 extern "C" int vnp_vn_bn_leaky_bwd_pass(hipStream_t st, int pass, const float* go, int ldgo, const float* go_row, const float* go_col,
                                         const float* p, int ldp, const float* d, int ldd,
                                         float* gq, int ldgq, float* gd, int ldgd, long long P, int C,
                                         const float* mean, const float* rstd, const float* gamma, const float* beta,
                                         float negative_slope, float* partial, float* gw_partial, int chunk_points,
-                                        const float* S, long long count)
+                                        const float* S, long long count, float* colsum)
 {
     if (!p || P <= 0 || C <= 0 || (pass != 1 && pass != 2)) return VNP_EINVAL;
     if (!mean || !rstd || !gamma || !beta) return VNP_EINVAL;
@@ -1152,11 +1172,11 @@ extern "C" int vnp_vn_bn_leaky_bwd_pass(hipStream_t st, int pass, const float* g
     if (pass == 1)
         hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel<1>, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
                            gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)partial, gw_partial, chunk,
-                           (const float*)nullptr, 0.f);
+                           (const float*)nullptr, 0.f, (float*)nullptr);
     else
         hipLaunchKernelGGL(vnp_bn_leaky_bwd1_kernel<2>, vnp_grid_pc(P, C, chunk), dim3(256), 0, st, go, ldgo, go_row, go_col, p, ldp, d, ldd,
                            gq, ldgq, gd, ldgd, P, C, mean, rstd, gamma, beta, negative_slope, (float2*)nullptr, (float*)nullptr, chunk,
-                           S, inv);
+                           S, inv, (d && pass == 2) ? colsum : (float*)nullptr);
     return vnp_last_error();
 }
 

@@ -221,9 +221,11 @@ def _bn_leaky_forward(p, d, C, gamma, beta, running_mean, running_var, training,
 
 
 def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_bn=True, go_row=None, go_col=None,
-                       want_gw=False):
-    """Returns (gpd [R, 2C or C] with dL/dp in [:, :C] and dL/dd in [:, C:], ggamma, gbeta[, gw]).
-    Rank-1 upstream gradient: go=None, go[r, c] = go_row[r] * go_col[c]; want_gw adds dL/d(go_col) = sum_r go_row[r]*out[r, :]."""
+                       want_gw=False, colsum_rows_per_group=0):
+    """Returns (gpd [R, 2C or C] with dL/dp in [:, :C] and dL/dd in [:, C:], ggamma, gbeta[, gw][, gb]).
+    Rank-1 upstream gradient: go=None, go[r, c] = go_row[r] * go_col[c]; want_gw adds dL/d(go_col) = sum_r go_row[r]*out[r, :].
+    ``colsum_rows_per_group`` > 0 appends gb [R/rows_per_group*3, 2C] = per-sample column sums of gpd per component (the gradient of a
+    per-sample bias), taken inside the final-gradient pass when the sample is a whole number of chunks (else from a pass over gpd)."""
     R = p.shape[0]
     P = R // 3
     dev = p.device
@@ -241,15 +243,20 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
     if go is not None:
         go = _rows(go)
     ggamma = gbeta = None
-    if use_bn and BN_BWD_TWO_PASS and go is None:        # rank-1 (decoder tail) form: 6 maps instead of 7; matrix form: measured no gain
+    rpg = colsum_rows_per_group
+    fuse_colsum = bool(rpg) and use_bn and has_d and BN_BWD_TWO_PASS and rpg % 3 == 0 and (rpg // 3) % chunk == 0 and R % rpg == 0
+    cs_part = torch.empty((nch, 3, 2 * C), device=dev, dtype=torch.float32) if fuse_colsum else None
+    # two passes: the rank-1 (decoder tail) form saves a map (6 instead of 7); the matrix form is a wash on its own (measured) but lets
+    # the final-gradient pass also produce the per-sample bias gradient instead of a separate 1.6 GB read (encoder second_conv[0])
+    if use_bn and BN_BWD_TWO_PASS and (go is None or fuse_colsum):
         # pass 1: the per-channel sums (read-only);  pass 2: final dL/dp | dL/dd with phase 2 applied on the fly — dL/dq is never
         # written and re-read (vnp_vn_bn_leaky_bwd_pass)
         args = (ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col), ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0,
                 ptr(gq), ldg, ptr(gd), ldg, P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
-        call("vnp_vn_bn_leaky_bwd_pass", 1, *args, ptr(part), ptr(gw_part), chunk, None, P)
+        call("vnp_vn_bn_leaky_bwd_pass", 1, *args, ptr(part), ptr(gw_part), chunk, None, P, None)
         S = torch.empty((C, 2), device=dev, dtype=torch.float32)
         call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
-        call("vnp_vn_bn_leaky_bwd_pass", 2, *args, None, None, chunk, ptr(S) if training else None, P)
+        call("vnp_vn_bn_leaky_bwd_pass", 2, *args, None, None, chunk, ptr(S) if training else None, P, ptr(cs_part))
         gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
     else:
         call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
@@ -262,9 +269,16 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
             call("vnp_vn_bn_bwd2", ptr(gq), ldg, ptr(p), _ld(p), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                  ptr(S) if training else None, P)
             gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
+    res = [gpd, ggamma, gbeta]
     if want_gw:
-        return gpd, ggamma, gbeta, reduce_rows(gw_part, 1, nch_pad, C)
-    return gpd, ggamma, gbeta
+        res.append(reduce_rows(gw_part, 1, nch_pad, C))
+    if rpg:
+        if fuse_colsum:
+            nb, cps = R // rpg, (rpg // 3) // chunk
+            res.append(reduce_rows(cs_part.view(nb, cps, 6 * C), nb, cps, 6 * C).view(nb * 3, 2 * C))
+        else:
+            res.append(_per_sample_colsum(gpd, rpg))
+    return tuple(res)
 
 
 def _wgrad(gy, x):
@@ -370,13 +384,16 @@ class VNLinearLeakyFn(Function):
     def backward(ctx, go):
         x, Wcat, gamma, beta, pd, mean, rstd = ctx.saved_tensors
         C, rpg, training, ns, has_bias = ctx.cfg
-        gpd, ggamma, gbeta = _bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, ns)
+        want_gb = has_bias and ctx.needs_input_grad[7]
+        out = _bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, ns,
+                                 colsum_rows_per_group=rpg if want_gb else 0)
+        gpd, ggamma, gbeta = out[:3]
+        gb = out[3] if want_gb else None
         gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None          # dX = [dP | dD] [Wf; Wd]
         gWf = gWd = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gW = _wgrad(gpd, x)                                                     # [2C, Cin] in one split-K launch
             gWf, gWd = gW[:C], gW[C:]
-        gb = _per_sample_colsum(gpd, rpg) if (has_bias and ctx.needs_input_grad[7]) else None
         return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None
 
 
