@@ -155,6 +155,10 @@ int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long long batch_str
 long long vnp_linear_pool_ws_bytes(long long G, int gs, int C);
 int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
                         int K, int* idx, float* out, int ldo, void* ws);
+/* As vnp_linear_pool_fwd when the linear output y = x W^T has another consumer as well (encoder first_conv[1] -> maxpool1 and
+ * second_conv[0], models/pcn.py:169-172): y [G*gs*3, ldy >= C] is stored too; the direction still never exists in memory. */
+int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
+                              int K, float* y, int ldy, int* idx, float* out, int ldo, void* ws);
 /* The same operator — same arguments, same restrictions, same results BIT FOR BIT — with an exact screened arg-max: a 3-product
  * pass (half the MFMA work) brackets every score between rigorous bounds, the ~1-2 surviving candidates per (group, channel) are
  * evaluated exactly as diagonals of MFMA tiles with the full kernels' product sequence, and a predicated launch of the full

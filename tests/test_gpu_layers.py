@@ -416,6 +416,36 @@ def test_pool_tap_adds_into_the_other_consumers_gradient(lib_built):
     assert torch.allclose(ar.grad, br.grad, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("G,gs,C,K", [(2, 2048, 512, 128), (3, 64, 128, 64), (1, 192, 64, 32)])
+def test_linear_pool_tap_fused_equals_linear_then_tap(lib_built, G, gs, C, K):
+    """VNLinearPoolTapFn (one GEMM that stores y = x W^T and pools in its epilogue: vnp_linear_pool_store_fwd) against VNLinearFn ->
+    VNMaxPoolTapFn: y, pooled vectors and indices bit for bit (the same MFMA sequence per element), gradients to fp32 summation order."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(G + gs + C + K)
+    a = torch.randn(G * gs * 3, K, generator=g).cuda()
+    a[3 * (gs // 2):3 * (gs // 2) + 3] = a[0:3]                    # an exact tie in group 0
+    W = (torch.randn(C, K, generator=g) / K ** 0.5).cuda()
+    Wd = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    W2 = (torch.randn(40, C, generator=g) / C ** 0.5).cuda()
+    cot1, cot2 = torch.randn(G * 3, C, generator=g).cuda(), torch.randn(G * gs * 3, 40, generator=g).cuda()
+    assert ops.VNLinearPoolTapFn.supported(a, W, G, gs)
+    res = {}
+    for fused in (True, False):
+        ar, Wr = a.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        if fused:
+            y, pooled, idx = ops.VNLinearPoolTapFn.apply(ar, Wr, Wd, G, gs)
+        else:
+            y0 = ops.VNLinearFn.apply(ar, Wr, None, 0)
+            y, pooled, idx = ops.VNMaxPoolTapFn.apply(y0, Wd, G, gs, ar.detach(), Wr.detach())
+        z = ops.VNLinearFn.apply(y, W2, None, 0)
+        ((pooled * cot1).sum() + (z * cot2).sum()).backward()
+        res[fused] = (y.detach().clone(), pooled.detach(), idx, ar.grad, Wr.grad)
+    assert torch.equal(res[True][2], res[False][2])
+    assert torch.equal(res[True][0].view(torch.int32), res[False][0].view(torch.int32))
+    assert torch.equal(res[True][1].view(torch.int32), res[False][1].view(torch.int32))
+    assert relerr(res[True][3], res[False][3]) < 1e-6 and relerr(res[True][4], res[False][4]) < 1e-6
+
+
 @pytest.mark.parametrize("nb,n,W", [(3, 1248, 40), (2, 2048, 64), (2, 1031, 16), (1, 7, 5), (4, 4992, 24)])
 def test_reduce_rows_any_count(lib_built, nb, n, W):
     """Partial-sum reduction for counts that are not multiples of 256 (config 5 folds 1248 coarse points) and for primes."""

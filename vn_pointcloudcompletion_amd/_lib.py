@@ -85,6 +85,7 @@ _SIGNATURES = {
     "vnp_vn_bn_bwd2": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll],
     "vnp_reduce_rows": [_vp, _i, _ll, _i, _ll, _i, _vp, _ll],
     "vnp_linear_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _i, _vp],
+    "vnp_linear_pool_store_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp],
     "vnp_linear_pool_screened_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _i, _vp, _i],
     "vnp_vn_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _i, _vp, _vp],
     "vnp_vn_pool_bwd": [_vp, _i, _vp, _ll, _i, _i, _vp, _i],

@@ -290,6 +290,39 @@ extern "C" int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, cons
     return vnp_last_error();
 }
 
+// VNLinear -> VNMaxPool where the linear output has ANOTHER consumer too (encoder first_conv[1] -> maxpool1 and second_conv[0]): as
+// vnp_linear_pool_fwd, and y = x W^T [G*gs*3, C] is stored as well (EPI = 5); the direction d = W' x still never exists in memory and
+// the separate direction GEMM + pool pass over y and d are gone.  ws: vnp_linear_pool_ws_bytes(G, gs, C).
+extern "C" int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
+                                         int K, float* y, int ldy, int* idx, float* out, int ldo, void* ws)
+{
+    if (!x || !Wcat || !y || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0) return VNP_EINVAL;
+    const long long M = G * gs * 3;
+    if (vnp_gemm_get_mode() != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || ldy < C || M > 2147483647LL ||
+        (uintptr_t)x % 16 || (uintptr_t)Wcat % 16 || G > 65535)
+        return VNP_EINVAL;
+    const long long nslot = G * (gs / 32) * (long long)C;
+    VnpGemmArgs p{};
+    p.A = x; p.B = Wcat; p.C = y; p.bias = nullptr;
+    p.M = (int)M; p.N = 2 * C; p.K = K;
+    p.lda = ldx; p.ldb = ldw; p.ldc = ldy; p.rows_per_group = 1;
+    p.tiles_per_split = K / 32; p.nsplit = 1; p.nbatch = 1;
+    p.pool_val = (float*)ws;
+    p.pool_idx = (int*)((char*)ws + nslot * 4);
+    p.pool_x = (float*)((char*)ws + nslot * 8);
+    p.pool_gs = gs;
+    p.col_group = 8;
+    const long long items = (M / 192) * (2LL * C / 128);
+    if (items > 2147483647LL) return VNP_EINVAL;
+    const long long cap = (long long)vnp_num_cus() * 2;
+    dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
+    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 5>), grid, block, 0, st, p);
+    hipLaunchKernelGGL(vnp_pool_fused_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
+                       (const float*)p.pool_val, (const int*)p.pool_idx, (const float*)p.pool_x, gs / 32, C, idx, out, ldo,
+                       (const int*)nullptr);
+    return vnp_last_error();
+}
+
 // ---- the same pool with an exact SCREENED arg-max ---------------------------------------------------------------------------
 // The 6-product GEMM above spends 1.65 TFLOP (config 2) to pick ONE point per (sample, channel).  Here a 3-product pass (half
 // the MFMA work, no l plane) brackets every score s6(n, c) = <x6, d6> the 6-product kernels would produce between rigorous

@@ -174,7 +174,8 @@ __device__ __forceinline__ void vnp_split_write(const vnp_u2 (&pl)[NV][3], char*
 // rows are interleaved per 32 channels as [32 rows of W | 32 rows of W'] (x = W f, d = W' f), so a wave's 64 columns are
 // 32 channels of x and the same 32 channels of d.  The A tile is loaded under a row permutation that puts component t of
 // point (16 i3 + r) into MFMA row-tile 3 i3 + t, row r: every lane then holds whole 3-vectors of x and d for 8 points x 2
-// channels, forms <x, d> in registers and reduces the arg-max over the wave's 32 points.  Neither x nor d is ever written.
+// channels, forms <x, d> in registers and reduces the arg-max over the wave's 32 points.  Neither x nor d is ever written
+// (EPI = 5: the same, but x IS stored to C [M, N/2] for the tensor's other consumer).
 template <int BM, int BN, bool AKC, bool BKC, bool FAST, int VAR = 0, int EPI = 0>
 __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArgs p)
 {
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
             }
         }
 
-        if (EPI == 1) {
+        if (EPI == 1 || EPI == 5) {
             // acc[3 i3 + t][j][e]: component t of wave-local point 16 i3 + 4 lq + e; j = 0, 1: x channels, j = 2, 3: d channels
             const int pt0 = m0 / 3 + wm * 32;                         // first point of this wave (global point index)
             const int grp = pt0 / 32;                                  // partial slot: one per 32 points
@@ -352,6 +353,14 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                         const float d0 = acc[3 * i3][jj + 2][e], d1 = acc[3 * i3 + 1][jj + 2][e], d2 = acc[3 * i3 + 2][jj + 2][e];
                         const float dot = fmaf(x2, d2, fmaf(x1, d1, x0 * d0));
                         if ((i3 == 0 && e == 0) || dot > bv) { bv = dot; bi = 16 * i3 + 4 * lq + e; bx0 = x0; bx1 = x1; bx2 = x2; }
+                        if (EPI == 5) {
+                            // x = W f is needed by another consumer as well: store it (rows de-permuted as in EPI = 2: MFMA row-tile
+                            // 3 i3 + t, row r  <->  component t of wave-local point 16 i3 + r); d is still never written
+                            float* dst = p.C + (size_t)(m0 + wm * 96 + (16 * i3 + 4 * lq + e) * 3) * p.ldc + (n0 >> 1) + wn * 32 + jj * 16 + l16;
+                            __builtin_nontemporal_store(x0, dst);
+                            __builtin_nontemporal_store(x1, dst + p.ldc);
+                            __builtin_nontemporal_store(x2, dst + 2 * p.ldc);
+                        }
                     }
 #pragma unroll
                 for (int o = 16; o <= 32; o <<= 1) {                    // the other lane groups hold the other points

@@ -570,6 +570,63 @@ class VNMaxPoolTapFn(Function):
         return gx, None, None, None, None, None
 
 
+class VNLinearPoolTapFn(Function):
+    """VNLinear followed by a VNMaxPool of its output AND by another consumer of that output (encoder first_conv[1] -> maxpool1 /
+    second_conv[0], models/pcn.py:169-172): one GEMM over the interleaved [W ; Wd W] rows stores y = x W^T and pools in its epilogue
+    (vnp_linear_pool_store_fwd) — no direction GEMM, no pass over y and d.  Returns (y, pooled, idx).  Backward: the pool's
+    one-row-per-channel gradient is added into y's gradient from the other consumer (as VNMaxPoolTapFn), then the VNLinear backward."""
+
+    @staticmethod
+    def supported(x, W, G, gs):
+        C, K = W.shape
+        return (POOL_DIRECTION_REASSOCIATE and POOL_FUSED_EPILOGUE and _lib.get_gemm_mode() == "split" and (G * gs * 3) % 192 == 0
+                and gs % 32 == 0 and C % 64 == 0 and K % 32 == 0 and G <= 65535 and x.dim() == 2 and x.stride(1) == 1
+                and _ld(x) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, x, W, Wd, G, gs):
+        x = _rows(x)
+        C, K = W.shape
+        dev = x.device
+        Wp = gemm(Wd, W, op_b=1)
+        Wcat = torch.stack([_rows(W).view(C // 32, 32, K), Wp.view(C // 32, 32, K)], dim=1).reshape(2 * C, K)
+        y = torch.empty((G * gs * 3, C), device=dev, dtype=torch.float32)
+        idx = torch.empty((G, C), device=dev, dtype=torch.int32)
+        out = torch.empty((G * 3, C), device=dev, dtype=torch.float32)
+        ws = torch.empty((_lib.lib().vnp_linear_pool_ws_bytes(G, gs, C) + 7) // 8, device=dev, dtype=torch.int64)
+        prof = GEMM_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("vnp_linear_pool_store_fwd", ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(y), C, ptr(idx), ptr(out), C, ptr(ws))
+        if prof is not None:
+            e1.record()
+            prof.append(("NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
+        _trace("linear_pool_tap_fused", idx)
+        ctx.save_for_backward(x, W, idx)
+        ctx.cfg = (G, gs, C)
+        ctx.mark_non_differentiable(idx)
+        return y, out, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gout, _gidx):
+        x, W, idx = ctx.saved_tensors
+        G, gs, C = ctx.cfg
+        if gout is not None:
+            gout = _rows(gout)
+            if gy is None or gy.dim() != 2 or gy.stride(1) != 1 or gy.shape != (G * gs * 3, C):
+                dense = torch.empty((G * gs * 3, C), device=x.device, dtype=torch.float32)
+                call("vnp_vn_pool_bwd", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(dense), C)
+                gy = dense if gy is None else gy + dense
+            else:
+                call("vnp_vn_pool_bwd_acc", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(gy), _ld(gy))
+        gy = _rows(gy)
+        gx = gemm(gy, W, op_b=1) if ctx.needs_input_grad[0] else None
+        gW = _wgrad(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gW, None, None, None
+
+
 class VNLinearMaxPoolFn(Function):
     """VNLinear followed by VNMaxPool when the pool is the linear output's ONLY consumer (encoder second_conv[1] ->
     maxpool2, models/pcn.py:173-174).  Forward: y = x W^T, d = y Wd^T, arg-max pool (y and d are dropped afterwards).
