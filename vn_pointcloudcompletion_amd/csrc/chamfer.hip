@@ -105,6 +105,66 @@ __global__ void vnp_chamfer_grad_kernel(int n, const float* __restrict__ xyz1, i
     }
 }
 
+// The scatter half of the backward without global atomics.  Workgroup (part, b, direction) owns CHG_TARGETS consecutive points of
+// the cloud that RECEIVES the scatter, keeps their three gradient components as doubles in LDS, scans the nearest-neighbour indices of
+// all points of the other cloud and adds  -2 g_j (q_j - r_idx[j])  for those that land in its range (ds_add_f64: order of arrival
+// varies, but a double sum of <= 32768 fp32 terms rounds to the same float except on rounding ties — where the 1.5 M scattered
+// global float atomics of the previous version (0.67 ms per step: each lane its own 64-B memory-side request) differed run to run in the
+// last bits), then adds the sums to the points' own terms, which vnp_chamfer_own_kernel has stored.
+#define CHG_TARGETS 2048
+__global__ void __launch_bounds__(1024) vnp_chamfer_scatter_kernel(int n, const float* __restrict__ xyz1, int m, const float* __restrict__ xyz2,
+                                                                   const float* __restrict__ gd1, const int* __restrict__ idx1,
+                                                                   const float* __restrict__ gd2, const int* __restrict__ idx2,
+                                                                   float* __restrict__ g1, float* __restrict__ g2)
+{
+    __shared__ double acc[CHG_TARGETS * 3];
+    const int b = blockIdx.y, dir = blockIdx.z;
+    // dir 0: queries = cloud 1 (n points, idx1 into cloud 2), receiver = cloud 2;  dir 1: the converse
+    const int nq = dir == 0 ? n : m, nr = dir == 0 ? m : n;
+    const int t0 = blockIdx.x * CHG_TARGETS;
+    if (t0 >= nr) return;
+    const float* q = (dir == 0 ? xyz1 : xyz2) + (size_t)b * nq * 3;
+    const float* r = (dir == 0 ? xyz2 : xyz1) + (size_t)b * nr * 3;
+    const float* gd = (dir == 0 ? gd1 : gd2) + (size_t)b * nq;
+    const int* ix = (dir == 0 ? idx1 : idx2) + (size_t)b * nq;
+    float* out = (dir == 0 ? g2 : g1) + (size_t)b * nr * 3;
+    for (int i = threadIdx.x; i < CHG_TARGETS * 3; i += 1024) acc[i] = 0.0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < nq; j += 1024) {
+        const int t = ix[j] - t0;
+        if ((unsigned)t >= (unsigned)CHG_TARGETS) continue;
+        const float g = gd[j] * 2.f;
+        const float* rp = r + (size_t)(t0 + t) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = g * (q[(size_t)j * 3 + c] - rp[c]);          // the same fp32 value the point's own term uses
+            atomicAdd(&acc[t * 3 + c], -(double)v);
+        }
+    }
+    __syncthreads();
+    const int lim = min(CHG_TARGETS, nr - t0) * 3;
+    for (int i = threadIdx.x; i < lim; i += 1024) out[(size_t)t0 * 3 + i] += (float)acc[i];
+}
+
+// own terms of both directions: g1[j] = 2 gd1[j] (x1[j] - x2[idx1[j]]),  g2[j] = 2 gd2[j] (x2[j] - x1[idx2[j]])   (plain stores)
+__global__ void vnp_chamfer_own_kernel(int n, const float* __restrict__ xyz1, int m, const float* __restrict__ xyz2,
+                                       const float* __restrict__ gd1, const int* __restrict__ idx1,
+                                       const float* __restrict__ gd2, const int* __restrict__ idx2,
+                                       float* __restrict__ g1, float* __restrict__ g2)
+{
+    const int b = blockIdx.y, dir = blockIdx.z;
+    const int nq = dir == 0 ? n : m, nr = dir == 0 ? m : n;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nq) return;
+    const float* q = (dir == 0 ? xyz1 : xyz2) + ((size_t)b * nq + j) * 3;
+    const int t = (dir == 0 ? idx1 : idx2)[(size_t)b * nq + j];
+    const float* r = (dir == 0 ? xyz2 : xyz1) + ((size_t)b * nr + t) * 3;
+    const float g = (dir == 0 ? gd1 : gd2)[(size_t)b * nq + j] * 2.f;
+    float* o = (dir == 0 ? g1 : g2) + ((size_t)b * nq + j) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = g * (q[c] - r[c]);
+}
+
 static int vnp_chamfer_one_direction(hipStream_t st, int B, int n, const float* q, int m, const float* r,
                                      float* dist, int* idx, unsigned long long* packed)
 {
@@ -444,9 +504,19 @@ extern "C" int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, 
     if (B <= 0 || n <= 0 || m <= 0 || !xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2)
         return VNP_EINVAL;
     if (B > 65535) return VNP_EINVAL;
+    if (n <= 32768 && m <= 32768) {
+        // own terms (plain stores), then the scatter terms through LDS accumulators: no global atomics
+        const int big = n > m ? n : m;
+        hipLaunchKernelGGL(vnp_chamfer_own_kernel, dim3(vnp_cdiv(big, 256), B, 2), dim3(256), 0, st, n, xyz1, m, xyz2, grad_dist1, idx1,
+                           grad_dist2, idx2, grad_xyz1, grad_xyz2);
+        hipLaunchKernelGGL(vnp_chamfer_scatter_kernel, dim3(vnp_cdiv(big, CHG_TARGETS), B, 2), dim3(1024), 0, st, n, xyz1, m, xyz2,
+                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2);
+        return vnp_last_error();
+    }
     hipError_t e = hipMemsetAsync(grad_xyz2, 0, (size_t)B * m * 12, st);
     if (e != hipSuccess) return (int)e;
-    // pass 1 stores grad_xyz1 and scatters into the zeroed grad_xyz2; pass 2 adds its own terms to grad_xyz2 and scatters into grad_xyz1
+    // very large clouds: pass 1 stores grad_xyz1 and scatters (global atomics) into the zeroed grad_xyz2; pass 2 adds its own terms to
+    // grad_xyz2 and scatters into grad_xyz1
     hipLaunchKernelGGL(vnp_chamfer_grad_kernel<true>, dim3(vnp_cdiv(n, 256), B), dim3(256), 0, st, n, xyz1, m, xyz2, grad_dist1, idx1, grad_xyz1, grad_xyz2);
     hipLaunchKernelGGL(vnp_chamfer_grad_kernel<false>, dim3(vnp_cdiv(m, 256), B), dim3(256), 0, st, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
     return vnp_last_error();
