@@ -175,7 +175,6 @@ def roofline_other(B, N, Mc, Md):
     the HBM bound (algorithmic bytes: every operand read or written once)."""
     import torch
     from vn_pointcloudcompletion_amd import ops
-    from vn_pointcloudcompletion_amd._lib import call, ptr
     out = []
     g = torch.Generator().manual_seed(5)
     dense = (torch.rand(B, Md, 3, generator=g) - 0.5).cuda()
