@@ -46,17 +46,35 @@ static int vnp_num_cus()
     return n;
 }
 
-// out[r][c] (+)= sum_z ws[z][r][c]; ws slabs are dense [M, N]
-__global__ void vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit, long long slab, float* __restrict__ C,
-                                        int M, int N, int ldc, int accumulate)
+// out[r][c] (+)= sum_z ws[z][r][c]; ws slabs are dense [M, N].  A workgroup = 64 consecutive outputs x 4 slab lanes: lane q sums the
+// slabs z = q, q + 4, ... with four loads in flight, the four partial sums meet in LDS in a fixed order (deterministic).  (One thread
+// per output walking all nsplit slabs was a dependent chain of up to 256 loads: 19 us per call at 1 TB/s, 109 calls per step in config 5.)
+__global__ void __launch_bounds__(256) vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit, long long slab, float* __restrict__ C,
+                                                               int M, int N, int ldc, int accumulate)
 {
+    __shared__ float part[4][64];
     const long long total = (long long)M * N;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < nsplit; ++z) s += ws[(size_t)z * slab + i];
-        const int r = (int)(i / N), c = (int)(i % N);
-        float* dst = C + (size_t)r * ldc + c;
-        *dst = accumulate ? *dst + s : s;
+    const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+        const long long i = base + ox;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (i < total) {
+            const float* src = ws + i;
+            int z = q;
+            for (; z + 12 < nsplit; z += 16) {
+                s0 += src[(size_t)z * slab]; s1 += src[(size_t)(z + 4) * slab]; s2 += src[(size_t)(z + 8) * slab]; s3 += src[(size_t)(z + 12) * slab];
+            }
+            for (; z < nsplit; z += 4) s0 += src[(size_t)z * slab];
+        }
+        part[q][ox] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && i < total) {
+            const float s = (part[0][ox] + part[1][ox]) + (part[2][ox] + part[3][ox]);
+            const int r = (int)(i / N), c = (int)(i % N);
+            float* dst = C + (size_t)r * ldc + c;
+            *dst = accumulate ? *dst + s : s;
+        }
+        __syncthreads();
     }
 }
 
@@ -162,7 +180,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             hipLaunchKernelGGL(vnp_gemm_wcolsum_kernel, dim3(vnp_cdiv(cols, 64), ns), dim3(256), 0, stream, X, ldx, wv, ws_, K, cols, rps, slab);
             int rc2 = vnp_last_error();
             if (rc2) return rc2;
-            int blocks = vnp_cdiv(cols, 256);
+            int blocks = vnp_cdiv(cols, 64);
             hipLaunchKernelGGL(vnp_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)slab, ns, (long long)cols, C,
                                M, N, ldc, accumulate);
             return vnp_last_error();
@@ -218,8 +236,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     if (rc) return rc;
     if (nsplit > 1) {
         const long long total = (long long)M * N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 4096) blocks = 4096;
+        int blocks = (int)((total + 63) / 64 > 16384 ? 16384 : (total + 63) / 64);
         hipLaunchKernelGGL(vnp_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream,
                            (const float*)ws, nsplit, (long long)M * N, C, M, N, ldc, accumulate);
         rc = vnp_last_error();
