@@ -544,6 +544,9 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                         if (p.accumulate) v += drow[col];
                         // activation-sized outputs are streamed (non-temporal: they do not fit any cache and would only evict the
                         // A / B panels); split-K slabs are re-read at once by the slab reduction and stay cached
+#ifdef VNP_EXPERIMENT_NO_STORE             // scripts/gemm_variants_probe.hip only: prices the epilogue's stores (one lane in 2^20 still stores)
+                        if (v != 1.2345678e-30f) continue;
+#endif
                         if (p.nsplit == 1) __builtin_nontemporal_store(v, &drow[col]);
                         else drow[col] = v;
                     }
