@@ -162,7 +162,8 @@ int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx, const flo
 /* The same operator — same arguments, same restrictions, same results BIT FOR BIT — with an exact screened arg-max: a 3-product
  * pass (half the MFMA work) brackets every score between rigorous bounds, the ~1-2 surviving candidates per (group, channel) are
  * evaluated exactly as diagonals of MFMA tiles with the full kernels' product sequence, and a predicated launch of the full
- * kernel takes over if the candidate list overflows or a bound is not finite (NaN / Inf inputs, massive exact ties).
+ * kernel takes over if the candidate list (32 pairs per (group, channel) on average) overflows or a bound is not finite (NaN / Inf
+ * inputs, massive exact ties).
  * ws: vnp_linear_pool_screened_ws_bytes(G, gs, C) bytes; afterwards its first three ints are {candidates evaluated,
  * fallback flag, candidate capacity} (diagnostics). */
 /* flags: 0 = bracketing pass on three bf16 products (truncation 2^-16); VNP_POOL_SCREEN_FP16 = on ONE fp16 product (2^-10: about twice

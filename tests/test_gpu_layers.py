@@ -306,6 +306,33 @@ def test_screened_pool_random_shapes_and_magnitudes(lib_built):
     print(f"fallback flag raised in {flags} of 48 screened calls")
 
 
+def test_screened_pool_backs_off_after_a_fallback(lib_built):
+    """After a call whose candidate list overflowed, the next calls of that shape skip the bracketing pass (the flag travels to the host
+    through a non-blocking copy: no sync in the forward) and the search is tried again once the back-off has run out."""
+    require_split_gemm()
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(9)
+    G, gs, C, K = 2, 64, 64, 32
+    same = torch.randn(1, 3, K, generator=g).expand(G * gs, 3, K).reshape(G * gs * 3, K).contiguous().cuda()   # every point identical: overflow
+    W, Wd = (torch.randn(C, K, generator=g) / K ** 0.5).cuda(), (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    key = (torch.cuda.current_device(), G, gs, C, K)
+    ops._screen_state.pop(key, None)
+    old = ops.POOL_SCREEN_BACKOFF
+    ops.POOL_SCREEN_BACKOFF = 3
+    try:
+        paths = []
+        for _ in range(7):
+            ops.TRACE = tr = {}
+            ops.VNLinearMaxPoolFn.apply(same, W, Wd, G, gs)
+            torch.cuda.synchronize()                       # lets the flag of this call be visible to the next one
+            ops.TRACE = None
+            paths.append("screened" if "linear_pool_screened" in tr else "full")
+        assert paths == ["screened", "full", "full", "full", "screened", "full", "full"], paths
+    finally:
+        ops.POOL_SCREEN_BACKOFF, ops.TRACE = old, None
+        ops._screen_state.pop(key, None)
+
+
 def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
     require_split_gemm()
     g = torch.Generator().manual_seed(6)

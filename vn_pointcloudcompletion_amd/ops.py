@@ -42,6 +42,35 @@ POOL_SCREEN_PASS = _os.environ.get("VNP_POOL_SCREEN_PASS", "fp16")
 BN_BWD_TWO_PASS = _os.environ.get("VNP_BN_BWD_TWO_PASS", "1") != "0"
 # tests set this to a list to receive the screened pool's diagnostics tensor (int32 [3]: candidates, fallback flag, capacity)
 POOL_SCREEN_STATS = None
+# If the screened search had to fall back (candidate list overflow, non-finite bounds) the bracketing pass was wasted work.  The flag of
+# every call is copied to pinned host memory WITHOUT a sync and looked at when the next call of the same shape comes round: after a
+# fallback the next POOL_SCREEN_BACKOFF calls of that shape go straight to the full six-product epilogue, then the search is tried again.
+POOL_SCREEN_BACKOFF = 64
+_screen_state = {}        # shape key -> {"host": pinned int32[4], "event": Event or None, "skip": calls left on the full path}
+
+
+def _screen_allowed(key):
+    st = _screen_state.get(key)
+    if st is None:
+        return True
+    if st["event"] is not None and st["event"].query():
+        if int(st["host"][1]) != 0:
+            st["skip"] = POOL_SCREEN_BACKOFF
+        st["event"] = None
+    if st["skip"] > 0:
+        st["skip"] -= 1
+        return False
+    return True
+
+
+def _screen_report(key, ws):
+    st = _screen_state.get(key)
+    if st is None:
+        st = _screen_state[key] = {"host": torch.zeros(4, dtype=torch.int32).pin_memory(), "event": None, "skip": 0}
+    if st["event"] is None:                      # one copy in flight per shape is enough
+        st["host"].copy_(ws[:2].view(torch.int32), non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record()
 
 # bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
 # entries are (variant, flops, start_event, end_event)
@@ -641,11 +670,14 @@ class VNLinearMaxPoolFn(Function):
         out = torch.empty((G * 3, C), device=x.device, dtype=torch.float32)
         fused = (POOL_DIRECTION_REASSOCIATE and POOL_FUSED_EPILOGUE and _lib.get_gemm_mode() == "split" and (G * gs * 3) % 192 == 0
                  and gs % 32 == 0 and C % 64 == 0 and K % 32 == 0 and G <= 65535 and _ld(x) % 4 == 0 and x.data_ptr() % 16 == 0)
+        screened = False
         if fused:
             # one GEMM over the interleaved [W ; Wd W] rows whose epilogue does the arg-max pool: y and d are never written
             Wp = gemm(Wd, W, op_b=1)
             Wcat = torch.stack([_rows(W).view(C // 32, 32, K), Wp.view(C // 32, 32, K)], dim=1).reshape(2 * C, K)
-            screened = POOL_SCREENED and gs <= 2048            # the selection pass keeps a group's 32-point blocks in registers
+            skey = (x.device.index, G, gs, C, K)
+            # the selection pass keeps a group's 32-point blocks in registers (gs <= 2048); back off after a fallback (see above)
+            screened = POOL_SCREENED and gs <= 2048 and (POOL_SCREEN_STATS is not None or _screen_allowed(skey))
             entry = "vnp_linear_pool_screened_fwd" if screened else "vnp_linear_pool_fwd"
             nb = (_lib.lib().vnp_linear_pool_screened_ws_bytes if screened else _lib.lib().vnp_linear_pool_ws_bytes)(G, gs, C)
             ws = torch.empty((nb + 7) // 8, device=x.device, dtype=torch.int64)
@@ -663,8 +695,11 @@ class VNLinearMaxPoolFn(Function):
                 e1.record()
                 # algorithmic work of the pool: both products over every point; the screened search EXECUTES about half of it
                 prof.append(("NT-pool-screened" if screened else "NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
-            if screened and POOL_SCREEN_STATS is not None:
-                POOL_SCREEN_STATS.append(ws[:2].view(torch.int32)[:3].clone())
+            if screened:
+                if POOL_SCREEN_STATS is not None:
+                    POOL_SCREEN_STATS.append(ws[:2].view(torch.int32)[:3].clone())
+                else:
+                    _screen_report(skey, ws)
         else:
             y = gemm(x, W, nsplit=1)
             if POOL_DIRECTION_REASSOCIATE:
@@ -678,7 +713,7 @@ class VNLinearMaxPoolFn(Function):
             ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
             ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
             call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
-        _trace(("linear_pool_screened" if (POOL_SCREENED and gs <= 2048) else "linear_pool_fused_epilogue") if fused else "linear_pool_unfused", idx)
+        _trace(("linear_pool_screened" if screened else "linear_pool_fused_epilogue") if fused else "linear_pool_unfused", idx)
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
