@@ -453,29 +453,81 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float
     }
 }
 
-// one wave = 16 candidate pairs: x6_t = <f[(pt, t)], W_c>, d6_t = <f[(pt, t)], W'_c> as diagonals of 16x16x32 bf16 MFMA tiles with
-// the product sequence of vnp_gemm_split_kernel (K-tiles ascending; per K-tile (l h)(h l)(m m)(m h)(h m)(h h)), then the score in the
-// pool kernels' fmaf form.  Operands go global -> registers -> MFMA (a lane's fragment IS row lane&15, k = 8 (lane>>4) .. +7).
-__global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Wcat, int ldw,
-                                                                    int K, const VnpScreenHead* __restrict__ head, const int2* __restrict__ list,
-                                                                    const int* __restrict__ order, float4* __restrict__ res)
+// ---- exact evaluation of the candidate pairs ---------------------------------------------------------------------------------------
+// The pairs are counting-sorted by BIN = 5 consecutive points (hist -> scan -> scatter).  One wave evaluates one TILE = up to 16 pairs of
+// one bin: the A operand of its MFMAs holds the bin's 15 feature rows (5 points x 3 components, row 3 s + t), the B operands the W and W'
+// rows of the tile's 16 pairs, so  C[3 s + t][j] = <f[(5 bin + s, t)], W_(c_j)>  and pair j reads its x6 / d6 from the three rows of its
+// own point — 48 of the 256 tile entries are useful instead of the 16 of a pure diagonal arrangement, and a bin's feature rows are
+// converted once per tile instead of once per pair.  Product sequence and K order are those of vnp_gemm_split_kernel (K-tiles ascending;
+// per K-tile (l h)(h l)(m m)(m h)(h m)(h h); A = features, B = weights), so x6, d6 and the score (the pool kernels' fmaf form) have the bits
+// the full kernels produce: an MFMA output element depends only on its own A row, B row and accumulator.
+#define SCR_BIN 5
+
+__global__ void vnp_pool_screen_hist_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ list, int* __restrict__ hist)
 {
     const int count = head->flag ? 0 : head->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) atomicAdd(&hist[list[i].x / SCR_BIN], 1);
+}
+
+// hist[n] (counts) -> start[n + 1] (exclusive prefix of the counts), cursor[n] (a copy for the scatter pass), tstart[n + 1] (exclusive
+// prefix of the tiles ceil(count / 16)); one workgroup of 1024 threads, contiguous chunks + an LDS scan of the chunk totals
+__global__ void __launch_bounds__(1024) vnp_pool_screen_scan_kernel(const int* __restrict__ hist, int n, int* __restrict__ start,
+                                                                    int* __restrict__ cursor, int* __restrict__ tstart)
+{
+    __shared__ int tot[1024], ttot[1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
+    int s = 0, ts = 0;
+    for (int i = lo; i < hi; ++i) { const int v = hist[i]; s += v; ts += (v + 15) >> 4; }
+    tot[t] = s; ttot[t] = ts;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? tot[t - o] : 0, tv = t >= o ? ttot[t - o] : 0;
+        __syncthreads();
+        tot[t] += v; ttot[t] += tv;
+        __syncthreads();
+    }
+    int run = tot[t] - s, trun = ttot[t] - ts;
+    for (int i = lo; i < hi; ++i) {
+        const int v = hist[i];
+        start[i] = run; cursor[i] = run; tstart[i] = trun;
+        run += v; trun += (v + 15) >> 4;
+    }
+    if (t == 1023) { start[n] = tot[1023]; tstart[n] = ttot[1023]; }
+}
+
+__global__ void vnp_pool_screen_scatter_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ list, int* __restrict__ cursor,
+                                               int* __restrict__ order)
+{
+    const int count = head->flag ? 0 : head->count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) order[atomicAdd(&cursor[list[i].x / SCR_BIN], 1)] = i;
+}
+
+__global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ Wcat, int ldw,
+                                                                    int K, long long npts, const VnpScreenHead* __restrict__ head,
+                                                                    const int2* __restrict__ list, const int* __restrict__ order,
+                                                                    const int* __restrict__ start, const int* __restrict__ tstart, int nbins,
+                                                                    float4* __restrict__ res)
+{
+    if (head->flag) return;
     const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile * 16 >= count) return;
-    // pairs are visited in point order (order[]: counting sort by point), so the 16 pairs of a wave share a few points and the
-    // feature rows — 12 KB per point, the bulk of this pass's traffic — are fetched once instead of once per pair
-    const int mine = order[min(tile * 16 + l16, count - 1)];
+    if (tile >= tstart[nbins]) return;
+    // the bin of this tile: largest b with tstart[b] <= tile (wave-uniform binary search)
+    int lo = 0, hi = nbins;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tstart[mid] <= tile) lo = mid; else hi = mid; }
+    const int bin = lo;
+    const int first = start[bin] + 16 * (tile - tstart[bin]);
+    const int npair = min(16, start[bin + 1] - first);
+    const int mine = order[first + min(l16, npair - 1)];              // lanes past the tile's last pair repeat it
     const int2 pc = list[mine];
-    const float* f0 = x + (size_t)pc.x * 3 * ldx + lq * 8;
+    // A row of this lane: component r % 3 of point 5 bin + r / 3 (r = lane & 15; row 15 is unused and repeats row 14)
+    const int r = min(l16, 14);
+    long long pa = (long long)bin * SCR_BIN + r / 3;
+    if (pa >= npts) pa = npts - 1;
+    const float* f0 = x + ((size_t)pa * 3 + r % 3) * ldx + lq * 8;
     const float* w0 = Wcat + (size_t)((pc.y >> 5) * 64 + (pc.y & 31)) * ldw + lq * 8;
     const float* w1 = w0 + (size_t)32 * ldw;
-    vnp_f4 ax[3], ad[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ax[t][e] = 0.f; ad[t][e] = 0.f; }
+    vnp_f4 ax = {0.f, 0.f, 0.f, 0.f}, ad = {0.f, 0.f, 0.f, 0.f};
     auto planes = [](const vnp_f4 v0, const vnp_f4 v1, vnp_bf8 (&pl)[3]) {
         unsigned h[4], m[4], l[4];
         vnp_split_pair(v0[0], v0[1], h[0], m[0], l[0]);
@@ -488,78 +540,45 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float*
     };
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-    const float* src[5] = {f0, f0 + ldx, f0 + 2 * (size_t)ldx, w0, w1};
-    vnp_f4 cur[5][2], nxt[5][2];
+    const float* src[3] = {f0, w0, w1};
+    vnp_f4 cur[3][2], nxt[3][2];
 #pragma unroll
-    for (int o = 0; o < 5; ++o) { cur[o][0] = *(const vnp_f4*)src[o]; cur[o][1] = *(const vnp_f4*)(src[o] + 4); }
+    for (int o = 0; o < 3; ++o) { cur[o][0] = *(const vnp_f4*)src[o]; cur[o][1] = *(const vnp_f4*)(src[o] + 4); }
     for (int k0 = 0; k0 < K; k0 += 32) {
         if (k0 + 32 < K) {                          // next K-step's operands in flight during this step's MFMAs
 #pragma unroll
-            for (int o = 0; o < 5; ++o) { nxt[o][0] = *(const vnp_f4*)(src[o] + k0 + 32); nxt[o][1] = *(const vnp_f4*)(src[o] + k0 + 36); }
+            for (int o = 0; o < 3; ++o) { nxt[o][0] = *(const vnp_f4*)(src[o] + k0 + 32); nxt[o][1] = *(const vnp_f4*)(src[o] + k0 + 36); }
         }
-        vnp_bf8 a[3][3], bw[3], bd[3];
+        vnp_bf8 a[3], bw[3], bd[3];
+        planes(cur[0][0], cur[0][1], a);
+        planes(cur[1][0], cur[1][1], bw);
+        planes(cur[2][0], cur[2][1], bd);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) planes(cur[t][0], cur[t][1], a[t]);
-        planes(cur[3][0], cur[3][1], bw);
-        planes(cur[4][0], cur[4][1], bd);
+        for (int q = 0; q < 6; ++q) {
+            ax = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], bw[PB[q]], ax, 0, 0, 0);
+            ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[PA[q]], bd[PB[q]], ad, 0, 0, 0);
+        }
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                ax[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][PA[q]], bw[PB[q]], ax[t], 0, 0, 0);
-                ad[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t][PA[q]], bd[PB[q]], ad[t], 0, 0, 0);
-            }
-#pragma unroll
-        for (int o = 0; o < 5; ++o) { cur[o][0] = nxt[o][0]; cur[o][1] = nxt[o][1]; }
+        for (int o = 0; o < 3; ++o) { cur[o][0] = nxt[o][0]; cur[o][1] = nxt[o][1]; }
     }
-    // C layout: lane holds column lane&15, rows 4 (lane>>4) + e: the diagonal element of pair i sits in lane (i>>2)*16 + i, e = i&3
-    if (lq == (l16 >> 2) && tile * 16 + l16 < count) {
-        const int e = l16 & 3;
-        float xv[3], dv[3];
+    // C layout: lane (lq, col j = lane & 15) holds rows 4 lq + e of column j.  Pair j needs rows 3 s + t (s = its point's slot in the bin):
+    // row R sits in lane (R >> 2) * 16 + j, register R & 3 — fetched with one shuffle per register and selected.
+    const int sl = pc.x - bin * SCR_BIN;                                          // 0 .. 4
+    float xv[3], dv[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            xv[t] = e == 0 ? ax[t][0] : e == 1 ? ax[t][1] : e == 2 ? ax[t][2] : ax[t][3];
-            dv[t] = e == 0 ? ad[t][0] : e == 1 ? ad[t][1] : e == 2 ? ad[t][2] : ad[t][3];
-        }
+    for (int t = 0; t < 3; ++t) {
+        const int R = 3 * sl + t, srcl = (R >> 2) * 16 + l16, e = R & 3;
+        const float x0 = __shfl(ax[0], srcl), x1 = __shfl(ax[1], srcl), x2 = __shfl(ax[2], srcl), x3 = __shfl(ax[3], srcl);
+        const float d0 = __shfl(ad[0], srcl), d1 = __shfl(ad[1], srcl), d2 = __shfl(ad[2], srcl), d3 = __shfl(ad[3], srcl);
+        xv[t] = e == 0 ? x0 : e == 1 ? x1 : e == 2 ? x2 : x3;
+        dv[t] = e == 0 ? d0 : e == 1 ? d1 : e == 2 ? d2 : d3;
+    }
+    if (lq == 0 && l16 < npair) {
         float4 o;
         o.x = xv[0]; o.y = xv[1]; o.z = xv[2];
         o.w = fmaf(xv[2], dv[2], fmaf(xv[1], dv[1], xv[0] * dv[0]));      // the pool kernels' score form
         res[mine] = o;
     }
-}
-
-// ---- counting sort of the candidate pairs by group of 4 consecutive points (3 tiny kernels; the list itself stays grouped by
-// (sample, channel)) ----
-__global__ void vnp_pool_screen_hist_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ list, int* __restrict__ hist)
-{
-    const int count = head->flag ? 0 : head->count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) atomicAdd(&hist[list[i].x >> 2], 1);
-}
-
-// in place: hist[n] -> exclusive prefix sums (one workgroup of 1024 threads, contiguous chunks + an LDS scan of the chunk totals)
-__global__ void __launch_bounds__(1024) vnp_pool_screen_scan_kernel(int* __restrict__ hist, int n)
-{
-    __shared__ int tot[1024];
-    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += hist[i];
-    tot[t] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = t >= o ? tot[t - o] : 0;
-        __syncthreads();
-        tot[t] += v;
-        __syncthreads();
-    }
-    int run = tot[t] - s;
-    for (int i = lo; i < hi; ++i) { const int v = hist[i]; hist[i] = run; run += v; }
-}
-
-__global__ void vnp_pool_screen_scatter_kernel(const VnpScreenHead* __restrict__ head, const int2* __restrict__ list, int* __restrict__ cursor,
-                                               int* __restrict__ order)
-{
-    const int count = head->flag ? 0 : head->count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) order[atomicAdd(&cursor[list[i].x >> 2], 1)] = i;
 }
 
 // per (group, channel): arg-max over its candidates' exact scores (strictly greater wins, ties to the lowest point: the first maximum
@@ -607,7 +626,7 @@ extern "C" long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int 
     if (G <= 0 || gs <= 0 || C <= 0 || gs % 32) return 0;
     const long long nslot = G * (gs / 32) * (long long)C, cap = vnp_screen_cap(G, C);
     return 256 + vnp_align256(G * gs * 3 * 4) + vnp_align256(2LL * C * 4) + vnp_align256(nslot * 16) + vnp_align256(nslot * 4) + vnp_align256(G * C * 8) +
-           vnp_align256(cap * 8) + vnp_align256(cap * 16) + vnp_align256(G * gs * 4) + vnp_align256(cap * 4) +
+           vnp_align256(cap * 8) + vnp_align256(cap * 16) + 4 * vnp_align256((G * gs / SCR_BIN + 2) * 4) + vnp_align256(cap * 4) +
            vnp_align256(vnp_linear_pool_ws_bytes(G, gs, C));
 }
 
@@ -631,7 +650,12 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     int2* seg = (int2*)w;                          w += vnp_align256(G * C * 8);
     int2* list = (int2*)w;                         w += vnp_align256(cap * 8);
     float4* res = (float4*)w;                      w += vnp_align256(cap * 16);
-    int* hist = (int*)w;                           w += vnp_align256(G * gs * 4);
+    const int nbins = (int)((G * gs + SCR_BIN - 1) / SCR_BIN);
+    const long long binb = vnp_align256((G * gs / SCR_BIN + 2) * 4);
+    int* hist = (int*)w;                           w += binb;
+    int* start = (int*)w;                          w += binb;
+    int* cursor = (int*)w;                         w += binb;
+    int* tstart = (int*)w;                         w += binb;
     int* order = (int*)w;                          w += vnp_align256(cap * 4);
     void* ws_full = (void*)w;
     hipLaunchKernelGGL(vnp_pool_screen_init_kernel, dim3(1), dim3(1), 0, st, head, (int)cap);
@@ -662,15 +686,16 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
         p.screen_abs = 0.f;
         hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 3>), grid, block, 0, st, p);
     }
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)G * gs, st);                  // G*gs/4 bins (gs % 32 == 0)
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)nbins * 4, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vnp_pool_screen_select_kernel, dim3(C / 64, (unsigned)G), dim3(256), 0, st,
                        (const float4*)slots, (const int*)slot_idx, gs / 32, C, gs, head, seg, list);
     hipLaunchKernelGGL(vnp_pool_screen_hist_kernel, dim3(1024), dim3(256), 0, st, (const VnpScreenHead*)head, (const int2*)list, hist);
-    hipLaunchKernelGGL(vnp_pool_screen_scan_kernel, dim3(1), dim3(1024), 0, st, hist, (int)(G * gs / 4));
-    hipLaunchKernelGGL(vnp_pool_screen_scatter_kernel, dim3(1024), dim3(256), 0, st, (const VnpScreenHead*)head, (const int2*)list, hist, order);
-    hipLaunchKernelGGL(vnp_pool_screen_exact_kernel, dim3((unsigned)vnp_cdiv(cap, 64)), dim3(256), 0, st, x, ldx, Wcat, ldw, K,
-                       (const VnpScreenHead*)head, (const int2*)list, (const int*)order, res);
+    hipLaunchKernelGGL(vnp_pool_screen_scan_kernel, dim3(1), dim3(1024), 0, st, (const int*)hist, nbins, start, cursor, tstart);
+    hipLaunchKernelGGL(vnp_pool_screen_scatter_kernel, dim3(1024), dim3(256), 0, st, (const VnpScreenHead*)head, (const int2*)list, cursor, order);
+    // at most cap / 16 + nbins tiles (every bin's last tile may be partial); waves past the real tile count exit at once
+    hipLaunchKernelGGL(vnp_pool_screen_exact_kernel, dim3((unsigned)vnp_cdiv(cap / 16 + nbins, 4)), dim3(256), 0, st, x, ldx, Wcat, ldw, K,
+                       G * gs, (const VnpScreenHead*)head, (const int2*)list, (const int*)order, (const int*)start, (const int*)tstart, nbins, res);
     hipLaunchKernelGGL(vnp_pool_screen_final_kernel, dim3(vnp_cdiv(C, 32), (unsigned)G), dim3(256), 0, st,
                        (const VnpScreenHead*)head, (const int2*)seg, (const int2*)list, (const float4*)res, C, gs, idx, out, ldo);
     // predicated fallback: the full 6-product pool, runs only if the flag was raised
