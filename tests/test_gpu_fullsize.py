@@ -147,3 +147,28 @@ def test_other_configs_step_at_full_batch_and_resolution(lib_built, enc, dec, B,
     assert ms < ceiling_ms, ms
     del net, opt
     torch.cuda.empty_cache()
+
+
+def test_screened_pool_on_surface_like_clouds_needs_no_fallback(net):
+    """The candidate count of the screened arg-max pool depends on the data: uniform noise (the benchmark's clouds) leaves ~4 candidates
+    per (sample, channel), points sampled from a surface ~20 (neighbouring points have nearly equal scores).  The candidate list must hold
+    that without raising the fallback flag."""
+    from vn_pointcloudcompletion_amd import _lib, ops
+    if _lib.get_gemm_mode() != "split":
+        pytest.skip("the screened pool belongs to the split GEMM mode")
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(4, 2048, 3, generator=g)
+    v = v / v.norm(dim=-1, keepdim=True)
+    p = (v * (0.35 + 0.05 * torch.sin(7 * v[..., :1]))).cuda()
+    net.train()
+    stats = []
+    ops.POOL_SCREEN_STATS = stats
+    try:
+        with torch.no_grad():
+            net(p)
+    finally:
+        ops.POOL_SCREEN_STATS = None
+    cand, flag, cap = stats[-1].tolist()
+    per_pair = cand / (4 * 2048)
+    print(f"surface-like clouds: {per_pair:.1f} candidates per (sample, channel), capacity {cap / (4 * 2048):.0f}, fallback flag {flag}")
+    assert flag == 0 and per_pair < 32
