@@ -245,12 +245,13 @@ int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v,
  *   mode 2: partial [nchunk][C][2] = (sum g_nhat, sum g_nhat*xhat) from the upstream gradient go
  *   mode 3: part5 [nchunk][5][2C] = per-chunk sums for dbias (rows 0-2), dwseed (3), dwcoarse (4); gcoarse [B*Mc][3]
  *           (zero-filled here, accumulated atomically); sums [C][2] = reduced mode-2 partials (NULL: eval-mode BatchNorm)
- * nchunk = ceil(B*Mc*S / vnp_chunk_points()); S must divide vnp_chunk_points(). */
+ * nchunk = B*Mc / coarse_per_chunk; coarse_per_chunk divides Mc and coarse_per_chunk*S <= vnp_chunk_points() (0: vnp_chunk_points()/S):
+ * a chunk is coarse_per_chunk consecutive coarse points with their S dense points each and never straddles two samples. */
 int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* wseed, const float* wcoarse,
                    const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
                    float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
-                   float* part5, float* gcoarse);
+                   float* part5, float* gcoarse, int coarse_per_chunk);
 
 /* ---- small reductions -------------------------------------------------------------------------------------- */
 /* out[r] = sum_c X[r][c]*w[c] (+ add[((r/3)/add_group)*3 + r%3]) : final VNLinear(C->1) + point_feat (pcn.py:387) */

@@ -527,3 +527,38 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
             ops.STATS_IN_EPILOGUE = True
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-12)
+
+
+@pytest.mark.parametrize("B,Mc,S,C,batched,training", [(2, 64, 16, 256, False, True),      # one 1024-point chunk per sample
+                                                       (3, 96, 16, 128, True, True),       # Mc*S not a chunk multiple: 48 coarse points per chunk
+                                                       (2, 78, 16, 64, False, True),       # config-5-like Mc = 2*3*13: 39 per chunk
+                                                       (2, 40, 4, 72, True, False)])       # eval mode, C not a multiple of 64
+def test_fold_layer0_fused_equals_unfused(lib_built, B, Mc, S, C, batched, training):
+    """FoldingNet layer 0 with the (p | d) pre-activations recomputed inside each pass (ops.FoldBnLeakyFn / vnp_fold_fused) against the
+    materialising pair FoldFn + VNBnLeakyFn, for chunkings where a sample is not a whole number of 1024-point chunks: forward bit-identical
+    (same arithmetic per element; statistics merged from different chunk sizes agree to rounding), every gradient to 2e-5."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Mc)
+    rn = lambda *s: torch.randn(*s, generator=g).cuda()
+    bias0, ws0, wc0 = rn(B * 3, 2 * C), rn(2 * C), rn(2 * C)
+    seed0, coarse0 = rn(B if batched else 1, S, 3) * 0.3, rn(B, Mc, 3) * 0.5
+    gamma0, beta0 = rn(C).abs() + 0.5, rn(C) * 0.1
+    go = rn(B * Mc * S * 3, C)
+    res = {}
+    for fused in (True, False):
+        leaves = [x.clone().requires_grad_(True) for x in (bias0, ws0, wc0, coarse0, gamma0, beta0)]
+        bias, ws, wc, coarse, gamma, beta = leaves
+        rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+        if fused:
+            assert ops.FoldBnLeakyFn.coarse_per_chunk(Mc, S) * S <= 1024 and Mc % ops.FoldBnLeakyFn.coarse_per_chunk(Mc, S) == 0
+            out = ops.FoldBnLeakyFn.apply(bias, ws, wc, seed0, coarse, gamma, beta, rm, rv, training, 0.2)
+        else:
+            pd = ops.FoldFn.apply(bias, ws, wc, seed0, coarse)
+            out = ops.VNBnLeakyFn.apply(pd, True, gamma, beta, rm, rv, training, 0.2)
+        out.backward(go)
+        res[fused] = [out.detach(), rm, rv] + [x.grad for x in leaves]
+    names = ["out", "running_mean", "running_var", "g_bias", "g_wseed", "g_wcoarse", "g_coarse", "g_gamma", "g_beta"]
+    for n, a, b in zip(names, res[True], res[False]):
+        if not training and n in ("g_gamma", "g_beta"):
+            continue
+        assert relerr(a, b) < (2e-6 if n in ("out", "running_mean", "running_var") else 3e-5), (n, relerr(a, b))

@@ -788,6 +788,7 @@ struct VnpFoldArgs {
     const float* bias; int ldb;
     const float* wseed; const float* wcoarse; const float* seed; int seed_batched;
     const float* coarse; int Mc, S, C; long long ncoarse;      // ncoarse = B*Mc
+    int cpc;                              // coarse points per chunk (divides Mc: a chunk never straddles two samples)
     const float* mean; const float* rstd; const float* gamma; const float* beta; float ns;
     float* out; int ldo;                  // MODE 1
     const float* go; int ldgo;            // MODE 2, 3
@@ -810,7 +811,7 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     const int j = blockIdx.x * 64 + cx;
     const bool live = j < a.C;
     const int C = a.C, S = a.S;
-    const int cpc = VNP_CHUNK / S;                                 // coarse points per chunk
+    const int cpc = a.cpc;                                         // coarse points per chunk
     const long long cp0 = (long long)blockIdx.y * cpc;
     const long long cp1 = min(a.ncoarse, cp0 + cpc);
     float wsf = 0, wcf = 0, wsd = 0, wcd = 0, mu = 0, rs = 0, ga = 0, be = 0;
@@ -932,15 +933,18 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
 #undef FDIV
 
 // mode 0: statistics partials; 1: forward; 2: backward sums; 3: backward gradients (see ops.FoldBnLeakyFn).
-// partial: [nchunk][C][2]; part5: [nchunk][5][2C]; gcoarse [B*Mc][3] is zero-filled here in mode 3.  S must divide
-// vnp_chunk_points().
+// partial: [nchunk][C][2]; part5: [nchunk][5][2C] with nchunk = B*Mc / coarse_per_chunk; gcoarse [B*Mc][3] is zero-filled here in mode 3.
 extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* wseed, const float* wcoarse,
                               const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int C,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
                               float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
-                              float* part5, float* gcoarse)
+                              float* part5, float* gcoarse, int coarse_per_chunk)
 {
-    if (!bias || !wseed || !wcoarse || !seed || !coarse || B <= 0 || Mc <= 0 || S <= 0 || C <= 0 || VNP_CHUNK % S) return VNP_EINVAL;
+    if (!bias || !wseed || !wcoarse || !seed || !coarse || B <= 0 || Mc <= 0 || S <= 0 || C <= 0) return VNP_EINVAL;
+    // chunk = coarse_per_chunk coarse points (x S dense points): must divide Mc and hold at most vnp_chunk_points() dense points;
+    // 0 = vnp_chunk_points() / S (the historical layout)
+    const int cpc = coarse_per_chunk > 0 ? coarse_per_chunk : (VNP_CHUNK % S == 0 ? VNP_CHUNK / S : 0);
+    if (cpc <= 0 || Mc % cpc || (long long)cpc * S > VNP_CHUNK) return VNP_EINVAL;
     if (mode < 0 || mode > 3) return VNP_EINVAL;
     if (mode > 0 && (!mean || !rstd || !gamma || !beta)) return VNP_EINVAL;
     if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
@@ -953,8 +957,8 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
     a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
     a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo; a.partial = (float2*)partial;
     a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f; a.part5 = part5; a.gcoarse = gcoarse;
-    const long long P = (long long)B * Mc * S;
-    const int nchunk = vnp_cdiv(P, VNP_CHUNK);
+    a.cpc = cpc;
+    const int nchunk = vnp_cdiv((long long)B * Mc, cpc);
     if (nchunk > 65535) return VNP_EINVAL;
     dim3 grid(vnp_cdiv(C, 64), nchunk), block(256);
     if (mode == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<0>), grid, block, 0, st, a);

@@ -826,15 +826,18 @@ class FoldBnLeakyFn(Function):
         wseed, wcoarse = wseed.contiguous(), wcoarse.contiguous()
         dev = bias.device
         P = B * Mc * S
-        nch = _nchunk(P)
+        cpc = FoldBnLeakyFn.coarse_per_chunk(Mc, S)
+        if not cpc:
+            raise _lib.VnpError(f"FoldBnLeakyFn: grid^2 = {S} exceeds vnp_chunk_points()")
+        nch = B * Mc // cpc
         args = (ptr(bias), _ld(bias), ptr(wseed), ptr(wcoarse), ptr(seed), batched, ptr(coarse), B, Mc, S, C)
         if training:
             part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-            call("vnp_fold_fused", 0, *args, None, None, None, None, ns, None, 0, None, 0, ptr(part), None, 0, None, None)
+            call("vnp_fold_fused", 0, *args, None, None, None, None, ns, None, 0, None, 0, ptr(part), None, 0, None, None, cpc)
             mean = torch.empty(C, device=dev, dtype=torch.float32)
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_vn_bn_finalize", ptr(part), nch, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-                 BN_MOMENTUM, BN_EPS)
+            call("vnp_vn_bn_finalize_chunked", ptr(part), nch, cpc * S, C, P, ptr(mean), ptr(rstd), ptr(running_mean),
+                 ptr(running_var), BN_MOMENTUM, BN_EPS)
         else:
             mean = running_mean
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
@@ -842,39 +845,43 @@ class FoldBnLeakyFn(Function):
         out = torch.empty((P * 3, C), device=dev, dtype=torch.float32)
         _trace("fold_layer0_fused")
         call("vnp_fold_fused", 1, *args, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns, ptr(out), C, None, 0, None, None, 0,
-             None, None)
+             None, None, cpc)
         ctx.save_for_backward(bias, wseed, wcoarse, seed, coarse, gamma, beta, mean, rstd)
-        ctx.cfg = (B, Mc, S, C, batched, training, ns)
+        ctx.cfg = (B, Mc, S, C, batched, training, ns, cpc)
         return out
+
+    @staticmethod
+    def coarse_per_chunk(Mc, S):
+        """Coarse points per statistics chunk: the largest divisor of ``Mc`` whose S dense points each fit a chunk of
+        vnp_chunk_points() points, so that a chunk never straddles two samples (0: no such divisor, S too large)."""
+        cap = _lib.chunk_points() // S
+        for d in range(min(cap, Mc), 0, -1):
+            if Mc % d == 0:
+                return d
+        return 0
 
     @staticmethod
     @once_differentiable
     def backward(ctx, go):
         bias, wseed, wcoarse, seed, coarse, gamma, beta, mean, rstd = ctx.saved_tensors
-        B, Mc, S, C, batched, training, ns = ctx.cfg
+        B, Mc, S, C, batched, training, ns, cpc = ctx.cfg
         go = _rows(go)
         dev = go.device
         P = B * Mc * S
-        nch = _nchunk(P)
+        nch = B * Mc // cpc
         args = (ptr(bias), _ld(bias), ptr(wseed), ptr(wcoarse), ptr(seed), batched, ptr(coarse), B, Mc, S, C)
         bn = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
         part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-        call("vnp_fold_fused", 2, *args, *bn, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, None)
+        call("vnp_fold_fused", 2, *args, *bn, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, None, cpc)
         Ssum = reduce_rows(part.view(1, nch, 2 * C), 1, nch, 2 * C).view(C, 2)
         part5 = torch.empty((nch, 5, 2 * C), device=dev, dtype=torch.float32)
         gcoarse = torch.empty((B, Mc, 3), device=dev, dtype=torch.float32)
         call("vnp_fold_fused", 3, *args, *bn, None, 0, ptr(go), _ld(go), None, ptr(Ssum) if training else None, P,
-             ptr(part5), ptr(gcoarse))
+             ptr(part5), ptr(gcoarse), cpc)
         W = 2 * C
-        chunks_per_sample = (Mc * S) // _lib.chunk_points()
-        if chunks_per_sample >= 1 and (Mc * S) % _lib.chunk_points() == 0:
-            per_sample = reduce_rows(part5, B, chunks_per_sample, 5 * W)               # [B][5W]
-            gbias = per_sample[:, :3 * W].reshape(B * 3, W)
-            tot = reduce_rows(per_sample, 1, B, 5 * W)
-        else:
-            # small clouds: a chunk may straddle samples; split the chunk sums per sample on the host side is not possible,
-            # so this path is only taken when a sample is a whole number of chunks (callers fall back to FoldFn otherwise)
-            raise _lib.VnpError("FoldBnLeakyFn needs num_coarse*grid^2 to be a multiple of vnp_chunk_points()")
+        per_sample = reduce_rows(part5, B, Mc // cpc, 5 * W)                           # [B][5W]: a chunk lies inside one sample
+        gbias = per_sample[:, :3 * W].reshape(B * 3, W)
+        tot = reduce_rows(per_sample, 1, B, 5 * W)
         gws, gwc = tot[0, 3 * W:4 * W], tot[0, 4 * W:]
         return (gbias, gws, gwc, None, gcoarse if ctx.needs_input_grad[4] else None, Ssum[:, 1].contiguous(),
                 Ssum[:, 0].contiguous(), None, None, None, None)

@@ -135,9 +135,7 @@ class VN_FoldingNet(nn.Module):
         coarse = coarse.contiguous().float()
         bn = l0.batchnorm.bn
         l0.batchnorm._tick()
-        from . import _lib
-        chunk = _lib.chunk_points()
-        if (Mc * S) % chunk == 0 and chunk % S == 0:
+        if ops.FoldBnLeakyFn.coarse_per_chunk(Mc, S) >= min(Mc, 16):
             # fused layer 0: the (p | d) pre-activations are recomputed inside every pass instead of being stored
             f = ops.FoldBnLeakyFn.apply(bias, wseed, wcoarse, seed, coarse, bn.weight, bn.bias, bn.running_mean,
                                         bn.running_var, self.training, l0.negative_slope)
