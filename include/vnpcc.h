@@ -69,6 +69,19 @@ int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, int ldbias, int rows_per_group,
              int accumulate, int nsplit, float* ws);
+/* vnp_gemm given the operands' absolute maxima (opt-in fast path): amax_a / amax_b (both or neither) are device words holding the bit
+ * pattern of max |A| and max |B| over the WHOLE operand (vnp_absmax; any upper bound within a few binades works, an element ABOVE the
+ * word overflows to Inf / NaN).  Aligned shapes with K >= 64 then run on two fp16 planes of the power-of-two scaled operands and three
+ * MFMA products instead of three bf16 planes and six; the partial sum of every 32-wide K-tile is added to the running sum in fp32 with
+ * round-to-nearest.  Accuracy: operands are kept to 22-23 bits relative to themselves down to 2^-16 of the operand's largest element
+ * and to 2^-39 of that element below — normwise at or below an fp32 FMA-chain sgemm against fp64 for K >= 64, not element by element.
+ * Other shapes, and null words: exactly vnp_gemm. */
+int vnp_gemm_ex(hipStream_t st, int op_a, int op_b, int M, int N, int K,
+                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, int ldbias, int rows_per_group,
+                int accumulate, int nsplit, float* ws, const unsigned* amax_a, const unsigned* amax_b);
+/* out[0] = bit pattern of max |x[r][c]| over rows x cols (x 16-byte aligned, cols % 4 == 0, ld % 4 == 0); NaN ranks above Inf */
+int vnp_absmax(hipStream_t st, const float* x, long long ld, long long rows, int cols, unsigned* out);
 
 /* nbatch independent products C_i = op(A_i) op(B_i), element strides bsa/bsb/bsc (attention: one per (sample, head)) */
 /* vnp_gemm (NT, optional per-sample VN bias) that also returns, for the first stats_cols columns, the per-1024-point Welford
@@ -78,6 +91,10 @@ int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
 long long vnp_gemm_vn_stats_ws_floats(long long M, int stats_cols);
 int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                       const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws);
+/* the same with the operands' absolute maxima (see vnp_gemm_ex) */
+int vnp_gemm_vn_stats_ex(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                      const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws,
+                         const unsigned* amax_a, const unsigned* amax_b);
 int vnp_gemm_batched(hipStream_t st, int op_a, int op_b, int M, int N, int K,
                      const float* A, int lda, long long bsa, const float* B, int ldb, long long bsb,
                      float* C, int ldc, long long bsc, int nbatch, int accumulate);

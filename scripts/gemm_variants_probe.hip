@@ -7,10 +7,12 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-template <int BM, bool AKC, bool BKC, int EPI>
+static unsigned* g_amax = nullptr;      // [2]: bits of max |A|, max |B| (PREC >= 1)
+template <int BM, bool AKC, bool BKC, int EPI, int PREC = 0>
 static float run(const char* name, int M, int N, int K, int nsplit, const float* A, const float* B, float* C, float* ws)
 {
     VnpGemmArgs p{};
+    p.amax_a = g_amax; p.amax_b = g_amax + 1;
     p.A = A; p.B = B; p.M = M; p.N = N; p.K = K;
     p.lda = AKC ? K : M; p.ldb = BKC ? K : N; p.ldc = N; p.rows_per_group = 1; p.col_group = 8;
     p.tiles_per_split = K / 32 / nsplit; p.nsplit = nsplit; p.nbatch = 1; p.slab = (long long)M * N;
@@ -18,10 +20,10 @@ static float run(const char* name, int M, int N, int K, int nsplit, const float*
     const long long items = (long long)(M / BM) * (N / 128) * nsplit;
     dim3 grid((unsigned)(items < 512 ? items : 512)), block(256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true, 0, EPI>), grid, block, 0, 0, p);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true, 0, EPI, PREC>), grid, block, 0, 0, p);
     hipEventRecord(e0);
     const int it = 20;
-    for (int i = 0; i < it; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true, 0, EPI>), grid, block, 0, 0, p);
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM, 128, AKC, BKC, true, 0, EPI, PREC>), grid, block, 0, 0, p);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
     printf("%-28s M=%8d N=%5d K=%8d split=%3d  %8.3f ms  %7.1f TF/s fp32-equivalent\n", name, M, N, K, nsplit, ms, 2.0 * M * N * K / ms * 1e-9);
@@ -39,18 +41,26 @@ int main()
     CK(hipMemcpy(A, h.data(), nA * 4, hipMemcpyHostToDevice));
     for (auto& v : h) v = ((float)(rand() & 0xffffff) / 8388608.f - 1.f) * 0.05f;
     CK(hipMemcpy(B, h.data(), nA * 4, hipMemcpyHostToDevice));
+    const unsigned am[2] = {0x3f800000u, 0x3d4ccccdu};            // 1.0, 0.05
+    CK(hipMalloc(&g_amax, 8)); CK(hipMemcpy(g_amax, am, 8, hipMemcpyHostToDevice));
 #ifdef VNP_EXPERIMENT_CHEAP_SPLIT
     printf("== conversion replaced by 3 bit-ops per pair (wrong results) ==\n");
 #else
     printf("== production kernel ==\n");
 #endif
-    float t = 0;
-    t += run<192, true, true, 0>("enc fwd NT [p|d]", 196608, 2048, 512, 1, A, B, C, ws);
-    t += run<192, true, true, 0>("dec fwd NT [p|d]", 1572864, 512, 256, 1, A, B, C, ws);
-    t += run<192, true, false, 0>("enc dgrad NN", 196608, 512, 2048, 1, A, B, C, ws);
-    t += run<192, true, false, 0>("dec dgrad NN", 1572864, 256, 512, 1, A, B, C, ws);
-    t += run<128, false, false, 0>("enc wgrad TN", 2048, 512, 196608, 16, A, B, C, ws);
-    t += run<128, false, false, 0>("dec wgrad TN", 512, 256, 1572864, 128, A, B, C, ws);
-    printf("sum %.3f ms\n", t);
+#define ALL(PREC, label)                                                                                              \
+    do {                                                                                                              \
+        float t = 0;                                                                                                  \
+        printf("-- %s --\n", label);                                                                                  \
+        t += run<192, true, true, 0, PREC>("enc fwd NT [p|d]", 196608, 2048, 512, 1, A, B, C, ws);                    \
+        t += run<192, true, true, 0, PREC>("dec fwd NT [p|d]", 1572864, 512, 256, 1, A, B, C, ws);                    \
+        t += run<192, true, false, 0, PREC>("enc dgrad NN", 196608, 512, 2048, 1, A, B, C, ws);                       \
+        t += run<192, true, false, 0, PREC>("dec dgrad NN", 1572864, 256, 512, 1, A, B, C, ws);                       \
+        t += run<128, false, false, 0, PREC>("enc wgrad TN", 2048, 512, 196608, 16, A, B, C, ws);                     \
+        t += run<128, false, false, 0, PREC>("dec wgrad TN", 512, 256, 1572864, 128, A, B, C, ws);                    \
+        printf("sum %.3f ms\n", t);                                                                                   \
+    } while (0)
+    ALL(0, "three bf16 planes, six products");
+    ALL(1, "two fp16 planes, three products, per-K-tile partial sums added on the VALU");
     return 0;
 }

@@ -209,3 +209,98 @@ def test_degenerate_shapes_take_streaming_kernels():
     G, x = _mk(60000, 200, seed=47), _mk(60000, 1, seed=48)
     assert relerr(ops.gemm(G, x, op_a=1, op_b=1), G.double().t() @ x.double()) < 1e-5          # [200, 1]
     assert relerr(ops.gemm(x, G, op_a=1, op_b=1), x.double().t() @ G.double()) < 1e-5          # [1, 200]
+
+
+def _gemm_h2(A, B, op_a, op_b, nsplit=None):
+    """ops.gemm forced onto the two-plane path (whatever the size threshold says), asserting that it was taken."""
+    from vn_pointcloudcompletion_amd import ops
+    keep, ops.GEMM_FP16X2, ops.GEMM_FP16X2_MIN_FLOP, ops.TRACE = (ops.GEMM_FP16X2, ops.GEMM_FP16X2_MIN_FLOP), True, 0.0, {}
+    try:
+        C = ops.gemm(A, B, op_a=op_a, op_b=op_b, nsplit=nsplit)
+        assert ops.TRACE.get("gemm_fp16x2", 0) == 1, ops.TRACE
+    finally:
+        (ops.GEMM_FP16X2, ops.GEMM_FP16X2_MIN_FLOP), ops.TRACE = keep, None
+    return C
+
+
+def _normwise_err(C, ref, A, B, op_a, op_b):
+    """(rms, max) of (C - ref) / (|A row|_2 |B row|_2): the error in units of what a normwise bound is proportional to."""
+    Ad, Bd = A.double(), B.double()
+    na = (Ad * Ad).sum(0 if op_a else 1).sqrt()
+    nb = (Bd * Bd).sum(0 if op_b else 1).sqrt()
+    e = (C.double() - ref).abs() / (na[:, None] * nb[None, :]).clamp_min(1e-300)
+    return (e ** 2).mean().sqrt().item(), e.max().item()
+
+
+@pytest.mark.parametrize("dist", sorted(_DISTRIBUTIONS))
+@pytest.mark.parametrize("layout,M,N,K", [("nt", 384, 256, 2048), ("nt", 768, 512, 256), ("nn", 384, 256, 512), ("tn", 256, 128, 24576),
+                                          ("nt", 192, 128, 64)])
+def test_fp16x2_is_sgemm_grade(_mode, dist, layout, M, N, K):
+    """The opt-in two-fp16-plane, three-product GEMM (vnp_gemm_ex) against fp64, next to torch's CPU sgemm — the arithmetic of the
+    reference's CPU path — on the same operands, in the normwise measure |C - ref| / (|A row|_2 |B row|_2): rms and worst element within
+    1.5x of the sgemm's (measured: 0.4-0.9x for zero-mean data, 1.3-1.4x for one-signed data at K = 2048); zero-mean, one-signed, 2^40-wide,
+    tiny (1e-18) and huge (1e15) data; every operand layout.  (Element by element — relative to sum |a||b| — the 2^40-wide data does worse:
+    elements more than 2^16 below the operand's maximum keep absolute, not relative, accuracy.  That is why the mode is opt-in.)"""
+    from vn_pointcloudcompletion_amd import ops
+    if _mode != "split":
+        pytest.skip("the two-plane path belongs to the default GEMM mode")
+    g = torch.Generator().manual_seed(sum(map(ord, dist + layout)) + K)
+    f = _DISTRIBUTIONS[dist]
+    op_a, op_b = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[layout]
+    A = f(g, *((K, M) if op_a else (M, K)))
+    B = f(g, *((K, N) if op_b else (N, K)))
+    ref = (A.double().t() if op_a else A.double()) @ (B.double() if op_b else B.double().t())
+    cpu = (A.t() if op_a else A) @ (B if op_b else B.t())                                  # torch CPU fp32 matmul
+    Ad, Bd = A.cuda(), B.cuda()
+    h2 = _gemm_h2(Ad, Bd, op_a, op_b, nsplit=1 if layout != "tn" else None)
+    r_cpu, m_cpu = _normwise_err(cpu, ref, A, B, op_a, op_b)
+    r_h2, m_h2 = _normwise_err(h2.cpu(), ref, A, B, op_a, op_b)
+    msg = dict(rms=(r_cpu, r_h2), max=(m_cpu, m_h2))
+    assert r_h2 <= 1.5 * r_cpu + 1e-12, msg
+    assert m_h2 <= 1.5 * m_cpu + 1e-11, msg
+    if dist != "wide":
+        assert _err_vs_fp64(h2, ref.cuda(), Ad, Bd, op_a, op_b) < 2e-6, msg
+
+
+def test_fp16x2_scaling_edge_cases(_mode):
+    """Operand maxima at exact powers of two and just below (the scaled maximum sits at 2^14 resp. just under 2^15), all-zero operands,
+    one huge outlier among small values (they drop to absolute accuracy 2^-39 of the outlier), and Inf / NaN operands (NaN out, no hang)."""
+    from vn_pointcloudcompletion_amd import ops
+    if _mode != "split":
+        pytest.skip("the two-plane path belongs to the default GEMM mode")
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 192, 128, 128
+    base_a, base_b = torch.rand(M, K, generator=g) * 2 - 1, torch.rand(N, K, generator=g) * 2 - 1
+    for top in (1.0, 2.0, 0.5, 1.9999999, 65504.0, 3.0e38, 1.2e-38):
+        A = base_a.clone() * (top / (4 if top < 1e30 else 4096)); A[5, 7] = top        # (the largest case must not overflow fp32 itself)
+        B = base_b.clone(); B[3, 9] = -top if top < 1e30 else -1.0
+        ref = A.double() @ B.double().t()
+        C = _gemm_h2(A.cuda(), B.cuda(), 0, 0)
+        assert torch.isfinite(C).all(), top
+        assert _err_vs_fp64(C, ref.cuda(), A.cuda(), B.cuda(), 0, 0) < 2e-6, top
+    Z = torch.zeros(M, K).cuda()
+    assert torch.equal(_gemm_h2(Z, base_b.cuda(), 0, 0), torch.zeros(M, N).cuda())
+    A = base_a.clone() * 1e-3; A[0, 0] = 1e6                              # outlier 2^30 above the rest
+    ref = A.double() @ base_b.double().t()
+    C = _gemm_h2(A.cuda(), base_b.cuda(), 0, 0)
+    err = (C.double().cpu() - ref).abs()
+    assert err[0].max() < 2.0 ** -21 * 1e6                                # the outlier's row: relative to the outlier
+    assert err[1:].max() < K * 2.0 ** -39 * 1e6                           # the other rows: K terms, each to 2^-39 of the OPERAND's maximum ...
+    assert err[1:].max() > 2.0 ** -24 * ref[1:].abs().max()               # ... which is far from fp32-grade relative to the rows themselves
+    for bad in (float("inf"), float("nan")):
+        A = base_a.clone(); A[1, 1] = bad
+        C = _gemm_h2(A.cuda(), base_b.cuda(), 0, 0)
+        assert not torch.isfinite(C[1]).all()
+        assert torch.isfinite(C[2:]).all() or bad != bad or True                  # other rows: unspecified (the scale came from a poisoned word)
+
+
+def test_absmax_word(_mode):
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1000, 36, generator=g) * 3).cuda()
+    x[777, 5] = -123.456
+    w = ops.amax_word(x)
+    assert w.view(torch.float32).item() == pytest.approx(123.456, rel=1e-7) and w.view(torch.float32).item() == x.abs().max().item()
+    v = x[:, 4:24]                                                     # strided view: ld 36, 20 columns
+    assert ops.amax_word(v).view(torch.float32).item() == v.abs().max().item()
+    assert ops.amax_word(x[:, 1:5]) is None                            # misaligned: callers keep the six-product path

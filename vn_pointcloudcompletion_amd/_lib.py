@@ -67,6 +67,9 @@ _SIGNATURES = {
     "vnp_emd_matchcost_bwd": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_gemm": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "vnp_gemm_vn_stats": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp],
+    "vnp_gemm_vn_stats_ex": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "vnp_gemm_ex": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "vnp_absmax": [_vp, _ll, _ll, _i, _vp],
     "vnp_gemm_batched": [_i, _i, _i, _i, _i, _vp, _i, _ll, _vp, _i, _ll, _vp, _i, _ll, _i, _i],
     "vnp_vn_layernorm_fwd": [_vp, _i, _ll, _i, _vp, _vp, _vp, _i, _vp],
     "vnp_vn_layernorm_bwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],

@@ -147,7 +147,8 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
                          const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          const float* bias, int ldbias, int rows_per_group,
                          int accumulate, int nsplit, float* ws,
-                         int nbatch, long long bsa, long long bsb, long long bsc)
+                         int nbatch, long long bsa, long long bsb, long long bsc,
+                         const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr)
 {
     if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return VNP_EINVAL;
     if (bias && rows_per_group <= 0) return VNP_EINVAL;
@@ -215,11 +216,15 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     const bool fast = aligned && (M % bm == 0) && (N % 128 == 0) && (K % BK == 0) && K > 0;
     // resident workgroups per CU: 2 for the 192-row tiles (~240 VGPRs), 3 for the aligned 128-row weight-gradient kernel (151)
     const bool split = vnp_gemm_get_mode() == 0;
+    // two fp16 planes / three products when the caller supplies max |A| and max |B| (vnp_gemm_ex); aligned shapes with K >= 64 only
+    const bool h2 = split && fast && amax_a && amax_b && K >= 64;
+    p.amax_a = amax_a; p.amax_b = amax_b;
     const long long cap = (long long)vnp_num_cus() * ((!split && bm == 128 && fast && op_b == 1) ? 3 : 2);
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
 #define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                                    \
     do {                                                                                                                \
-        if (split) {                                                                                                    \
+        if (h2) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true, 0, 0, 1>), grid, block, 0, stream, p); \
+        else if (split) {                                                                                               \
             if (fast) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true>), grid, block, 0, stream, p);  \
             else      hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, false>), grid, block, 0, stream, p); \
         } else {                                                                                                        \
@@ -747,8 +752,10 @@ extern "C" long long vnp_gemm_vn_stats_ws_floats(long long M, int stats_cols) { 
 // (mean, M2) of n = |row triple| + eps per 1024 points in part1024 [M/3072][stats_cols][2] — what vnp_vn_norm_stats would
 // have produced from C, without reading C back.  ws: vnp_gemm_vn_stats_ws_floats(M, stats_cols) floats.
 // VNP_EINVAL unless split GEMM mode, M % 3072 == 0, N % 128 == 0, K % 32 == 0, stats_cols % 64 == 0, 16-byte alignment.
-extern "C" int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                                 const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws)
+// amax_a / amax_b (both or neither): device words with the bit pattern of max |A|, max |B| (vnp_absmax) -> two fp16 planes, three products
+extern "C" int vnp_gemm_vn_stats_ex(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                    const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws,
+                                    const unsigned* amax_a, const unsigned* amax_b)
 {
     if (!A || !B || !C || !part1024 || !ws || M <= 0 || N <= 0 || K <= 0 || stats_cols <= 0) return VNP_EINVAL;
     if (vnp_gemm_get_mode() != 0 || M % 3072 || N % 128 || K % 32 || stats_cols % 64 || stats_cols > N || lda % 4 || ldb % 4 ||
@@ -763,9 +770,49 @@ extern "C" int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const floa
     const long long items = (long long)(M / 192) * (N / 128);
     const long long cap = (long long)vnp_num_cus() * 2;
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
-    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
+    if ((amax_a == nullptr) != (amax_b == nullptr)) return VNP_EINVAL;
+    p.amax_a = amax_a; p.amax_b = amax_b;
+    if (amax_a && K >= 64) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
     hipLaunchKernelGGL(vnp_stats_merge32_kernel, dim3(vnp_cdiv(stats_cols, 64), M / 3072), dim3(256), 0, st,
                        (const float2*)ws, stats_cols, (float2*)part1024);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_gemm_vn_stats(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                 const float* bias, int ldbias, int rows_per_group, int stats_cols, float* part1024, float* ws)
+{
+    return vnp_gemm_vn_stats_ex(st, M, N, K, A, lda, B, ldb, C, ldc, bias, ldbias, rows_per_group, stats_cols, part1024, ws, nullptr, nullptr);
+}
+
+// ---- max |x| of a matrix, as the bit pattern of the fp32 value (non-negative floats order like unsigned integers; a NaN ranks above
+// Inf, so a poisoned operand is visible in the word).  out is overwritten.
+__global__ void __launch_bounds__(256) vnp_absmax_kernel(const float* __restrict__ x, long long ld, long long rows, int cols4, unsigned* __restrict__ out)
+{
+    unsigned m = 0;
+    const long long total = rows * cols4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols4; const int c = (int)(i - r * cols4);
+        const vnp_f4 v = __builtin_nontemporal_load((const vnp_f4*)(x + r * ld) + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu; m = b > m ? b : m; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// out[0] = bits of max |x[r][c]| over rows x cols (cols % 4 == 0, ld % 4 == 0, x 16-byte aligned; else VNP_EINVAL)
+extern "C" int vnp_absmax(hipStream_t st, const float* x, long long ld, long long rows, int cols, unsigned* out)
+{
+    if (!x || !out || rows <= 0 || cols <= 0 || cols % 4 || ld % 4 || ld < cols || (uintptr_t)x % 16) return VNP_EINVAL;
+    hipError_t e = hipMemsetAsync(out, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    const long long total = rows * (cols / 4);
+    long long blocks = (total + 255) / 256;
+    const long long cap = (long long)vnp_num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(vnp_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, rows, cols / 4, out);
     return vnp_last_error();
 }
 
@@ -776,6 +823,20 @@ extern "C" int vnp_gemm(hipStream_t stream, int op_a, int op_b, int M, int N, in
 {
     return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias, ldbias, rows_per_group,
                          accumulate, nsplit, ws, 1, 0, 0, 0);
+}
+
+// vnp_gemm with the operands' absolute maxima (device words: bit pattern of max |A| and of max |B| over the WHOLE operand, from
+// vnp_absmax or from the kernel that produced the operand): aligned shapes with K >= 64 in the default GEMM mode then run with two fp16
+// planes and three MFMA products instead of three bf16 planes and six (gemm_split_kernel.h, PREC = 1), every other shape as vnp_gemm does.
+// The words must be upper bounds of the operands' magnitudes: an element above the word overflows fp16 and gives Inf / NaN.
+extern "C" int vnp_gemm_ex(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
+                           const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                           const float* bias, int ldbias, int rows_per_group,
+                           int accumulate, int nsplit, float* ws, const unsigned* amax_a, const unsigned* amax_b)
+{
+    if ((amax_a == nullptr) != (amax_b == nullptr)) return VNP_EINVAL;
+    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias, ldbias, rows_per_group,
+                         accumulate, nsplit, ws, 1, 0, 0, 0, amax_a, amax_b);
 }
 
 // nbatch independent products C_i = op(A_i) op(B_i) with element strides bsa / bsb / bsc (attention: one per (sample, head))

@@ -29,6 +29,9 @@ struct VnpGemmArgs {
     float2* stats_part; int stats_cols;
     int col_group;                       // split kernel: walk the column tiles in groups of this many (0 = all): keeps the B
                                          // panels of a group L2-resident while the row panels stream past
+    // PREC = 1 (two fp16 planes, three products): device words holding the bit pattern of max |A|, max |B| over the whole operand
+    // (vnp_absmax, or emitted by the kernel that produced the operand); the kernel derives its power-of-two operand scales from them
+    const unsigned* amax_a; const unsigned* amax_b;
 };
 
 template <int R, int BK, bool KC, int NV>

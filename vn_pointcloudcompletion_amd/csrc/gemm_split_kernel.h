@@ -11,6 +11,25 @@
 // Limits (documented, tested): an operand element that is Inf/NaN gives NaN (Inf - Inf in the remainder); |x| above
 // bf16's largest finite value 3.39e38 rounds to Inf likewise; fp32 denormal operands lose their low planes.
 //
+// PREC = 1 (opt-in, vnp_gemm_ex): TWO fp16 planes and THREE products (l h), (h l), (h h) on v_mfma_f32_16x16x32_f16.  fp16 keeps 11
+// significant bits, so x s = h + l holds to 22-23 bits: with h = RN16(x s) the remainder x s - h is an exact fp32 number of at most 12
+// significant bits and l = RN16(x s - h) drops at most its last one: |x s - h - l| <= 2^-23 |x s| (zero for three operands in four);
+// the dropped product obeys |l l'| <= 2^-22 |x y|.  fp16 has 5 exponent bits, so each operand is scaled by a power of two
+// s = 2^(14 - floor(log2 max|x|)) (exact; max |x| over the whole operand comes in as a device word, VnpGemmArgs::amax_a / amax_b) and
+// the accumulators are multiplied by 1 / (s_a s_b) (exact) before the epilogue: the largest element lands in [2^14, 2^15), elements
+// down to 2^-16 of it keep the full 22-23 bits, smaller ones an ABSOLUTE accuracy of 2^-39 max|x| through fp16's subnormals (the MFMA
+// honours them: profiles/r02_mfma_f16_subnormals.txt) — so the result is accurate NORMWISE (relative to |A row| |B row|), not
+// element by element like the three-plane form.
+// The matrix pipe aligns every product to the largest exponent among the addends (C included) and cuts it 2^-26 below
+// (scripts/mfma_round_probe.hip, profiles/r02_mfma_rounding.txt).  A bf16 product has 16 bits and never reaches the cut; an fp16
+// product has 22 and, accumulated onto a running sum, loses low bits with a negative bias that grows along the chain (measured: 2-4x
+// an sgemm's error at K = 2048).  So the three products of a K-tile start from ZERO accumulators and their sum joins the running sum
+// through a VALU add (round to nearest): measured against fp64 the result is then at or below torch's CPU sgemm on the same operands
+// in the rms normwise measure for K >= 64 (tests/test_gpu_gemm.py::test_fp16x2_is_sgemm_grade).
+// Cost: half the MFMA work, two planes through LDS, 6 conversion ops per pair instead of 11, plus 96 VALU adds per K-tile: 12.9 -> 10.7 ms
+// over the six big GEMMs of the step (9.2 with one accumulation chain, which is not accurate enough).  NOT the default: operand
+// precision is narrowed (22-23 bits), and the two absmax passes per GEMM give the gain back unless producers emit the maxima.
+//
 // Structure = vnp_gemm_kernel's: persistent 256-thread workgroups (4 waves, 2(M) x 2(N)), 192x128x32 or 128x128x32
 // tiles, global -> registers -> LDS with the next K-tile in flight during the MFMAs.  The split happens once per loaded
 // element on the way into LDS (11 VALU ops per pair of elements); LDS holds the three bf16 planes of both operands as
@@ -60,6 +79,25 @@ __device__ __forceinline__ void vnp_split_pair(float x0, float x1, unsigned& H, 
     const float s0 = r0 - __uint_as_float(M << 16);
     const float s1 = r1 - __uint_as_float(M & 0xffff0000u);
     L = __builtin_bit_cast(unsigned, __builtin_convertvector(vnp_f2{s0, s1}, vnp_bf2));
+}
+
+// (x0, x1) * s -> packed fp16 pairs H, L with x s = h + l to 2^-23 relative (see PREC = 1 above); s is a power of two
+__device__ __forceinline__ void vnp_split_pair_h2(float x0, float x1, float s, unsigned& H, unsigned& L)
+{
+    const float y0 = x0 * s, y1 = x1 * s;
+    const vnp_h2 h = __builtin_convertvector(vnp_f2{y0, y1}, vnp_h2);                           // v_cvt_pk_f16_f32 (RNE)
+    H = __builtin_bit_cast(unsigned, h);
+    L = vnp_pack_f16(y0 - (float)h[0], y1 - (float)h[1]);
+}
+
+// operand scale of the PREC = 1 split from the bit pattern of max |x|: s = 2^(14 - floor(log2 max)), inv = 1 / s; both stay normal
+// fp32 numbers for every input word (zero, subnormal, Inf and NaN words included)
+__device__ __forceinline__ void vnp_h2_scale(unsigned amax_bits, float& s, float& inv)
+{
+    int es = 268 - (int)((amax_bits >> 23) & 0xffu);
+    es = es < 1 ? 1 : es > 253 ? 253 : es;
+    s = __uint_as_float((unsigned)es << 23);
+    inv = __uint_as_float((unsigned)(254 - es) << 23);
 }
 
 // byte offset of (row, 16-byte slot q) inside one plane of R rows.  A 16-lane group covers all 64 banks when its 16-byte
@@ -123,14 +161,27 @@ __device__ __forceinline__ void vnp_split_load_generic(vnp_f4 (&reg)[NV], const 
 // fp32 registers -> packed bf16 plane registers: pl[u][plane] holds 4 consecutive k of one row (u = float4 index j for a
 // K-contiguous operand, row-in-block e for a row-contiguous one, whose 4(k) x 4(row) block is transposed here)
 template <bool KC, int NV, int NPL = 3, bool F16 = false>
-__device__ __forceinline__ void vnp_split_convert(const vnp_f4 (&reg)[NV], vnp_u2 (&pl)[NV][3])
+__device__ __forceinline__ void vnp_split_convert(const vnp_f4 (&reg)[NV], vnp_u2 (&pl)[NV][3], float scale = 1.f)
 {
     static_assert(KC || NV == 4, "row-contiguous operands: 4 k-rows x 4 rows per thread");
-    static_assert(!F16 || (KC && NPL == 1), "the fp16 screening pass stages one plane of K-contiguous operands");
+    static_assert(!F16 || NPL == 2 || (KC && NPL == 1), "fp16: one plane (screening pass, K-contiguous operands) or two (PREC = 1)");
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-        if (F16) {                                  // one fp16 plane: the single-product screening pass
+        if (F16 && NPL == 1) {                      // one fp16 plane: the single-product screening pass
             pl[u][0] = vnp_u2{vnp_pack_f16(reg[u][0], reg[u][1]), vnp_pack_f16(reg[u][2], reg[u][3])};
+            continue;
+        }
+        if (F16) {                                  // two fp16 planes of the scaled operand (PREC = 1)
+            unsigned h0, l0, h1, l1;
+            if (KC) {
+                vnp_split_pair_h2(reg[u][0], reg[u][1], scale, h0, l0);
+                vnp_split_pair_h2(reg[u][2], reg[u][3], scale, h1, l1);
+            } else {
+                vnp_split_pair_h2(reg[0][u], reg[1][u], scale, h0, l0);
+                vnp_split_pair_h2(reg[2][u], reg[3][u], scale, h1, l1);
+            }
+            pl[u][0] = vnp_u2{h0, h1};
+            pl[u][1] = vnp_u2{l0, l1};
             continue;
         }
         unsigned h0, m0, l0, h1, m1, l1;
@@ -164,7 +215,7 @@ __device__ __forceinline__ void vnp_split_write(const vnp_u2 (&pl)[NV][3], char*
         for (int e = 0; e < 4; ++e) {
             char* d = S + vnp_split_row_off<R, false>(r4 + e, kq >> 1) + (kq & 1) * 8;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) *(vnp_u2*)(d + q * R * 64) = pl[e][q];
+            for (int q = 0; q < NPL; ++q) *(vnp_u2*)(d + q * R * 64) = pl[e][q];
         }
     }
 }
@@ -176,9 +227,10 @@ __device__ __forceinline__ void vnp_split_write(const vnp_u2 (&pl)[NV][3], char*
 // point (16 i3 + r) into MFMA row-tile 3 i3 + t, row r: every lane then holds whole 3-vectors of x and d for 8 points x 2
 // channels, forms <x, d> in registers and reduces the arg-max over the wave's 32 points.  Neither x nor d is ever written
 // (EPI = 5: the same, but x IS stored to C [M, N/2] for the tensor's other consumer).
-template <int BM, int BN, bool AKC, bool BKC, bool FAST, int VAR = 0, int EPI = 0>
+template <int BM, int BN, bool AKC, bool BKC, bool FAST, int VAR = 0, int EPI = 0, int PREC = 0>
 __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArgs p)
 {
+    static_assert(PREC == 0 || (FAST && (EPI == 0 || EPI == 2)), "PREC = 1: aligned shapes, plain or BatchNorm-statistics epilogue");
     constexpr int BK = 32;
     constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave: (BM/2)/16 x (BN/2)/16
     constexpr int AV = BM * BK / 4 / 256, BV = BN * BK / 4 / 256;
@@ -204,9 +256,11 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     static_assert(EPI == 0 || (BM == 192 && BN == 128 && AKC && BKC && FAST), "the VN epilogues need the aligned 192x128 NT kernel");
     // EPI = 3: bf16 screening pass, products (m h), (h m), (h h): the l plane is never formed, staged or read.
     // EPI = 4: fp16 screening pass: ONE plane (fp16, 11 significant bits) and ONE product per operand pair.
-    constexpr bool F16 = EPI == 4;
-    constexpr int NPL = EPI == 3 ? 2 : EPI == 4 ? 1 : 3;          // planes staged through LDS
-    constexpr int T0 = EPI == 3 ? 3 : EPI == 4 ? 5 : 0;           // first of the six products issued
+    constexpr bool F16 = EPI == 4 || PREC == 1;
+    constexpr int NPL = (EPI == 3 || PREC == 1) ? 2 : EPI == 4 ? 1 : 3;          // planes staged through LDS
+    constexpr int T0 = (EPI == 3 || PREC == 1) ? 3 : EPI == 4 ? 5 : 0;           // first of the six products issued
+    float sca = 1.f, scb = 1.f, isa = 1.f, isb = 1.f;              // PREC = 1: operand scales and their inverses (powers of two)
+    if (PREC == 1) { vnp_h2_scale(*p.amax_a, sca, isa); vnp_h2_scale(*p.amax_b, scb, isb); }
     if (p.pred && *p.pred == 0) return;            // predicated launch (wave-uniform)
     int perm_off[AV];                       // EPI >= 1: element offset of the global row that LDS row tid/8 + 32 j holds
     if (EPI >= 1) {
@@ -253,8 +307,8 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     };
     vnp_u2 pa[AV][3], pb[BV][3];
     auto convert = [&]() {
-        vnp_split_convert<AKC, AV, NPL, F16>(ra, pa);
-        vnp_split_convert<BKC, BV, NPL, F16>(rb, pb);
+        vnp_split_convert<AKC, AV, NPL, F16>(ra, pa, sca);
+        vnp_split_convert<BKC, BV, NPL, F16>(rb, pb, scb);
     };
     auto write = [&]() {
         vnp_split_write<BM, AKC, AV, NPL>(pa, As, tid);
@@ -315,6 +369,23 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
                         a[pl] = __builtin_bit_cast(vnp_bf8, *(const vnp_u4*)(As + pl * APL + a_rd[i]));
+                    if (PREC == 1) {
+                        // products (l h), (h l), (h h) of this K-tile from ZERO accumulators; their sum joins acc through a VALU add (see PREC = 1 above)
+                        vnp_f4 tq[TN];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            tq[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vnp_h8, a[1]), __builtin_bit_cast(vnp_h8, b[j][0]),
+                                                                           vnp_f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            tq[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vnp_h8, a[0]), __builtin_bit_cast(vnp_h8, b[j][1]), tq[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            tq[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vnp_h8, a[0]), __builtin_bit_cast(vnp_h8, b[j][0]), tq[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] += tq[j];
+                        continue;
+                    }
 #pragma unroll
                     for (int t = T0; t < 6; ++t)
 #pragma unroll
@@ -335,6 +406,16 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
             }
         }
 
+        if (PREC == 1) {                      // undo the operand scales (exact: powers of two)
+            const float inv = isa * isb;
+            const bool one = inv >= 1e-30f && inv <= 1e30f;          // the product itself may leave fp32's normal range
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] = one ? acc[i][j][e] * inv : (acc[i][j][e] * isa) * isb;
+        }
         if (EPI == 1 || EPI == 5) {
             // acc[3 i3 + t][j][e]: component t of wave-local point 16 i3 + 4 lq + e; j = 0, 1: x channels, j = 2, 3: d channels
             const int pt0 = m0 / 3 + wm * 32;                         // first point of this wave (global point index)

@@ -40,6 +40,11 @@ POOL_SCREEN_PASS = _os.environ.get("VNP_POOL_SCREEN_PASS", "fp16")
 # BatchNorm + leaky backward in two read-heavy passes (sums, then final gradients) instead of bwd1 -> reduce -> bwd2, which writes
 # dL/dq and reads it back (VNP_BN_BWD_TWO_PASS=0 keeps that form); same arithmetic term for term
 BN_BWD_TWO_PASS = _os.environ.get("VNP_BN_BWD_TWO_PASS", "1") != "0"
+# Opt-in (VNP_GEMM_FP16X2=1): large aligned GEMMs (K >= 64) on two fp16 planes of the power-of-two scaled operands and three MFMA products
+# (vnp_gemm_ex; normwise error against fp64 at or below an fp32 sgemm's) instead of three bf16 planes and six products.  Off by default:
+# operand precision is narrowed to 22-23 bits, and the absmax pass over each operand costs what the GEMM saves.
+GEMM_FP16X2 = _os.environ.get("VNP_GEMM_FP16X2", "0") == "1"
+GEMM_FP16X2_MIN_FLOP = 2.0e10
 # tests set this to a list to receive the screened pool's diagnostics tensor (int32 [3]: candidates, fallback flag, capacity)
 POOL_SCREEN_STATS = None
 # If the screened search had to fall back (candidate list overflow, non-finite bounds) the bracketing pass was wasted work.  The flag of
@@ -117,8 +122,44 @@ def _chunk_pc(P: int, C: int):
     return c, (P + c - 1) // c
 
 
-def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumulate=False, nsplit=None):
-    """C = op(A) op(B) (+ per-sample bias).  See vnp_gemm in include/vnpcc.h."""
+def set_amax(t, word):
+    """Attach the device word holding the bits of max |t| (written by the kernel that produced ``t``) to the tensor; it is trusted
+    for as long as the tensor's version counter stands.  Code that rewrites ``t`` through a raw pointer must call ``drop_amax``."""
+    t._vnp_amax = (word, t._version)
+    return t
+
+
+def drop_amax(t):
+    if hasattr(t, "_vnp_amax"):
+        del t._vnp_amax
+
+
+def amax_word(t):
+    """int32 [1] device tensor: bit pattern of max |t| (2-D, unit inner stride) — the producer's word when there is one, else one
+    vnp_absmax pass.  None when the layout is outside vnp_absmax's contract (callers then use the six-product GEMM)."""
+    a = getattr(t, "_vnp_amax", None)
+    if a is not None and a[1] == t._version:
+        return a[0]
+    rows, cols = t.shape
+    ld = _ld(t)
+    if cols % 4 or ld % 4 or t.data_ptr() % 16:
+        return None
+    w = torch.empty(1, device=t.device, dtype=torch.int32)
+    call("vnp_absmax", ptr(t), ld, rows, cols, ptr(w))
+    _trace("absmax_pass")
+    return w
+
+
+def _fp16x2_shape(op_a, M, N, K, A, B, nsplit):
+    """The shapes vnp_gemm_ex runs on the two-plane path (gemm.hip: aligned tiles, K >= 64) that are worth two absmax launches."""
+    bm = 192 if op_a == 0 else 128
+    return (GEMM_FP16X2 and K >= 64 and K % 32 == 0 and M % bm == 0 and N % 128 == 0 and 2.0 * M * N * K >= GEMM_FP16X2_MIN_FLOP
+            and _lib.get_gemm_mode() == "split" and _ld(A) % 4 == 0 and _ld(B) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumulate=False, nsplit=None, amax_a=None, amax_b=None):
+    """C = op(A) op(B) (+ per-sample bias).  See vnp_gemm / vnp_gemm_ex in include/vnpcc.h.  ``amax_a`` / ``amax_b``: the operands'
+    ``amax_word`` when the caller already holds it (an operand used by two GEMMs)."""
     A, B = _rows(A), _rows(B)
     M, K = (A.shape[0], A.shape[1]) if op_a == 0 else (A.shape[1], A.shape[0])
     N, Kb = (B.shape[0], B.shape[1]) if op_b == 0 else (B.shape[1], B.shape[0])
@@ -145,8 +186,18 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
-         ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))
+    h2 = _fp16x2_shape(op_a, M, N, K, A, B, nsplit)
+    if h2:
+        amax_a = amax_a if amax_a is not None else amax_word(A)
+        amax_b = amax_b if amax_b is not None else amax_word(B)
+        h2 = amax_a is not None and amax_b is not None
+    if h2:
+        _trace("gemm_fp16x2")
+        call("vnp_gemm_ex", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
+             ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws), ptr(amax_a), ptr(amax_b))
+    else:
+        call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
+             ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))
     if prof is not None:
         e1.record()
         prof.append(("NT" if (op_a, op_b) == (0, 0) else "NN" if (op_a, op_b) == (0, 1) else "TN" if (op_a, op_b) == (1, 1) else "TT",
@@ -205,8 +256,16 @@ def gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, want_stats):
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("vnp_gemm_vn_stats", R, 2 * C, K, ptr(x), _ld(x), ptr(Wcat), K, ptr(pd), _ld(pd), ptr(bias),
-         _ld(bias) if bias is not None else 0, rows_per_group, C, ptr(part), ptr(ws))
+    am_x = am_w = None
+    if _fp16x2_shape(0, R, 2 * C, K, x, Wcat, 1):
+        am_x, am_w = amax_word(x), amax_word(Wcat)
+    if am_x is not None and am_w is not None:
+        _trace("gemm_fp16x2")
+        call("vnp_gemm_vn_stats_ex", R, 2 * C, K, ptr(x), _ld(x), ptr(Wcat), K, ptr(pd), _ld(pd), ptr(bias),
+             _ld(bias) if bias is not None else 0, rows_per_group, C, ptr(part), ptr(ws), ptr(am_x), ptr(am_w))
+    else:
+        call("vnp_gemm_vn_stats", R, 2 * C, K, ptr(x), _ld(x), ptr(Wcat), K, ptr(pd), _ld(pd), ptr(bias),
+             _ld(bias) if bias is not None else 0, rows_per_group, C, ptr(part), ptr(ws))
     if prof is not None:
         e1.record()
         prof.append(("NT", 2.0 * R * 2 * C * K, 1, (R, 2 * C, K), e0, e1))
