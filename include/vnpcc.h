@@ -181,12 +181,12 @@ int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx, const flo
  * evaluated exactly as diagonals of MFMA tiles with the full kernels' product sequence, and a predicated launch of the full
  * kernel takes over if the candidate list (32 pairs per (group, channel) on average) overflows or a bound is not finite (NaN / Inf
  * inputs, massive exact ties).
- * ws: vnp_linear_pool_screened_ws_bytes(G, gs, C) bytes; afterwards its first three ints are {candidates evaluated,
+ * ws: vnp_linear_pool_screened_ws_bytes(G, gs, C, K) bytes; afterwards its first three ints are {candidates evaluated,
  * fallback flag, candidate capacity} (diagnostics). */
 /* flags: 0 = bracketing pass on three bf16 products (truncation 2^-16); VNP_POOL_SCREEN_FP16 = on ONE fp16 product (2^-10: about twice
  * the candidates, 40 % less pass time; operands beyond fp16's range raise the fallback flag).  Either way the result is exact. */
 #define VNP_POOL_SCREEN_FP16 1
-long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C);
+long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C, int K);
 int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
                                  int K, int* idx, float* out, int ldo, void* ws, int flags);
 int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int ldd, long long G, int gs, int C,

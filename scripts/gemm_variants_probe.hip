@@ -34,7 +34,7 @@ int main()
 {
     const size_t nA = (size_t)1572864 * 512, nC = (size_t)1572864 * 512;
     float *A, *B, *C, *ws;
-    CK(hipMalloc(&A, nA * 4)); CK(hipMalloc(&B, nA * 4)); CK(hipMalloc(&C, nC * 4)); CK(hipMalloc(&ws, (size_t)128 * 512 * 256 * 4 + (size_t)16 * 2048 * 512 * 4));
+    CK(hipMalloc(&A, nA * 4)); CK(hipMalloc(&B, nA * 4)); CK(hipMalloc(&C, nC * 4)); CK(hipMalloc(&ws, (size_t)6144 * 2048 * 16 + (size_t)128 * 512 * 256 * 4 + (size_t)16 * 2048 * 512 * 4));
     std::vector<float> h(nA);
     srand(1);
     for (auto& v : h) v = ((float)(rand() & 0xffffff) / 8388608.f - 1.f);
@@ -60,6 +60,21 @@ int main()
         t += run<128, false, false, 0, PREC>("dec wgrad TN", 512, 256, 1572864, 128, A, B, C, ws);                    \
         printf("sum %.3f ms\n", t);                                                                                   \
     } while (0)
+    {   // the one-fp16-product screening pass of the pool (EPI = 4: fp16 operand images, bracketing epilogue): maxpool2's shape
+        VnpGemmArgs p{};
+        const int M = 196608, N = 4096, K = 1024;
+        p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.rows_per_group = 1; p.col_group = 8;       // (as halves)
+        p.tiles_per_split = K / 32; p.nsplit = 1; p.nbatch = 1; p.pool_gs = 2048;
+        p.pool_val = ws; p.pool_idx = (int*)C; p.row_norm = C + (1 << 24); p.col_norm = C + (1 << 25); p.screen_eps = 1e-3f; p.screen_abs = 1e-8f;
+        dim3 grid(512), block(256);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, 0, p);
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, 0, p);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("pool screening pass (one fp16 product) M=%d N=%d K=%d: %.3f ms\n", M, N, K, ms / 10);
+    }
     ALL(0, "three bf16 planes, six products");
     ALL(1, "two fp16 planes, three products, per-K-tile partial sums added on the VALU");
     return 0;

@@ -359,7 +359,10 @@ extern "C" int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx
 // unconditionally behind it as a predicated launch — recomputes everything; without the flag it exits at once (~10 us).
 
 // upper bound of |row|_2 for rows of K floats (one wave per row); inflated past its own fp32 rounding
-__global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restrict__ x, int ld, long long rows, int K, float* __restrict__ out)
+// h16 (optional): the row rounded to fp16 (round to nearest even; |x| > 65504 -> Inf), [rows][K] halves — the operand image the
+// one-product screening pass reads
+__global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restrict__ x, int ld, long long rows, int K, float* __restrict__ out,
+                                                          unsigned short* __restrict__ h16)
 {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -369,6 +372,7 @@ __global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restri
     for (int k = lane * 4; k < K; k += 256) {
         const vnp_f4 v = __builtin_nontemporal_load((const vnp_f4*)(src + k));
         s = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], s))));
+        if (h16) *(vnp_u2*)(h16 + (size_t)r * K + k) = vnp_u2{vnp_pack_f16(v[0], v[1]), vnp_pack_f16(v[2], v[3])};
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -626,16 +630,16 @@ static inline long long vnp_align256(long long v) { return (v + 255) / 256 * 256
 // random-init weights, 8 / 21 on surface-like clouds, where neighbouring points have nearly equal scores)
 static inline long long vnp_screen_cap(long long G, int C) { long long c = 32 * G * C; return c > 2000000000LL ? 2000000000LL : c; }
 
-extern "C" long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C)
+extern "C" long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C, int K)
 {
-    if (G <= 0 || gs <= 0 || C <= 0 || gs % 32) return 0;
+    if (G <= 0 || gs <= 0 || C <= 0 || K <= 0 || gs % 32) return 0;
     const long long nslot = G * (gs / 32) * (long long)C, cap = vnp_screen_cap(G, C);
-    return 256 + vnp_align256(G * gs * 3 * 4) + vnp_align256(2LL * C * 4) + vnp_align256(nslot * 16) + vnp_align256(nslot * 4) + vnp_align256(G * C * 8) +
+    return 256 + vnp_align256(G * gs * 3 * (long long)K * 2) + vnp_align256(2LL * C * K * 2) + vnp_align256(G * gs * 3 * 4) + vnp_align256(2LL * C * 4) + vnp_align256(nslot * 16) + vnp_align256(nslot * 4) + vnp_align256(G * C * 8) +
            vnp_align256(cap * 8) + vnp_align256(cap * 16) + 4 * vnp_align256((G * gs / SCR_BIN + 2) * 4) + vnp_align256(cap * 4) +
            vnp_align256(vnp_linear_pool_ws_bytes(G, gs, C));
 }
 
-// Same contract, arguments and results (bit for bit) as vnp_linear_pool_fwd; ws: vnp_linear_pool_screened_ws_bytes(G, gs, C) bytes.
+// Same contract, arguments and results (bit for bit) as vnp_linear_pool_fwd; ws: vnp_linear_pool_screened_ws_bytes(G, gs, C, K) bytes.
 // After the call ws begins with {int candidates, int fallback_flag, int capacity} (diagnostics; device memory).
 extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
                                             int K, int* idx, float* out, int ldo, void* ws, int flags)
@@ -648,6 +652,8 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     const long long nslot = G * (gs / 32) * (long long)C, cap = vnp_screen_cap(G, C);
     char* w = (char*)ws;
     VnpScreenHead* head = (VnpScreenHead*)w;       w += 256;
+    unsigned short* x16 = (unsigned short*)w;      w += vnp_align256(M * (long long)K * 2);          // fp16 images of x and Wcat
+    unsigned short* w16 = (unsigned short*)w;      w += vnp_align256(2LL * C * K * 2);
     float* rnorm = (float*)w;                      w += vnp_align256(M * 4);
     float* cnorm = (float*)w;                      w += vnp_align256(2LL * C * 4);
     float4* slots = (float4*)w;                    w += vnp_align256(nslot * 16);
@@ -664,8 +670,10 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     int* order = (int*)w;                          w += vnp_align256(cap * 4);
     void* ws_full = (void*)w;
     hipLaunchKernelGGL(vnp_pool_screen_init_kernel, dim3(1), dim3(1), 0, st, head, (int)cap);
-    hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(M, 4)), dim3(256), 0, st, x, ldx, M, K, rnorm);
-    hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(2LL * C, 4)), dim3(256), 0, st, Wcat, ldw, 2LL * C, K, cnorm);
+    const bool f16pass = (flags & VNP_POOL_SCREEN_FP16) != 0 && K % 64 == 0;          // the fp16 pass walks K in steps of 64
+    hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(M, 4)), dim3(256), 0, st, x, ldx, M, K, rnorm, f16pass ? x16 : nullptr);
+    hipLaunchKernelGGL(vnp_row_norm_kernel, dim3((unsigned)vnp_cdiv(2LL * C, 4)), dim3(256), 0, st, Wcat, ldw, 2LL * C, K, cnorm,
+                       f16pass ? w16 : nullptr);
     VnpGemmArgs p{};
     p.A = x; p.B = Wcat; p.C = nullptr; p.bias = nullptr;
     p.M = (int)M; p.N = 2 * C; p.K = K;
@@ -677,12 +685,13 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     if (items > 2147483647LL) return VNP_EINVAL;
     const long long capwg = (long long)vnp_num_cus() * 2;
     dim3 grid((unsigned)(items < capwg ? items : capwg)), block(256);
-    if (flags & VNP_POOL_SCREEN_FP16) {
+    if (f16pass) {
         // ONE fp16 product per operand pair (11 significant bits against bf16's 8): |w f - w~ f~| <= (2^-10 + 2^-22) |w||f| +
         // 2^-25 (|w| + |f|) (the second term: operands under fp16's normal range; an operand over 65504 becomes Inf and raises the
         // fallback flag through a non-finite bound), plus the worst-case fp32 rounding of both accumulations (K and 6K terms)
         p.screen_eps = 9.78e-4f + 7.2f * (float)K * 5.9605e-8f;
         p.screen_abs = 3.0e-8f * sqrtf((float)K) * 1.01f;
+        p.A = (const float*)x16; p.B = (const float*)w16; p.lda = K; p.ldb = K;          // the pass reads the fp16 images (halves)
         hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, st, p);
     } else {
         // THREE bf16 products: dropped (h l)+(l h)+(m m)+... <= 3.05 * 2^-18 of |w||f| per term, plus the worst-case fp32 rounding of

@@ -235,9 +235,12 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave: (BM/2)/16 x (BN/2)/16
     constexpr int AV = BM * BK / 4 / 256, BV = BN * BK / 4 / 256;
     constexpr int APL = BM * 64, BPL = BN * 64;                 // bytes per plane
-    __shared__ __attribute__((aligned(16))) char smem[3 * APL + 3 * BPL];
+    // EPI = 4 stages two 32-wide half-tiles of ONE fp16 plane (41 KB; three workgroups per CU would fit, but at 168 VGPRs the loop spills:
+    // 7.7 ms instead of 2.0); everything else up to three planes
+    constexpr int ASZ = EPI == 4 ? 2 * APL + 128 : 3 * APL, BSZ = EPI == 4 ? 2 * BPL + 128 : 3 * BPL;
+    __shared__ __attribute__((aligned(16))) char smem[ASZ + BSZ];
     char* As = smem;
-    char* Bs = smem + 3 * APL;
+    char* Bs = smem + ASZ;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -322,6 +325,175 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
     for (int i = 0; i < TM; ++i) a_rd[i] = vnp_split_row_off<BM, AKC>(wm * (BM / 2) + i * 16 + l16, lq);
 #pragma unroll
     for (int j = 0; j < TN; ++j) b_rd[j] = vnp_split_row_off<BN, BKC>(wn * (BN / 2) + j * 16 + l16, lq);
+
+    // ---- epilogue of the screening passes (EPI = 3, 4), shared by the generic loop and the fp16 pass's own loop below
+    auto screen_epilogue = [&](vnp_f4 (&acc)[TM][TN], int m0, int n0) {
+#ifdef VNP_EXPERIMENT_NO_SCREEN_EPILOGUE   // scripts/gemm_variants_probe.hip only: prices the bracketing epilogue (one lane in 2^20 still stores)
+        if (acc[0][0][0] != 1.2345678e-30f) return;
+#endif
+            // Screening pass of the exact screened arg-max pool.  acc holds the 3-product values x~, d~ in the layout of EPI = 1.
+            // For every (point, channel): s~ = <x~, d~> and a rigorous bound err >= |s6 - s~| on its distance to the value s6 the
+            // 6-product kernels compute for the same pair:  |x6_t - x~_t| <= E |W_c| |f_(n,t)| =: ex_t (Cauchy-Schwarz on the
+            // dropped products and on both accumulations' fp32 rounding; E = p.screen_eps, norms = upper bounds), same for d, so
+            //   |s6 - s~| <= sum_t (|x~_t| ed_t + |d~_t| ex_t + ex_t ed_t) + 2^-21 sum_t |x~_t d~_t|   (last term: the two fmaf chains).
+            // Per 32-point block: the largest lower bound, the two largest upper bounds with their points, and the third-largest
+            // upper bound (three or more candidates in one block make the whole block a candidate).  A non-finite bound poisons the slot with +Inf, which makes the selection pass raise the fallback flag.
+            const int pt0 = m0 / 3 + wm * 32;
+            const int grp = pt0 / 32;
+            const int loc0 = pt0 % p.pool_gs;
+            const int Cch = p.N >> 1;
+            const int rbase = m0 + wm * 96;
+            float nf[2][4][3];
+#pragma unroll
+            for (int i3 = 0; i3 < 2; ++i3)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) nf[i3][e][t] = p.row_norm[rbase + (16 * i3 + 4 * lq + e) * 3 + t];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int colx = n0 + wn * 64 + jj * 16 + l16;
+                const float cnx = p.col_norm[colx], cnd = p.col_norm[colx + 32];
+                const float Ex = p.screen_eps * cnx, Ed = p.screen_eps * cnd;
+                // fp16 pass only: operands below fp16's normal range lose absolute, not relative, accuracy: + A (|W_c| + |f|) per output
+                const float Ax = p.screen_abs * cnx, Ad = p.screen_abs * cnd, An = p.screen_abs;
+                float lmax = -INFINITY, u1 = -INFINITY, u2 = -INFINITY, u3 = -INFINITY;     // the three largest upper bounds of the block
+                int i1 = 0, i2 = 0;                                                        // and the points of the first two
+                bool bad = false;
+                auto insert = [&](float up, int ix) {
+                    if (up > u1) { u3 = u2; u2 = u1; i2 = i1; u1 = up; i1 = ix; }
+                    else if (up > u2) { u3 = u2; u2 = up; i2 = ix; }
+                    else u3 = fmaxf(u3, up);
+                };
+#pragma unroll
+                for (int i3 = 0; i3 < 2; ++i3)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = acc[3 * i3][jj][e], x1 = acc[3 * i3 + 1][jj][e], x2 = acc[3 * i3 + 2][jj][e];
+                        const float d0 = acc[3 * i3][jj + 2][e], d1 = acc[3 * i3 + 1][jj + 2][e], d2 = acc[3 * i3 + 2][jj + 2][e];
+                        const float st = fmaf(x2, d2, fmaf(x1, d1, x0 * d0));
+                        float err = 0.f, mag = 0.f;
+                        {
+                            const float ex0 = fmaf(Ex, nf[i3][e][0], fmaf(An, nf[i3][e][0], Ax)), ed0 = fmaf(Ed, nf[i3][e][0], fmaf(An, nf[i3][e][0], Ad));
+                            const float ex1 = fmaf(Ex, nf[i3][e][1], fmaf(An, nf[i3][e][1], Ax)), ed1 = fmaf(Ed, nf[i3][e][1], fmaf(An, nf[i3][e][1], Ad));
+                            const float ex2 = fmaf(Ex, nf[i3][e][2], fmaf(An, nf[i3][e][2], Ax)), ed2 = fmaf(Ed, nf[i3][e][2], fmaf(An, nf[i3][e][2], Ad));
+                            err = fmaf(fabsf(x0), ed0, fmaf(fabsf(d0), ex0, ex0 * ed0));
+                            err += fmaf(fabsf(x1), ed1, fmaf(fabsf(d1), ex1, ex1 * ed1));
+                            err += fmaf(fabsf(x2), ed2, fmaf(fabsf(d2), ex2, ex2 * ed2));
+                            mag = fabsf(x0 * d0) + fabsf(x1 * d1) + fabsf(x2 * d2);
+                        }
+                        err = fmaf(mag, 4.8e-7f, err) * 1.001f + 1e-37f;        // + the fmaf chains' rounding; inflated for its own rounding
+                        bad = bad || !(err < INFINITY) || !(fabsf(st) < INFINITY);
+                        const float lo = st - err, up = st + err;
+                        lmax = fmaxf(lmax, lo);
+                        insert(up, 16 * i3 + 4 * lq + e);
+                    }
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) {
+                    const float ol = __shfl_xor(lmax, o), ou1 = __shfl_xor(u1, o), ou2 = __shfl_xor(u2, o), ou3 = __shfl_xor(u3, o);
+                    const int oi1 = __shfl_xor(i1, o), oi2 = __shfl_xor(i2, o);
+                    const bool ob = __shfl_xor((int)bad, o) != 0;
+                    lmax = fmaxf(lmax, ol);
+                    insert(ou1, oi1);
+                    insert(ou2, oi2);
+                    u3 = fmaxf(u3, ou3);
+                    bad = bad || ob;
+                }
+                if (lq == 0) {
+                    const int ch = (n0 >> 1) + wn * 32 + jj * 16 + l16;
+                    const size_t slot = (size_t)grp * Cch + ch;
+                    float4 o4;
+                    o4.x = bad ? INFINITY : lmax; o4.y = bad ? INFINITY : u1; o4.z = bad ? INFINITY : u2; o4.w = bad ? INFINITY : u3;
+                    ((float4*)p.pool_val)[slot] = o4;
+                    p.pool_idx[slot] = (loc0 + i1) | ((loc0 + i2) << 16);          // pool_gs <= 2048: 16 bits each
+                }
+            }
+    };
+
+    if (EPI == 4) {
+        // ---- the one-fp16-product screening pass has its own K loop.  Its operands ARE fp16 already (p.A / p.B point to [rows][K] halves,
+        // lda / ldb in halves: gemm.hip converts them once, in the pass that takes the row norms), so there is nothing to do between the
+        // load and LDS — and with 24 MFMAs per 32-wide K-tile the pass is bound by the operand bytes a CU pulls from L2 (both panels are
+        // re-read for every tile: ~45 GB/s per CU against the 66-73 the L2 serves), not by the matrix pipe.  So: half the bytes (fp16
+        // images instead of fp32), K walked in steps of 64 — a thread loads 16 bytes and eight neighbouring lanes cover one whole
+        // 128-byte line of a row — with the second 32-wide half staged in the LDS region of the (unused) second plane, 128 bytes
+        // further so that the ds_write_b128 of a 16-lane group (two rows x two halves) still covers all 64 banks: half the barriers
+        // and twice the MFMAs behind every load.  Measured on maxpool2's shape (196608 x 4096 x 1024): 2.91 ms (fp32 operands converted
+        // in the loop) -> 2.24 (fp16 images) -> 2.07 (64-wide steps) -> see DESIGN.md; an LDS-DMA ring of three 32-wide tiles
+        // (global_load_lds_dwordx4 two tiles ahead, one raw barrier per tile, source-side swizzle) measured 2.37: its pieces are
+        // 64-byte row halves and it syncs twice as often.
+        const unsigned short* A16 = (const unsigned short*)p.A;
+        const unsigned short* B16 = (const unsigned short*)p.B;
+        constexpr int BK2 = 2 * BK, AH = BM / 32, BH = BN / 32;          // 16-byte loads per thread and step: row tid/8 + 32 j, slot tid & 7
+        constexpr int APL2 = APL + 128, BPL2 = BPL + 128;                // where the second half-tile lives
+        const int nkt = p.K / BK2;                                       // (the host guarantees K % 64 == 0)
+        int offA[AH], offB[BH];
+#pragma unroll
+        for (int j = 0; j < AH; ++j) {
+            const int rho = (tid >> 3) + 32 * j, half = rho / 96, within = rho % 96, i = within >> 4, r16 = within & 15;
+            offA[j] = (half * 96 + ((i / 3) * 16 + r16) * 3 + i % 3) * p.lda + (tid & 7) * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < BH; ++j) offB[j] = ((tid >> 3) + 32 * j) * p.ldb + (tid & 7) * 8;
+        const int sub = (tid >> 2) & 1, q = tid & 3;                     // which 32-wide half, and the 16-byte slot inside it
+        vnp_u4 ha[AH], hb[BH];
+        auto fetch4 = [&](int fm0, int fn0, int kt) {
+            const unsigned short* srcA = A16 + (size_t)fm0 * p.lda + kt * BK2;
+            const unsigned short* srcB = B16 + (size_t)fn0 * p.ldb + kt * BK2;
+#pragma unroll
+            for (int j = 0; j < AH; ++j) ha[j] = *(const vnp_u4*)(srcA + offA[j]);
+#pragma unroll
+            for (int j = 0; j < BH; ++j) hb[j] = *(const vnp_u4*)(srcB + offB[j]);
+        };
+        auto write4 = [&]() {
+#pragma unroll
+            for (int j = 0; j < AH; ++j) *(vnp_u4*)(As + sub * APL2 + vnp_split_row_off<BM, true>((tid >> 3) + 32 * j, q)) = ha[j];
+#pragma unroll
+            for (int j = 0; j < BH; ++j) *(vnp_u4*)(Bs + sub * BPL2 + vnp_split_row_off<BN, true>((tid >> 3) + 32 * j, q)) = hb[j];
+        };
+        int w = blockIdx.x;
+        if (w >= total) return;
+        set_item(w);
+        fetch4(m0, n0, 0);
+        write4();
+        __syncthreads();
+        while (true) {
+            vnp_f4 acc[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+            const int wnext = w + gridDim.x;
+            const bool more = wnext < total;
+            const int cm0 = m0, cn0 = n0;
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (kt + 1 < nkt) fetch4(cm0, cn0, kt + 1);
+                else if (more) { set_item(wnext); fetch4(m0, n0, 0); }          // the next item's first step, behind this item's last MFMAs
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    vnp_h8 b[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = __builtin_bit_cast(vnp_h8, *(const vnp_u4*)(Bs + s * BPL2 + b_rd[j]));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const vnp_h8 a = __builtin_bit_cast(vnp_h8, *(const vnp_u4*)(As + s * APL2 + a_rd[i]));
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                if (kt + 1 < nkt) { write4(); __syncthreads(); }
+            }
+            screen_epilogue(acc, cm0, cn0);
+            if (!more) break;
+            w = wnext;
+            write4();                // m0 / n0 already are the next item's (set above)
+            __syncthreads();
+        }
+        return;
+    }
 
     int w = blockIdx.x;
     if (w >= total) return;
@@ -457,84 +629,8 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
                     p.pool_x[3 * slot + 0] = bx0; p.pool_x[3 * slot + 1] = bx1; p.pool_x[3 * slot + 2] = bx2;
                 }
             }
-        } else if (EPI == 3 || EPI == 4) {
-            // Screening pass of the exact screened arg-max pool.  acc holds the 3-product values x~, d~ in the layout of EPI = 1.
-            // For every (point, channel): s~ = <x~, d~> and a rigorous bound err >= |s6 - s~| on its distance to the value s6 the
-            // 6-product kernels compute for the same pair:  |x6_t - x~_t| <= E |W_c| |f_(n,t)| =: ex_t (Cauchy-Schwarz on the
-            // dropped products and on both accumulations' fp32 rounding; E = p.screen_eps, norms = upper bounds), same for d, so
-            //   |s6 - s~| <= sum_t (|x~_t| ed_t + |d~_t| ex_t + ex_t ed_t) + 2^-21 sum_t |x~_t d~_t|   (last term: the two fmaf chains).
-            // Per 32-point block: the largest lower bound, the two largest upper bounds with their points, and the third-largest
-            // upper bound (three or more candidates in one block make the whole block a candidate).  A non-finite bound poisons the slot with +Inf, which makes the selection pass raise the fallback flag.
-            const int pt0 = m0 / 3 + wm * 32;
-            const int grp = pt0 / 32;
-            const int loc0 = pt0 % p.pool_gs;
-            const int Cch = p.N >> 1;
-            const int rbase = m0 + wm * 96;
-            float nf[2][4][3];
-#pragma unroll
-            for (int i3 = 0; i3 < 2; ++i3)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) nf[i3][e][t] = p.row_norm[rbase + (16 * i3 + 4 * lq + e) * 3 + t];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int colx = n0 + wn * 64 + jj * 16 + l16;
-                const float cnx = p.col_norm[colx], cnd = p.col_norm[colx + 32];
-                const float Ex = p.screen_eps * cnx, Ed = p.screen_eps * cnd;
-                // fp16 pass only: operands below fp16's normal range lose absolute, not relative, accuracy: + A (|W_c| + |f|) per output
-                const float Ax = p.screen_abs * cnx, Ad = p.screen_abs * cnd, An = p.screen_abs;
-                float lmax = -INFINITY, u1 = -INFINITY, u2 = -INFINITY, u3 = -INFINITY;     // the three largest upper bounds of the block
-                int i1 = 0, i2 = 0;                                                        // and the points of the first two
-                bool bad = false;
-                auto insert = [&](float up, int ix) {
-                    if (up > u1) { u3 = u2; u2 = u1; i2 = i1; u1 = up; i1 = ix; }
-                    else if (up > u2) { u3 = u2; u2 = up; i2 = ix; }
-                    else u3 = fmaxf(u3, up);
-                };
-#pragma unroll
-                for (int i3 = 0; i3 < 2; ++i3)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x0 = acc[3 * i3][jj][e], x1 = acc[3 * i3 + 1][jj][e], x2 = acc[3 * i3 + 2][jj][e];
-                        const float d0 = acc[3 * i3][jj + 2][e], d1 = acc[3 * i3 + 1][jj + 2][e], d2 = acc[3 * i3 + 2][jj + 2][e];
-                        const float st = fmaf(x2, d2, fmaf(x1, d1, x0 * d0));
-                        float err = 0.f, mag = 0.f;
-                        {
-                            const float ex0 = fmaf(Ex, nf[i3][e][0], fmaf(An, nf[i3][e][0], Ax)), ed0 = fmaf(Ed, nf[i3][e][0], fmaf(An, nf[i3][e][0], Ad));
-                            const float ex1 = fmaf(Ex, nf[i3][e][1], fmaf(An, nf[i3][e][1], Ax)), ed1 = fmaf(Ed, nf[i3][e][1], fmaf(An, nf[i3][e][1], Ad));
-                            const float ex2 = fmaf(Ex, nf[i3][e][2], fmaf(An, nf[i3][e][2], Ax)), ed2 = fmaf(Ed, nf[i3][e][2], fmaf(An, nf[i3][e][2], Ad));
-                            err = fmaf(fabsf(x0), ed0, fmaf(fabsf(d0), ex0, ex0 * ed0));
-                            err += fmaf(fabsf(x1), ed1, fmaf(fabsf(d1), ex1, ex1 * ed1));
-                            err += fmaf(fabsf(x2), ed2, fmaf(fabsf(d2), ex2, ex2 * ed2));
-                            mag = fabsf(x0 * d0) + fabsf(x1 * d1) + fabsf(x2 * d2);
-                        }
-                        err = fmaf(mag, 4.8e-7f, err) * 1.001f + 1e-37f;        // + the fmaf chains' rounding; inflated for its own rounding
-                        bad = bad || !(err < INFINITY) || !(fabsf(st) < INFINITY);
-                        const float lo = st - err, up = st + err;
-                        lmax = fmaxf(lmax, lo);
-                        insert(up, 16 * i3 + 4 * lq + e);
-                    }
-#pragma unroll
-                for (int o = 16; o <= 32; o <<= 1) {
-                    const float ol = __shfl_xor(lmax, o), ou1 = __shfl_xor(u1, o), ou2 = __shfl_xor(u2, o), ou3 = __shfl_xor(u3, o);
-                    const int oi1 = __shfl_xor(i1, o), oi2 = __shfl_xor(i2, o);
-                    const bool ob = __shfl_xor((int)bad, o) != 0;
-                    lmax = fmaxf(lmax, ol);
-                    insert(ou1, oi1);
-                    insert(ou2, oi2);
-                    u3 = fmaxf(u3, ou3);
-                    bad = bad || ob;
-                }
-                if (lq == 0) {
-                    const int ch = (n0 >> 1) + wn * 32 + jj * 16 + l16;
-                    const size_t slot = (size_t)grp * Cch + ch;
-                    float4 o4;
-                    o4.x = bad ? INFINITY : lmax; o4.y = bad ? INFINITY : u1; o4.z = bad ? INFINITY : u2; o4.w = bad ? INFINITY : u3;
-                    ((float4*)p.pool_val)[slot] = o4;
-                    p.pool_idx[slot] = (loc0 + i1) | ((loc0 + i2) << 16);          // pool_gs <= 2048: 16 bits each
-                }
-            }
+        } else if (EPI == 3) {
+            screen_epilogue(acc, m0, n0);
         } else if (EPI == 2) {
             // C store under the row permutation of EPI = 1 (MFMA row-tile 3 i3 + t, row r  <->  component t of wave-local point
             // 16 i3 + r) plus the BatchNorm statistics of the p columns: every lane holds whole 3-vectors, so n = |x| + eps is

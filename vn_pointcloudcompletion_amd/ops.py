@@ -738,7 +738,7 @@ class VNLinearMaxPoolFn(Function):
             # the selection pass keeps a group's 32-point blocks in registers (gs <= 2048); back off after a fallback (see above)
             screened = POOL_SCREENED and gs <= 2048 and (POOL_SCREEN_STATS is not None or _screen_allowed(skey))
             entry = "vnp_linear_pool_screened_fwd" if screened else "vnp_linear_pool_fwd"
-            nb = (_lib.lib().vnp_linear_pool_screened_ws_bytes if screened else _lib.lib().vnp_linear_pool_ws_bytes)(G, gs, C)
+            nb = _lib.lib().vnp_linear_pool_screened_ws_bytes(G, gs, C, K) if screened else _lib.lib().vnp_linear_pool_ws_bytes(G, gs, C)
             ws = torch.empty((nb + 7) // 8, device=x.device, dtype=torch.int64)
             prof = GEMM_PROFILE
             if prof is not None:
