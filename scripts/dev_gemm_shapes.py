@@ -8,7 +8,7 @@ from vn_pointcloudcompletion_amd import ops
 from vn_pointcloudcompletion_amd.model import PCNNet
 from vn_pointcloudcompletion_amd.optim import FusedAdam
 from vn_pointcloudcompletion_amd.train import train_step
-C = {3: ("vn_dgcnn_fps", "vn_foldingnet", 32, 512, "cd"), 4: ("vn_pointnet", "attention_vn_foldingnet", 16, 2048, "emd"),
+C = {2: ("vn_pointnet", "vn_foldingnet", 32, 2048, "cd"), 3: ("vn_dgcnn_fps", "vn_foldingnet", 32, 512, "cd"), 4: ("vn_pointnet", "attention_vn_foldingnet", 16, 2048, "emd"),
      5: ("vn_pointr", "vn_foldingnet", 32, 1024, "cd")}[sys.argv_cfg]
 cfg = SimpleNamespace(num_coarse=1024, latent_dim=C[3], only_coarse=False, enc_pretrained="none", device="cuda:0", coarse_loss=C[4],
                       dcd_opts={"alpha": 200, "lambda": 0.5}, knn_k=20 if sys.argv_cfg == 3 else 16)
@@ -26,5 +26,5 @@ for variant, flops, nsplit, shape, e0, e1 in prof:
     a = per.setdefault((variant, shape, nsplit), [0.0, 0.0, 0]); a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
 tot = sum(a[1] for a in per.values())
 print("total GEMM ms/step %.2f in %d launches" % (tot * 1e3, sum(a[2] for a in per.values())))
-for (variant, shape, nsplit), a in sorted(per.items(), key=lambda kv: -kv[1][1])[:22]:
+for (variant, shape, nsplit), a in sorted(per.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"  {variant} M={shape[0]:8d} N={shape[1]:5d} K={shape[2]:8d} split={nsplit:4d} x{a[2]:2d} {a[1] * 1e3:7.3f} ms {a[0] / a[1] / 1e12:6.1f} TF/s")
