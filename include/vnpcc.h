@@ -184,7 +184,8 @@ int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx, const flo
  * ws: vnp_linear_pool_screened_ws_bytes(G, gs, C, K) bytes; afterwards its first three ints are {candidates evaluated,
  * fallback flag, candidate capacity} (diagnostics). */
 /* flags: 0 = bracketing pass on three bf16 products (truncation 2^-16); VNP_POOL_SCREEN_FP16 = on ONE fp16 product (2^-10: about twice
- * the candidates, 40 % less pass time; operands beyond fp16's range raise the fallback flag).  Either way the result is exact. */
+ * the candidates, 60 % less pass time; operands beyond fp16's range raise the fallback flag; needs K % 64 == 0, else the three-product
+ * pass runs).  The fp16 pass reads fp16 images of x and Wcat that the row-norm pass writes into ws.  Either way the result is exact. */
 #define VNP_POOL_SCREEN_FP16 1
 long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C, int K);
 int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
