@@ -32,6 +32,7 @@ static inline hipError_t vnp_allow_dynamic_lds(std::atomic<unsigned long long>& 
 }
 
 typedef float vnp_f4 __attribute__((ext_vector_type(4)));
+typedef float vnp_f2 __attribute__((ext_vector_type(2)));
 typedef float vnp_f16 __attribute__((ext_vector_type(16)));
 
 // Activation layout used by every VN kernel ("rows layout"):
