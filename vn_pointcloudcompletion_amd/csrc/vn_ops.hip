@@ -798,9 +798,17 @@ struct VnpFoldArgs {
     float* gcoarse;                       // MODE 3: [B*Mc][3], zero-filled, atomically accumulated
 };
 
-template <int MODE>
+// two-lane helpers of the packed backward body (PK): one thread evaluates two seed points per step on v_pk_*_f32
+__device__ __forceinline__ vnp_f2 vnp_sq3(vnp_f2 a, vnp_f2 b, vnp_f2 c) { return a * a + b * b + c * c; }
+__device__ __forceinline__ vnp_f2 vnp_rcp2(vnp_f2 v) { return vnp_f2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
+__device__ __forceinline__ vnp_f2 vnp_sqrt2(vnp_f2 v) { return vnp_f2{__builtin_amdgcn_sqrtf(v[0]), __builtin_amdgcn_sqrtf(v[1])}; }
+
+// PK (backward modes, even S): the loop over a coarse point's S seed points takes two per step with packed fp32 arithmetic — the same
+// formulas lane by lane; only the order in which the per-thread sums collect their terms changes (even and odd seed points separately)
+template <int MODE, bool PK = false>
 __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a)
 {
+    static_assert(!PK || MODE >= 2, "the packed body exists for the backward modes");
     // the backward modes (gradients) use v_rcp_f32 / v_sqrt_f32 (1 ulp each) where the forward modes keep IEEE division and sqrtf so that statistics and
     // outputs stay bit-identical to the unfused path
 #define FDIV(a, b) (MODE >= 2 ? (a) * __builtin_amdgcn_rcpf(b) : (a) / (b))
@@ -837,6 +845,67 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
         float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;                     // MODE 3: dcoarse contributions of this column
         // (measured: `#pragma unroll 4` here — more gradient loads in flight — costs registers instead: mode 3 0.99 -> 1.16 ms,
         // mode 2 0.52 -> 0.69 ms)
+        if (PK) {
+            vnp_f2 vs1 = {0.f, 0.f}, vs2 = {0.f, 0.f}, vgc0 = {0.f, 0.f}, vgc1 = {0.f, 0.f}, vgc2 = {0.f, 0.f};
+            vnp_f2 vacc[2][5];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 5; ++r) vacc[h][r] = vnp_f2{0.f, 0.f};
+            for (int s = 0; s < S; s += 2) {
+                const vnp_f2 e0 = {sd[s * 3], sd[s * 3 + 3]}, e1 = {sd[s * 3 + 1], sd[s * 3 + 4]}, e2 = {sd[s * 3 + 2], sd[s * 3 + 5]};
+                const vnp_f2 x0 = pf[0] + wsf * e0, x1 = pf[1] + wsf * e1, x2 = pf[2] + wsf * e2;
+                const vnp_f2 pn = vnp_sqrt2(vnp_sq3(x0, x1, x2)), n = pn + VNP_EPS, rn = vnp_rcp2(n);
+                const vnp_f2 xh = (n - mu) * rs, nh = xh * ga + be, sc = nh * rn;
+                const vnp_f2 q0 = x0 * sc, q1 = x1 * sc, q2 = x2 * sc;
+                const vnp_f2 d0 = pdv[0] + wsd * e0, d1 = pdv[1] + wsd * e1, d2 = pdv[2] + wsd * e2;
+                const vnp_f2 dot = q0 * d0 + q1 * d1 + q2 * d2;
+                const size_t row = ((size_t)cp * S + s) * 3;
+                vnp_f2 g0 = {0.f, 0.f}, g1 = {0.f, 0.f}, g2 = {0.f, 0.f};
+                if (live) {
+                    const float* gp = a.go + row * a.ldgo + j;
+                    g0 = vnp_f2{__builtin_nontemporal_load(gp), __builtin_nontemporal_load(gp + 3 * (size_t)a.ldgo)};
+                    g1 = vnp_f2{__builtin_nontemporal_load(gp + a.ldgo), __builtin_nontemporal_load(gp + 4 * (size_t)a.ldgo)};
+                    g2 = vnp_f2{__builtin_nontemporal_load(gp + 2 * (size_t)a.ldgo), __builtin_nontemporal_load(gp + 5 * (size_t)a.ldgo)};
+                }
+                // the leaky branch, evaluated for both lanes and selected lane by lane
+                const float cc = 1.f - a.ns;
+                const vnp_f2 inv = vnp_rcp2(vnp_sq3(d0, d1, d2) + VNP_EPS);
+                const vnp_f2 al = dot * inv;
+                const vnp_f2 gdd = g0 * d0 + g1 * d1 + g2 * d2;
+                const vnp_f2 k1 = cc * gdd * inv;
+                vnp_f2 h0 = -cc * (al * g0 + gdd * (q0 * inv - 2.f * al * inv * d0));
+                vnp_f2 h1 = -cc * (al * g1 + gdd * (q1 * inv - 2.f * al * inv * d1));
+                vnp_f2 h2 = -cc * (al * g2 + gdd * (q2 * inv - 2.f * al * inv * d2));
+                const vnp_f2 t0 = g0 - k1 * d0, t1 = g1 - k1 * d1, t2 = g2 - k1 * d2;
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const bool neg = dot[l] < 0.f;
+                    h0[l] = neg ? h0[l] : 0.f; h1[l] = neg ? h1[l] : 0.f; h2[l] = neg ? h2[l] : 0.f;
+                    g0[l] = neg ? t0[l] : g0[l]; g1[l] = neg ? t1[l] : g1[l]; g2[l] = neg ? t2[l] : g2[l];      // now dL/dq
+                }
+                const vnp_f2 gs = g0 * x0 + g1 * x1 + g2 * x2;
+                const vnp_f2 gnh = gs * rn;
+                if (MODE == 2) { vs1 += gnh; vs2 += gnh * xh; continue; }
+                const vnp_f2 gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh * vnp_rcp2(n * n);
+                vnp_f2 kk = gn * vnp_rcp2(pn);
+                kk[0] = pn[0] > 0.f ? kk[0] : 0.f; kk[1] = pn[1] > 0.f ? kk[1] : 0.f;
+                const vnp_f2 r0 = sc * g0 + kk * x0, r1 = sc * g1 + kk * x1, r2 = sc * g2 + kk * x2;
+                vacc[0][0] += r0; vacc[0][1] += r1; vacc[0][2] += r2;
+                vacc[0][3] += r0 * e0 + r1 * e1 + r2 * e2;
+                vacc[0][4] += r0 * c0 + r1 * c1 + r2 * c2;
+                vacc[1][0] += h0; vacc[1][1] += h1; vacc[1][2] += h2;
+                vacc[1][3] += h0 * e0 + h1 * e1 + h2 * e2;
+                vacc[1][4] += h0 * c0 + h1 * c1 + h2 * c2;
+                vgc0 += r0 * wcf + h0 * wcd; vgc1 += r1 * wcf + h1 * wcd; vgc2 += r2 * wcf + h2 * wcd;
+            }
+            s1 += vs1[0] + vs1[1]; s2 += vs2[0] + vs2[1];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 5; ++r) acc[h][r] += vacc[h][r][0] + vacc[h][r][1];
+            gc0 = vgc0[0] + vgc0[1]; gc1 = vgc1[0] + vgc1[1]; gc2 = vgc2[0] + vgc2[1];
+        } else
         for (int s = 0; s < S; ++s) {
             const float e0 = sd[s * 3], e1 = sd[s * 3 + 1], e2 = sd[s * 3 + 2];
             const float x0 = pf[0] + wsf * e0, x1 = pf[1] + wsf * e1, x2 = pf[2] + wsf * e2;
@@ -963,11 +1032,14 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
     dim3 grid(vnp_cdiv(C, 64), nchunk), block(256);
     if (mode == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<0>), grid, block, 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL((vnp_fold_fused_kernel<1>), grid, block, 0, st, a);
-    else if (mode == 2) hipLaunchKernelGGL((vnp_fold_fused_kernel<2>), grid, block, 0, st, a);
-    else {
+    else if (mode == 2) {
+        if (S % 2 == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<2, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((vnp_fold_fused_kernel<2>), grid, block, 0, st, a);
+    } else {
         hipError_t e = hipMemsetAsync(gcoarse, 0, (size_t)B * Mc * 3 * 4, st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((vnp_fold_fused_kernel<3>), grid, block, 0, st, a);
+        if (S % 2 == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<3, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((vnp_fold_fused_kernel<3>), grid, block, 0, st, a);
     }
     return vnp_last_error();
 }
