@@ -218,12 +218,20 @@ __device__ __forceinline__ unsigned vnp_morton_spread5(unsigned v)
 }
 
 // sorted[b][i] = (x, y, z, original index as int bits); boxes[b][c][0/1] = (min, max) of chunk c; flag[0] |= non-finite
-__global__ void __launch_bounds__(1024) vnp_chamfer_bin_kernel(const float* __restrict__ xyz, int n, float4* sorted,
-                                                               float4* __restrict__ boxes, int* __restrict__ flag)
+// blockIdx.y selects the cloud: both clouds of a Chamfer call are binned by ONE launch (a workgroup per sample and cloud; the kernel is
+// latency-bound — 32 workgroups of a 256-CU chip — so two launches of B workgroups cost twice one launch of 2 B)
+__global__ void __launch_bounds__(1024) vnp_chamfer_bin_kernel(const float* __restrict__ xyz_a, int n_a, float4* sorted_a, float4* __restrict__ boxes_a,
+                                                               const float* __restrict__ xyz_b, int n_b, float4* sorted_b, float4* __restrict__ boxes_b,
+                                                               int* __restrict__ flag)
 {
     extern __shared__ unsigned cnt[];                          // CHP_BINS counters, then running offsets
     __shared__ float red[6][16];
     __shared__ unsigned wsum[16];
+    const bool second = blockIdx.y != 0;
+    const float* __restrict__ xyz = second ? xyz_b : xyz_a;
+    const int n = second ? n_b : n_a;
+    float4* sorted = second ? sorted_b : sorted_a;
+    float4* __restrict__ boxes = second ? boxes_b : boxes_a;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pts = xyz + (size_t)b * n * 3;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -485,8 +493,7 @@ extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float*
     static std::atomic<unsigned long long> lds_ok{0};
     e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_chamfer_bin_kernel, CHP_BINS * 4);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B), dim3(1024), (size_t)CHP_BINS * 4, st, xyz1, n, s1, b1, flag);
-    hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B), dim3(1024), (size_t)CHP_BINS * 4, st, xyz2, m, s2, b2, flag);
+    hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B, 2), dim3(1024), (size_t)CHP_BINS * 4, st, xyz1, n, s1, b1, xyz2, m, s2, b2, flag);
     hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
                        (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1);
     hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
