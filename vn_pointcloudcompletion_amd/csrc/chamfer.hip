@@ -17,8 +17,8 @@
 #define CH_TILE 1024             // reference points staged per LDS tile (16 KB)
 
 // Measured notes on the inner loop (kept for the next reader): (1) packing the arithmetic (v_pk_add/mul/fma_f32) halves the
-// instruction count but not the time — on gfx950 a wave64 v_pk_*_f32 issues in 4 cycles, the bound is 32 lane-ops / clk /
-// SIMD either way, and the extra v_mov splats made it 8 % slower; (2) tracking only chunk minima (v_min3) and re-scanning
+// instruction count but not the time when the pair was two REFERENCE points (the extra v_mov splats made it 8 % slower); pairing two
+// QUERIES needs no splats and is what the loop below does (round 2); (2) tracking only chunk minima (v_min3) and re-scanning
 // a chunk when some lane improved was slower too: with 256 queries per wave some lane improves in 40-60 % of 8-reference
 // chunks.  The plain form below — 3 sub, 1 mul, 2 fma, 1 cmp, 2 select per pair, 4 queries per thread sharing each LDS
 // broadcast read — runs 18.3 G pairs/step in ~3.1 ms = ~70 % of the VALU issue bound.
@@ -52,11 +52,15 @@ __global__ void __launch_bounds__(CH_THREADS) vnp_chamfer_nn_kernel(const float*
 #pragma unroll 4
         for (int i = 0; i < cnt; ++i) {
             const float4 t = tile[i];
+            static_assert(CH_QPT % 2 == 0, "queries are evaluated in pairs");
 #pragma unroll
-            for (int u = 0; u < CH_QPT; ++u) {
-                const float dx = t.x - qx[u], dy = t.y - qy[u], dz = t.z - qz[u];
-                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                if (d < best[u]) { best[u] = d; bi[u] = k0 + i; }
+            for (int u = 0; u < CH_QPT; u += 2) {
+                // two queries per packed instruction (the operands of a pair are loop-invariant register pairs: no splats); each
+                // distance is the same fmaf chain as before
+                const vnp_f2 dx = t.x - vnp_f2{qx[u], qx[u + 1]}, dy = t.y - vnp_f2{qy[u], qy[u + 1]}, dz = t.z - vnp_f2{qz[u], qz[u + 1]};
+                const vnp_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                if (d[0] < best[u]) { best[u] = d[0]; bi[u] = k0 + i; }
+                if (d[1] < best[u + 1]) { best[u + 1] = d[1]; bi[u + 1] = k0 + i; }
             }
         }
     }

@@ -397,21 +397,30 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
 }
 
 // out[b][j] = sum_{i<n} in[b*batch_stride + i*stride + j]   (double accumulation; small finalisation reductions)
-// block = 64 columns x 4 row lanes, grid (ceil(W/64), nb)
-__global__ void __launch_bounds__(256) vnp_reduce_rows_kernel(const float* __restrict__ in, long long batch_stride, int n, long long stride, int W,
+// block = 64 columns x 16 row lanes (two loads in flight per lane), grid (ceil(W/64), nb): these are latency-bound, a lane's chain of
+// dependent loads is n / 32 long
+#define VNP_RR_LANES 16
+__global__ void __launch_bounds__(64 * VNP_RR_LANES) vnp_reduce_rows_kernel(const float* __restrict__ in, long long batch_stride, int n, long long stride, int W,
                                                              float* __restrict__ out, long long out_stride)
 {
-    __shared__ double red[4][64];
+    __shared__ double red[VNP_RR_LANES][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cx;
-    double s = 0.0;
+    double s = 0.0, s2 = 0.0;
     if (j < W) {
         const float* src = in + (size_t)blockIdx.y * batch_stride + j;
-        for (int i = py; i < n; i += 4) s += src[(size_t)i * stride];
+        int i = py;
+        for (; i + VNP_RR_LANES < n; i += 2 * VNP_RR_LANES) { s += src[(size_t)i * stride]; s2 += src[(size_t)(i + VNP_RR_LANES) * stride]; }
+        if (i < n) s += src[(size_t)i * stride];
     }
-    red[py][cx] = s;
+    red[py][cx] = s + s2;
     __syncthreads();
-    if (py == 0 && j < W) out[(size_t)blockIdx.y * out_stride + j] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+    if (py == 0 && j < W) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < VNP_RR_LANES; ++q) t += red[q][cx];
+        out[(size_t)blockIdx.y * out_stride + j] = (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
@@ -1303,7 +1312,7 @@ extern "C" int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long lon
                                float* out, long long out_stride)
 {
     if (!in || !out || nb <= 0 || n <= 0 || W <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(W, 64), nb), dim3(256), 0, st, in, batch_stride, n, stride, W, out, out_stride);
+    hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(W, 64), nb), dim3(64 * VNP_RR_LANES), 0, st, in, batch_stride, n, stride, W, out, out_stride);
     return vnp_last_error();
 }
 
