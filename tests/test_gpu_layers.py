@@ -506,7 +506,11 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
     part_ref = torch.empty(R // 3072, C, 2, device="cuda")
     call("vnp_vn_norm_stats", ptr(pd_ref), 2 * C, R // 3, C, ptr(part_ref), 0)
     pd = torch.empty(R, 2 * C, device="cuda")
-    part = ops.gemm_pd_stats(x, W, pd, bias, rpg, C, True)
+    keep, ops.STATS_IN_EPILOGUE = ops.STATS_IN_EPILOGUE, True          # (whatever VNP_STATS_UNFUSED says: this test is about that path)
+    try:
+        part = ops.gemm_pd_stats(x, W, pd, bias, rpg, C, True)
+    finally:
+        ops.STATS_IN_EPILOGUE = keep
     assert part is not None and torch.equal(pd, pd_ref)
     assert (part[..., 0] - part_ref[..., 0]).abs().max().item() <= 2e-6 * part_ref[..., 0].abs().max().item()
     assert (part[..., 1] - part_ref[..., 1]).abs().max().item() <= 2e-5 * part_ref[..., 1].abs().max().item()
@@ -524,7 +528,7 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
             (out * go).sum().backward()
             res.append((out.detach(), xx.grad, Wf.grad, Wd.grad, rm, rv))
         finally:
-            ops.STATS_IN_EPILOGUE = True
+            ops.STATS_IN_EPILOGUE = keep
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-12)
 
