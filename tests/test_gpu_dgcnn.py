@@ -57,6 +57,20 @@ def test_fps_matches_oracle(D):
     assert np.array_equal(ops.fps_indices(x[:, :7].cuda(), 7).cpu().numpy(), O.fps_torch(x[:, :7], 7).numpy())
 
 
+def test_fps_sizes_and_exact_ties(lib_built):
+    """Both FPS kernels (four waves per sample up to 4096 points, sixteen above) on every slots-per-thread instantiation, with
+    duplicated points (exact ties in the running distance: the smaller index must win) — against the oracle's sequential restatement."""
+    from oracle import vn_oracle as O
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for N, m in ((70, 70), (300, 37), (1000, 100), (2048, 512), (3000, 40), (4096, 64), (4097, 30), (9000, 24)):
+        x = torch.rand(2, N, 3, generator=g) - 0.5
+        x[:, N // 2] = x[:, N // 3]                               # a duplicate: two candidates always tie exactly
+        x[:, N - 1] = x[:, 1]
+        got = ops.fps_indices(x.cuda(), m, skip_near_origin=False).cpu().numpy()
+        assert np.array_equal(got, O.fps_torch(x, m, skip_near_origin=False).numpy()), (N, m)
+
+
 def test_fps_pointnet2_near_origin_convention(lib_built):
     """pointnet2_ops' kernel never selects a candidate with |p|^2 <= 1e-3 (default here; VNP_FPS_PLAIN=1 / skip_near_origin=False
     is plain FPS).  Both conventions against the oracle's restatement, on clouds seeded with near-origin points."""

@@ -302,9 +302,75 @@ __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __res
     }
 }
 
+// Clouds of up to 4096 points (every FPS call of the networks): FOUR waves per sample instead of sixteen, the cloud's coordinates in LDS
+// (the last pick's coordinates are an LDS broadcast read, not a dependent global load) and ONE barrier per round: a wave publishes its
+// (best, index) in the slot set of the round's parity and every thread reduces the four slots itself, so the next round can start
+// without a second barrier (a wave cannot get more than one round ahead of the slowest one, which is what the two slot sets cover).
+// Same arithmetic, same tie rule (largest running distance, then smallest index), same picks as the kernel above.
+#define FPS_SMALL_THREADS 256
+#define FPS_SMALL_MAXN 4096
+template <int PPT, bool SKIP>
+__global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const float* __restrict__ xyz, int N, int M, int* __restrict__ out)
+{
+    __shared__ float sx[FPS_SMALL_MAXN], sy[FPS_SMALL_MAXN], sz[FPS_SMALL_MAXN];
+    __shared__ float sv[2][FPS_SMALL_THREADS / 64];
+    __shared__ int si[2][FPS_SMALL_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = xyz + (size_t)b * N * 3;
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const int i = tid + u * FPS_SMALL_THREADS;
+        if (i < N) { px[u] = p[i * 3]; py[u] = p[i * 3 + 1]; pz[u] = p[i * 3 + 2]; md[u] = 1e10f; sx[i] = px[u]; sy[i] = py[u]; sz[i] = pz[u]; }
+        else { px[u] = py[u] = pz[u] = 0.f; md[u] = -1.f; }
+        if (SKIP && i < N && px[u] * px[u] + py[u] * py[u] + pz[u] * pz[u] <= 1e-3f) md[u] = -1.f;     // never a candidate
+    }
+    int cur = 0;
+    if (tid == 0) out[(size_t)b * M] = 0;
+    __syncthreads();
+    for (int r = 1; r < M; ++r) {
+        const float cx = sx[cur], cy = sy[cur], cz = sz[cur];
+        float best = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int i = tid + u * FPS_SMALL_THREADS;
+            if (i < N) {
+                const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
+                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                md[u] = fminf(md[u], d);                          // a skipped point stays at -1 (d >= 0)
+                if (md[u] > best) { best = md[u]; bi = i; }       // ascending i within a thread: first max kept
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int par = r & 1;
+        if ((tid & 63) == 0) { sv[par][tid >> 6] = best; si[par][tid >> 6] = bi; }
+        __syncthreads();
+        float v = sv[par][0]; int i = si[par][0];
+#pragma unroll
+        for (int w = 1; w < FPS_SMALL_THREADS / 64; ++w) {
+            const float ov = sv[par][w]; const int oi = si[par][w];
+            if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+        }
+        if (i == 0x7fffffff) i = 0;
+        if (tid == 0) out[(size_t)b * M + r] = i;
+        cur = i;
+    }
+}
+
 template <bool SKIP>
 static int vnp_fps_launch(hipStream_t st, int B, int N, const float* xyz, int M, int* idx)
 {
+    if (N <= FPS_SMALL_MAXN) {
+        if (N <= 2 * FPS_SMALL_THREADS)      hipLaunchKernelGGL((vnp_fps_small_kernel<2, SKIP>), dim3(B), dim3(FPS_SMALL_THREADS), 0, st, xyz, N, M, idx);
+        else if (N <= 4 * FPS_SMALL_THREADS) hipLaunchKernelGGL((vnp_fps_small_kernel<4, SKIP>), dim3(B), dim3(FPS_SMALL_THREADS), 0, st, xyz, N, M, idx);
+        else if (N <= 8 * FPS_SMALL_THREADS) hipLaunchKernelGGL((vnp_fps_small_kernel<8, SKIP>), dim3(B), dim3(FPS_SMALL_THREADS), 0, st, xyz, N, M, idx);
+        else                                 hipLaunchKernelGGL((vnp_fps_small_kernel<16, SKIP>), dim3(B), dim3(FPS_SMALL_THREADS), 0, st, xyz, N, M, idx);
+        return vnp_last_error();
+    }
     if (N <= 2 * FPS_THREADS)      hipLaunchKernelGGL((vnp_fps_kernel<2, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
     else if (N <= 4 * FPS_THREADS) hipLaunchKernelGGL((vnp_fps_kernel<4, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
     else if (N <= 8 * FPS_THREADS) hipLaunchKernelGGL((vnp_fps_kernel<8, SKIP>), dim3(B), dim3(FPS_THREADS), 0, st, xyz, N, M, idx);
