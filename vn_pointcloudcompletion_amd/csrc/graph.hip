@@ -341,13 +341,11 @@ __global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const 
                 if (md[u] > best) { best = md[u]; bi = i; }       // ascending i within a thread: first max kept
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
+        // wave arg-max on DPP: the largest running distance, then the smallest index among the lanes that hold it
+        const float wbest = vnp_wave_max_f32(best);
+        const int wbi = vnp_wave_min_i32(best == wbest ? bi : 0x7fffffff);
         const int par = r & 1;
-        if ((tid & 63) == 0) { sv[par][tid >> 6] = best; si[par][tid >> 6] = bi; }
+        if ((tid & 63) == 0) { sv[par][tid >> 6] = wbest; si[par][tid >> 6] = wbi; }
         __syncthreads();
         float v = sv[par][0]; int i = si[par][0];
 #pragma unroll

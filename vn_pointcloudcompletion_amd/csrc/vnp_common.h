@@ -40,3 +40,26 @@ typedef float vnp_f16 __attribute__((ext_vector_type(16)));
 //   row = point*3 + t (t = Cartesian component), channels contiguous.
 // The reference's [B, C, 3, N] tensors (models/vn_layers.py:19) map to it by
 //   rows[(b*N + n)*3 + t][c] = x[b][c][t][n].
+
+// ---- wave-wide reductions on DPP (data-parallel primitives: the operand of a VALU instruction comes from another lane at no extra
+// latency), for chains where the ~12 dependent ds_bpermute round trips of a __shfl_xor butterfly are the critical path (FPS: one
+// arg-max per round, 500+ rounds).  Four steps reduce inside each row of 16 lanes (two quad permutes, row rotations by 4 and 8), then
+// row_bcast:15 / row_bcast:31 fold the rows: lane 63 holds the result, v_readlane makes it wave-uniform.
+#ifdef __HIPCC__
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int vnp_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ float vnp_wave_max_f32(float v)
+{
+#define VNP_STEP(CTRL, MASK) v = fmaxf(v, __int_as_float(vnp_dpp_i<CTRL, MASK>(__float_as_int(v))))
+    VNP_STEP(0xB1, 0xF); VNP_STEP(0x4E, 0xF); VNP_STEP(0x124, 0xF); VNP_STEP(0x128, 0xF); VNP_STEP(0x142, 0xA); VNP_STEP(0x143, 0xC);
+#undef VNP_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int vnp_wave_min_i32(int v)
+{
+#define VNP_STEP(CTRL, MASK) v = min(v, vnp_dpp_i<CTRL, MASK>(v))
+    VNP_STEP(0xB1, 0xF); VNP_STEP(0x4E, 0xF); VNP_STEP(0x124, 0xF); VNP_STEP(0x128, 0xF); VNP_STEP(0x142, 0xA); VNP_STEP(0x143, 0xC);
+#undef VNP_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
