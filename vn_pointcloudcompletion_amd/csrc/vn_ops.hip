@@ -1082,6 +1082,10 @@ struct VnpEdgeArgs {
 template <int MODE>
 __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a)
 {
+    // the backward modes use v_rcp_f32 / v_sqrt_f32 (1 ulp each) as the other gradient kernels do; the forward modes keep IEEE division
+    // and sqrtf, so statistics and outputs stay bit-identical to the materialising path
+#define EDIV(x, y) (MODE >= 2 ? (x) * __builtin_amdgcn_rcpf(y) : (x) / (y))
+#define ESQRT(x) (MODE >= 2 ? __builtin_amdgcn_sqrtf(x) : sqrtf(x))
     __shared__ float2 red[4][64];
     __shared__ int cnt[4];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
@@ -1111,7 +1115,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             const size_t urow = (size_t)nb[j] * 3;
             const float* ru = a.u + urow * a.ldu + cc;
             const float x0 = ru[0] + vp0, x1 = ru[a.ldu] + vp1, x2 = ru[2 * a.ldu] + vp2;
-            const float pn = sqrtf(vnp_sq3(x0, x1, x2));
+            const float pn = ESQRT(vnp_sq3(x0, x1, x2));
             const float n = pn + VNP_EPS;
             if (MODE == 0) {
                 ++wn;
@@ -1123,7 +1127,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             const float d0 = ru[C] + vd0, d1 = ru[a.ldu + C] + vd1, d2 = ru[2 * a.ldu + C] + vd2;
             const float xh = (n - mu) * rs;
             const float nh = xh * ga + be;
-            const float s = nh / n;
+            const float s = EDIV(nh, n);
             const float y0 = x0 * s, y1 = x1 * s, y2 = x2 * s;                             // q = bn(p)
             const float dot = y0 * d0 + y1 * d1 + y2 * d2;
             if (MODE == 1) {
@@ -1138,7 +1142,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             float g0 = ge0, g1 = ge1, g2 = ge2, e0 = 0.f, e1 = 0.f, e2 = 0.f;
             if (dot < 0.f) {
                 const float cf = 1.f - a.ns;
-                const float inv = 1.f / (vnp_sq3(d0, d1, d2) + VNP_EPS);
+                const float inv = EDIV(1.f, vnp_sq3(d0, d1, d2) + VNP_EPS);
                 const float al = dot * inv;
                 const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
                 const float k1 = cf * gdd * inv;
@@ -1148,10 +1152,10 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
                 g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;
             }
             const float gs = g0 * x0 + g1 * x1 + g2 * x2;
-            const float gnh = gs / n;
+            const float gnh = EDIV(gs, n);
             if (MODE == 2) { s1 += gnh; s2 += gnh * xh; continue; }
-            const float gn = ga * rs * (gnh - m1 - xh * m2) - gs * nh / (n * n);
-            const float kk = pn > 0.f ? gn / pn : 0.f;
+            const float gn = ga * rs * (gnh - m1 - xh * m2) - EDIV(gs * nh, n * n);
+            const float kk = pn > 0.f ? EDIV(gn, pn) : 0.f;
             const float f0 = s * g0 + kk * x0, f1 = s * g1 + kk * x1, f2 = s * g2 + kk * x2;   // dL/dp of this edge
             o0 += f0; o1 += f1; o2 += f2; h0 += e0; h1 += e1; h2 += e2;
             if (live) {
@@ -1193,6 +1197,8 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
         }
     }
 }
+#undef EDIV
+#undef ESQRT
 
 // ================================================================================================ C-ABI
 static inline dim3 vnp_grid_pc(long long P, int C, int chunk) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, chunk)); }
