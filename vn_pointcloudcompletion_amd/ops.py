@@ -375,6 +375,29 @@ def _wgrad(gy, x):
 
 
 # ------------------------------------------------------------------------------- autograd Functions
+class SplitColsFn(Function):
+    """W[:, 0:n0], W[:, n0:n0+n1], ... as views, with ONE concatenation as the backward: autograd's own slicing gives every slice a
+    zero-filled full-size gradient, a copy into it and an add per extra slice (a weight whose input channels are split between a
+    per-sample part and a per-point part — models/pcn.py:172, 375-385 — cost 5-8 small launches per step that way)."""
+
+    @staticmethod
+    def forward(ctx, W, *sizes):
+        if W.dim() != 2 or sum(sizes) != W.shape[1]:
+            raise _lib.VnpError(f"split_cols: sizes {sizes} do not cover {tuple(W.shape)}")
+        ctx.sizes, ctx.rows = sizes, W.shape[0]
+        return tuple(torch.split(W, list(sizes), dim=1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        parts = [g if g is not None else ref.new_zeros((ctx.rows, n)) for g, n in zip(gs, ctx.sizes)]
+        return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)
+
+
+def split_cols(W, *sizes):
+    return SplitColsFn.apply(W, *sizes)
+
+
 class ToRowsFn(Function):
     """reference layout [B, C, 3, N] -> rows [(B*N)*3, C]."""
 

@@ -138,10 +138,12 @@ class VNLinearLeakyReLU(nn.Module):
         if global_rows is not None:
             cg = global_rows.shape[1]
             cx = Wf.shape[1] - cg
-            gsl, xsl = (slice(0, cg), slice(cg, None)) if global_first else (slice(cx, None), slice(0, cx))
-            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wf[:, gsl], None, 0),
-                              ops.VNLinearFn.apply(global_rows, Wd[:, gsl], None, 0)], dim=1)
-            Wf, Wd = Wf[:, xsl], Wd[:, xsl]
+            if global_first:
+                (Wfg, Wf), (Wdg, Wd) = ops.split_cols(Wf, cg, cx), ops.split_cols(Wd, cg, cx)
+            else:
+                (Wf, Wfg), (Wd, Wdg) = ops.split_cols(Wf, cx, cg), ops.split_cols(Wd, cx, cg)
+            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
+                              ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                          rows_per_group, self.training, self.negative_slope)
 
