@@ -84,15 +84,39 @@ __global__ void __launch_bounds__(EMD_T) emd_pass_b_kernel(int n, int m, const f
 }
 
 // pass (c): match[l][k] += exp(level*d)*ratioL[k]*ratioR[l]; remainL[k] = max(0, remainL[k] - sum_l w)     :121-154
-__global__ void __launch_bounds__(EMD_T) emd_pass_c_kernel(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                          float* __restrict__ temp, float* __restrict__ match, float level)
+// Two launches: the match update is a read-modify-write of the whole [m][n] matrix (128 MB of traffic per level at B = 16, n = m = 1024) and
+// wants every CU — a workgroup per (tile of k, chunk of EMD_LCH rows l, sample); the row sums that drain remainL are a reduction over
+// all l per k and keep the one-thread-per-k form (and the l order) of the other passes.  As ONE kernel of n / 256 x B workgroups with
+// 1024 dependent read-modify-writes per thread the pass took 252 us per level; the weights w are the same expression in both kernels
+// (no contraction), so match and remainL have the bits of the single-kernel form.
+#define EMD_LCH 32
+__global__ void __launch_bounds__(EMD_T) emd_pass_c_match_kernel(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                                const float* __restrict__ temp, float* __restrict__ match, float level)
 {
+#pragma clang fp contract(off)
+    const int b = blockIdx.z, k = blockIdx.x * EMD_T + threadIdx.x;
+    if (k >= n) return;
+    const float* t = temp + (size_t)b * (n + m) * 2;
+    const float* ratioL = t + n + m; const float* ratioR = t + n + m + n;
+    const float* p1 = xyz1 + (size_t)b * n * 3; const float* p2 = xyz2 + (size_t)b * m * 3;
+    float* mt = match + (size_t)b * n * m;
+    const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2], rl = ratioL[k];
+    const int l0 = blockIdx.y * EMD_LCH, l1 = min(m, l0 + EMD_LCH);
+    for (int l = l0; l < l1; ++l) {                              // p2[l], ratioR[l]: wave-uniform (scalar) loads
+        const float w = __expf(level * emd_d2(x1, y1, z1, p2[l * 3], p2[l * 3 + 1], p2[l * 3 + 2])) * rl * ratioR[l];
+        mt[(size_t)l * n + k] += w;
+    }
+}
+
+__global__ void __launch_bounds__(EMD_T) emd_pass_c_sum_kernel(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                              float* __restrict__ temp, float level)
+{
+#pragma clang fp contract(off)
     __shared__ float4 buf[EMD_TILE];
     const int b = blockIdx.y, k = blockIdx.x * EMD_T + threadIdx.x;
     float* t = temp + (size_t)b * (n + m) * 2;
     float* remainL = t; const float* ratioL = t + n + m; const float* ratioR = t + n + m + n;
     const float* p1 = xyz1 + (size_t)b * n * 3; const float* p2 = xyz2 + (size_t)b * m * 3;
-    float* mt = match + (size_t)b * n * m;
     float x1 = 0, y1 = 0, z1 = 0, rl = 0;
     if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratioL[k]; }
     float suml = 0;
@@ -102,13 +126,10 @@ __global__ void __launch_bounds__(EMD_T) emd_pass_c_kernel(int n, int m, const f
         for (int l = threadIdx.x; l < lend; l += EMD_T)
             buf[l] = make_float4(p2[(l0 + l) * 3], p2[(l0 + l) * 3 + 1], p2[(l0 + l) * 3 + 2], ratioR[l0 + l]);
         __syncthreads();
-        if (k < n) {
-            for (int l = 0; l < lend; ++l) {
-                const float4 q = buf[l];
-                const float w = __expf(level * emd_d2(x1, y1, z1, q.x, q.y, q.z)) * rl * q.w;
-                mt[(size_t)(l0 + l) * n + k] += w;
-                suml += w;
-            }
+        for (int l = 0; l < lend; ++l) {
+            const float4 q = buf[l];
+            const float w = __expf(level * emd_d2(x1, y1, z1, q.x, q.y, q.z)) * rl * q.w;
+            suml += w;
         }
     }
     if (k < n) remainL[k] = fmaxf(0.0f, remainL[k] - suml);
@@ -200,7 +221,7 @@ __global__ void __launch_bounds__(256) emd_grad2_kernel(int n, int m, const floa
 // emd_cuda.approxmatch_forward(xyz1[B,n,3], xyz2[B,m,3]) -> match[B,m,n]  (emd.cpp:8-13); temp: B*(n+m)*2 floats
 extern "C" int vnp_emd_approxmatch(hipStream_t st, int B, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp)
 {
-    if (!xyz1 || !xyz2 || !match || !temp || B <= 0 || n <= 0 || m <= 0 || B > 65535) return VNP_EINVAL;
+    if (!xyz1 || !xyz2 || !match || !temp || B <= 0 || n <= 0 || m <= 0 || B > 65535 || vnp_cdiv(m, EMD_LCH) > 65535) return VNP_EINVAL;
     hipError_t e = hipMemsetAsync(match, 0, (size_t)B * n * m * 4, st);
     if (e != hipSuccess) return (int)e;
     const float multiL = n >= m ? 1.f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.f;      // integer division, :29-35
@@ -209,7 +230,9 @@ extern "C" int vnp_emd_approxmatch(hipStream_t st, int B, int n, int m, const fl
         const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
         hipLaunchKernelGGL(emd_pass_a_kernel, dim3(vnp_cdiv(n, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
         hipLaunchKernelGGL(emd_pass_b_kernel, dim3(vnp_cdiv(m, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
-        hipLaunchKernelGGL(emd_pass_c_kernel, dim3(vnp_cdiv(n, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, match, level);
+        hipLaunchKernelGGL(emd_pass_c_match_kernel, dim3(vnp_cdiv(n, EMD_T), vnp_cdiv(m, EMD_LCH), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2,
+                           (const float*)temp, match, level);
+        hipLaunchKernelGGL(emd_pass_c_sum_kernel, dim3(vnp_cdiv(n, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
     }
     return vnp_last_error();
 }
