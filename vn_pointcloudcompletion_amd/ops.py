@@ -209,6 +209,8 @@ def reduce_rows(part, nb, n, W):
     """part: contiguous [nb][n][W] partials -> [nb][W] (sum over n; two passes when n is large so that no thread
     walks more than a few hundred partials)."""
     dev = part.device
+    if n == 1:
+        return part.reshape(nb, W)
     if n > 1024:
         # first level over chunks of m partials, m the largest divisor of n in [16, 512] (n = 1248 -> 416); a count without
         # such a divisor (a large prime) is reduced in one level, which is only slower
@@ -232,6 +234,8 @@ def _per_sample_colsum(g, rows_per_group):
     nch = _nchunk(npts)
     part = torch.empty((nb, nch, 3 * W), device=g.device, dtype=torch.float32)
     call("vnp_colsum", ptr(g), rows_per_group * W, 3 * W, nb, npts, 3 * W, None, ptr(part))
+    if nch == 1:                                  # one chunk per group: the partials are the result (16384 groups of 16 points in config 4)
+        return part.view(nb * 3, W)
     out = torch.empty((nb * 3, W), device=g.device, dtype=torch.float32)
     call("vnp_reduce_rows", ptr(part), nb, nch * 3 * W, nch, 3 * W, 3 * W, ptr(out), 3 * W)
     return out
