@@ -200,6 +200,16 @@ def test_degenerate_shapes_take_streaming_kernels():
     assert relerr(out[:, N:], ref + a.double() @ w.double().t()) < 1e-6
     wn = _mk(1, N, seed=44)                                            # B as [K, N] (op_b = 1)
     assert relerr(ops.gemm(a, wn, op_b=1), a.double() @ wn.double()) < 1e-6
+    # the same through the 16-byte-store form (N % 4 == 0, aligned slice), groups shorter than a workgroup's 64 rows
+    M4, N4, rpg = 11 * 48 + 48, 72, 48
+    a4, w4, b4 = _mk(M4, 1, seed=51), _mk(N4, 1, seed=52), _mk(M4 // rpg * 3, N4, seed=53)
+    out4 = torch.zeros(M4, 2 * N4, device="cuda")
+    ops.gemm(a4, w4, out=out4[:, N4:], bias=b4, rows_per_group=rpg)
+    r4 = torch.arange(M4, device="cuda")
+    ref4 = a4.double() @ w4.double().t() + b4.double()[(r4 // rpg) * 3 + r4 % 3]
+    assert relerr(out4[:, N4:], ref4) < 1e-6 and out4[:, :N4].abs().max().item() == 0.0
+    ops.gemm(a4, w4, out=out4[:, N4:], accumulate=True)
+    assert relerr(out4[:, N4:], ref4 + a4.double() @ w4.double().t()) < 1e-6
     # matrix-vector, both B layouts
     A = _mk(5000, 512, seed=45)
     v = _mk(1, 512, seed=46)

@@ -84,16 +84,49 @@ __global__ void __launch_bounds__(256) vnp_reduce_slabs_kernel(const float* __re
 // kernels, not tensor-core work (the MFMA kernel spends a full 32-deep K tile on them: 0.95 ms instead of 0.4 for the 1.6 GB
 // outer product of config 4).
 // C[r][c] (+)= a[r] * b[c] (+ per-sample VN bias)
+// VEC4 (N % 4 == 0, unit-stride b, 16-byte aligned C / bias rows): a thread owns four consecutive columns: 16-byte stores, a wave writes 1 KB per row
+template <bool VEC4>
 __global__ void __launch_bounds__(256) vnp_gemm_rank1_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, long long bstride,
                                                             float* __restrict__ C, int ldc, int M, int N, const float* __restrict__ bias,
                                                             int ldbias, int rows_per_group, int accumulate)
 {
+    if (VEC4) {
+        const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+        if (c >= N) return;
+        const vnp_f4 bv = *(const vnp_f4*)(B + c);
+        const int r0 = blockIdx.y * 64 + (threadIdx.x >> 6), r1 = min(M, (int)(blockIdx.y + 1) * 64);
+        int grp = 0, rem = 0, t = 0;
+        if (bias) { grp = r0 / rows_per_group; rem = r0 - grp * rows_per_group; t = r0 % 3; }
+        for (int r = r0; r < r1; r += 4) {
+            vnp_f4 v = A[(size_t)r * lda] * bv;
+            if (bias) {
+                v += *(const vnp_f4*)(bias + (size_t)(grp * 3 + t) * ldbias + c);
+                rem += 4; t += 1;
+                while (rem >= rows_per_group) { rem -= rows_per_group; ++grp; }
+                if (t >= 3) t -= 3;
+            }
+            vnp_f4* dst = (vnp_f4*)(C + (size_t)r * ldc + c);
+            if (accumulate) v += *dst;
+            __builtin_nontemporal_store(v, dst);
+        }
+        return;
+    }
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     if (c >= N) return;
     const float bv = B[(size_t)c * bstride];
-    for (long long r = (long long)blockIdx.y * 64 + (threadIdx.x >> 6); r < M && r < ((long long)blockIdx.y + 1) * 64; r += 4) {
+    // a thread's rows are r0, r0 + 4, ...: group index and component advance incrementally (one 32-bit division per thread instead of a
+    // 64-bit division and a modulo per element: the kernel is a pure 0.8 GB store stream in config 4 and ran at half the store rate)
+    const int r0 = blockIdx.y * 64 + (threadIdx.x >> 6), r1 = min(M, (int)(blockIdx.y + 1) * 64);
+    int grp = 0, rem = 0, t = 0;
+    if (bias) { grp = r0 / rows_per_group; rem = r0 - grp * rows_per_group; t = r0 % 3; }
+    for (int r = r0; r < r1; r += 4) {
         float v = A[(size_t)r * lda] * bv;
-        if (bias) v += bias[(size_t)((r / rows_per_group) * 3 + r % 3) * ldbias + c];
+        if (bias) {
+            v += bias[(size_t)(grp * 3 + t) * ldbias + c];
+            rem += 4; t += 1;                                  // (r + 4) % 3 = (r % 3 + 1) % 3
+            while (rem >= rows_per_group) { rem -= rows_per_group; ++grp; }
+            if (t >= 3) t -= 3;
+        }
         float* dst = C + (size_t)r * ldc + c;
         if (accumulate) v += *dst;
         __builtin_nontemporal_store(v, dst);
@@ -158,8 +191,13 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     if (nbatch == 1 && K >= 1) {
         // outer product: A [M,1] (op_a = 0) x b [N]
         if (K == 1 && op_a == 0 && M <= 2147483647 / 2) {
-            hipLaunchKernelGGL(vnp_gemm_rank1_kernel, dim3(vnp_cdiv(N, 64), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B,
-                               (long long)(op_b == 0 ? ldb : 1), C, ldc, M, N, bias, ldbias, rows_per_group > 0 ? rows_per_group : 1, accumulate);
+            const long long bstr = op_b == 0 ? ldb : 1;
+            const bool v4 = bstr == 1 && N % 4 == 0 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && (uintptr_t)B % 16 == 0 &&
+                            (!bias || (ldbias % 4 == 0 && (uintptr_t)bias % 16 == 0));
+            if (v4) hipLaunchKernelGGL(vnp_gemm_rank1_kernel<true>, dim3(vnp_cdiv(N, 256), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B, bstr,
+                                       C, ldc, M, N, bias, ldbias, rows_per_group > 0 ? rows_per_group : 1, accumulate);
+            else hipLaunchKernelGGL(vnp_gemm_rank1_kernel<false>, dim3(vnp_cdiv(N, 64), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B, bstr,
+                                    C, ldc, M, N, bias, ldbias, rows_per_group > 0 ? rows_per_group : 1, accumulate);
             return vnp_last_error();
         }
         // matrix-vector: A [M,K] K-contiguous, one output column
