@@ -566,3 +566,19 @@ def test_fold_layer0_fused_equals_unfused(lib_built, B, Mc, S, C, batched, train
         if not training and n in ("g_gamma", "g_beta"):
             continue
         assert relerr(a, b) < (2e-6 if n in ("out", "running_mean", "running_var") else 3e-5), (n, relerr(a, b))
+
+
+@pytest.mark.parametrize("nb,npts,W,weighted", [(300, 16, 96, False), (64, 5, 40, True), (3, 2000, 72, False), (100, 128, 64, True), (70, 129, 64, False)])
+def test_colsum_short_and_long_groups(lib_built, nb, npts, W, weighted):
+    """vnp_colsum: per-group column sums of [nb][npts][W] (optionally weighted per row) — the wave-per-group kernel for short groups
+    (<= 128 rows, >= 64 groups) and the chunked one otherwise — against torch in float64."""
+    from vn_pointcloudcompletion_amd import _lib
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(nb + npts)
+    x = torch.randn(nb, npts, W, generator=g).cuda()
+    w = torch.randn(nb, npts, generator=g).cuda() if weighted else None
+    nch = (npts + _lib.chunk_points() - 1) // _lib.chunk_points()
+    part = torch.zeros(nb, nch, W, device="cuda")
+    call("vnp_colsum", ptr(x), npts * W, W, nb, npts, W, ptr(w) if weighted else None, ptr(part))
+    ref = (x.double() * (w.double()[..., None] if weighted else 1.0)).sum(1)
+    assert relerr(part.sum(1), ref) < 2e-6

@@ -141,7 +141,14 @@ __global__ void __launch_bounds__(256) vnp_gemm_matvec_kernel(const float* __res
     if (r >= M) return;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
-    for (int k = lane; k < K; k += 64) s = fmaf(__builtin_nontemporal_load(&A[(size_t)r * lda + k]), B[(size_t)k * bstride], s);
+    if (bstride == 1 && (K & 3) == 0 && (lda & 3) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0) {          // 16-byte loads: 1 KB per wave and step
+        for (int k = lane * 4; k < K; k += 256) {
+            const vnp_f4 av = __builtin_nontemporal_load((const vnp_f4*)(A + (size_t)r * lda + k));
+            const vnp_f4 bv = *(const vnp_f4*)(B + k);
+            s = fmaf(av[3], bv[3], fmaf(av[2], bv[2], fmaf(av[1], bv[1], fmaf(av[0], bv[0], s))));
+        }
+    } else
+        for (int k = lane; k < K; k += 64) s = fmaf(__builtin_nontemporal_load(&A[(size_t)r * lda + k]), B[(size_t)k * bstride], s);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) C[(size_t)r * ldc] = accumulate ? C[(size_t)r * ldc] + s : s;

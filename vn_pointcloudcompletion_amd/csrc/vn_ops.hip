@@ -1455,6 +1455,27 @@ extern "C" int vnp_group_sum3(hipStream_t st, const float* in, long long Pc, int
     return vnp_last_error();
 }
 
+// short groups (R <= 128 rows: 16 grid samples per coarse point in the attention decoder, 16384 groups): a WAVE per group, four groups
+// per workgroup — one workgroup per group left three of its four row lanes idle on every second load (0.3 TB/s)
+__global__ void __launch_bounds__(256) vnp_colsum_small_kernel(const float* __restrict__ X, long long batch_stride, long long row_stride,
+                                                              int nb, int R, int C, const float* __restrict__ w, float* __restrict__ partial)
+{
+    const int cx = threadIdx.x & 63, g = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int c = blockIdx.x * 64 + cx;
+    if (g >= nb || c >= C) return;
+    const float* base = X + (size_t)g * batch_stride + c;
+    const float* ww = w ? w + (size_t)g * R : nullptr;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int r = 0;
+    for (; r + 3 < R; r += 4) {
+        const float x0 = __builtin_nontemporal_load(&base[(size_t)r * row_stride]), x1 = __builtin_nontemporal_load(&base[(size_t)(r + 1) * row_stride]);
+        const float x2 = __builtin_nontemporal_load(&base[(size_t)(r + 2) * row_stride]), x3 = __builtin_nontemporal_load(&base[(size_t)(r + 3) * row_stride]);
+        t0 += x0 * (ww ? ww[r] : 1.f); t1 += x1 * (ww ? ww[r + 1] : 1.f); t2 += x2 * (ww ? ww[r + 2] : 1.f); t3 += x3 * (ww ? ww[r + 3] : 1.f);
+    }
+    for (; r < R; ++r) t0 += __builtin_nontemporal_load(&base[(size_t)r * row_stride]) * (ww ? ww[r] : 1.f);
+    partial[(size_t)g * C + c] = (t0 + t1) + (t2 + t3);
+}
+
 // partial: [nb][ceil(R / vnp_chunk_points())][C]
 extern "C" int vnp_colsum(hipStream_t st, const float* X, long long batch_stride, long long row_stride, int nb, long long R, int C,
                           const float* w, float* partial)
@@ -1462,6 +1483,11 @@ extern "C" int vnp_colsum(hipStream_t st, const float* X, long long batch_stride
     if (!X || !partial || nb <= 0 || R <= 0 || C <= 0 || nb > 65535) return VNP_EINVAL;
     const int nchunk = vnp_cdiv(R, VNP_CHUNK);
     if (nchunk > 65535) return VNP_EINVAL;
+    if (R <= 128 && nb >= 64) {
+        hipLaunchKernelGGL(vnp_colsum_small_kernel, dim3(vnp_cdiv(C, 64), vnp_cdiv(nb, 4)), dim3(256), 0, st, X, batch_stride, row_stride, nb, (int)R, C, w,
+                           partial);
+        return vnp_last_error();
+    }
     hipLaunchKernelGGL(vnp_colsum_kernel, dim3(vnp_cdiv(C, 64), nchunk, nb), dim3(256), 0, st, X, batch_stride, row_stride, R, C, w, nchunk, partial);
     return vnp_last_error();
 }
