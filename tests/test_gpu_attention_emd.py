@@ -188,3 +188,23 @@ def test_pcnnet_config4_step(lib_built):
     loss, l1, l2 = train_step(cfg, net, opt, p, c)
     assert torch.isfinite(loss) and l1.item() > 0 and l2.item() > 0
     assert not torch.equal(before, net.decoder.vn_folding2[2].map_to_feat.weight)
+
+
+@pytest.mark.parametrize("L", [64, 128, 256, 512, 1024, 2048, 192, 4096])
+def test_softmax_rows_forward_backward(lib_built, L):
+    """vnp_softmax_fwd / vnp_softmax_bwd (the register-resident kernels for rows of 128 ... 2048 elements, the streaming ones otherwise)
+    against torch in float64: P = softmax(S * scale), dS = P * (dP - sum dP P) * scale."""
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(L)
+    R, scale = 37, 0.37
+    S = (torch.randn(R, L, generator=g) * 3).cuda()
+    dP = torch.randn(R, L, generator=g).cuda()
+    Sd = S.double().requires_grad_(True)
+    Pd = (Sd * scale).softmax(-1)
+    Pd.backward(dP.double())
+    P = S.clone()
+    call("vnp_softmax_fwd", ptr(P), R, L, scale)
+    assert (P.double() - Pd.detach()).abs().max().item() < 2e-7
+    dS = dP.clone()
+    call("vnp_softmax_bwd", ptr(P), ptr(dS), R, L, scale)
+    assert (dS.double() - Sd.grad).abs().max().item() < 5e-7 * max(1.0, Sd.grad.abs().max().item())

@@ -114,6 +114,46 @@ __global__ void vnp_heads_to_rows_kernel(const float* __restrict__ heads, int B,
     }
 }
 
+// rows of up to 2048 elements (L % 64 == 0) stay in registers between the passes: one read and one write of the matrix instead of three
+// reads and two writes; same element-to-lane assignment and summation order as the streaming form below
+template <int NV>
+__global__ void __launch_bounds__(256) vnp_softmax_fwd_reg_kernel(float* __restrict__ S, long long R, float scale)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    float* row = S + (size_t)r * (NV * 64);
+    float v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = __builtin_nontemporal_load(&row[lane + 64 * i]) * scale; mx = fmaxf(mx, v[i]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = expf(v[i] - mx); s += v[i]; }
+    const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) row[lane + 64 * i] = v[i] * inv;
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) vnp_softmax_bwd_reg_kernel(const float* __restrict__ Pm, float* __restrict__ dP, long long R, float scale)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* p = Pm + (size_t)r * (NV * 64);
+    float* d = dP + (size_t)r * (NV * 64);
+    float pv[NV], dv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { pv[i] = __builtin_nontemporal_load(&p[lane + 64 * i]); dv[i] = __builtin_nontemporal_load(&d[lane + 64 * i]); s += dv[i] * pv[i]; }
+    s = wave_sum(s);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) d[lane + 64 * i] = pv[i] * (dv[i] - s) * scale;
+}
+
 // in-place row softmax of S[R][L] * scale; one wave per row
 __global__ void __launch_bounds__(256) vnp_softmax_fwd_kernel(float* __restrict__ S, long long R, int L, float scale)
 {
@@ -184,13 +224,27 @@ extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int 
 extern "C" int vnp_softmax_fwd(hipStream_t st, float* S, long long R, int L, float scale)
 {
     if (!S || R <= 0 || L <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_softmax_fwd_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, S, R, L, scale);
+#define VNP_SM_FWD(NV) hipLaunchKernelGGL((vnp_softmax_fwd_reg_kernel<NV>), dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, S, R, scale)
+    if (L == 64 * 16) VNP_SM_FWD(16);
+    else if (L == 64 * 8) VNP_SM_FWD(8);
+    else if (L == 64 * 4) VNP_SM_FWD(4);
+    else if (L == 64 * 2) VNP_SM_FWD(2);
+    else if (L == 64 * 32) VNP_SM_FWD(32);
+    else hipLaunchKernelGGL(vnp_softmax_fwd_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, S, R, L, scale);
+#undef VNP_SM_FWD
     return vnp_last_error();
 }
 
 extern "C" int vnp_softmax_bwd(hipStream_t st, const float* Pm, float* dP, long long R, int L, float scale)
 {
     if (!Pm || !dP || R <= 0 || L <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_softmax_bwd_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, Pm, dP, R, L, scale);
+#define VNP_SM_BWD(NV) hipLaunchKernelGGL((vnp_softmax_bwd_reg_kernel<NV>), dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, Pm, dP, R, scale)
+    if (L == 64 * 16) VNP_SM_BWD(16);
+    else if (L == 64 * 8) VNP_SM_BWD(8);
+    else if (L == 64 * 4) VNP_SM_BWD(4);
+    else if (L == 64 * 2) VNP_SM_BWD(2);
+    else if (L == 64 * 32) VNP_SM_BWD(32);
+    else hipLaunchKernelGGL(vnp_softmax_bwd_kernel, dim3(vnp_cdiv(R, 4)), dim3(256), 0, st, Pm, dP, R, L, scale);
+#undef VNP_SM_BWD
     return vnp_last_error();
 }
