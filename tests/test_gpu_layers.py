@@ -317,8 +317,8 @@ def test_screened_pool_backs_off_after_a_fallback(lib_built):
     W, Wd = (torch.randn(C, K, generator=g) / K ** 0.5).cuda(), (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
     key = (torch.cuda.current_device(), G, gs, C, K)
     ops._screen_state.pop(key, None)
-    old = ops.POOL_SCREEN_BACKOFF
-    ops.POOL_SCREEN_BACKOFF = 3
+    old, old_k = ops.POOL_SCREEN_BACKOFF, ops.POOL_SCREEN_MIN_K
+    ops.POOL_SCREEN_BACKOFF, ops.POOL_SCREEN_MIN_K = 3, 0          # (a K this small takes the full epilogue by default)
     try:
         paths = []
         for _ in range(7):
@@ -329,7 +329,7 @@ def test_screened_pool_backs_off_after_a_fallback(lib_built):
             paths.append("screened" if "linear_pool_screened" in tr else "full")
         assert paths == ["screened", "full", "full", "full", "screened", "full", "full"], paths
     finally:
-        ops.POOL_SCREEN_BACKOFF, ops.TRACE = old, None
+        ops.POOL_SCREEN_BACKOFF, ops.POOL_SCREEN_MIN_K, ops.TRACE = old, old_k, None
         ops._screen_state.pop(key, None)
 
 
@@ -477,6 +477,51 @@ def test_linear_pool_tap_fused_equals_linear_then_tap(lib_built, G, gs, C, K):
     assert torch.equal(res[True][0].view(torch.int32), res[False][0].view(torch.int32))
     assert torch.equal(res[True][1].view(torch.int32), res[False][1].view(torch.int32))
     assert relerr(res[True][3], res[False][3]) < 1e-6 and relerr(res[True][4], res[False][4]) < 1e-6
+
+
+@pytest.mark.parametrize("B,N,Mc", [(2, 256, 64), (2, 2048, 128)])
+def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
+    """VN_PointNet with second_conv[0] folded onto first_conv[1]'s input channels ((W2 W1) a, ops.ENC_LINEAR_REASSOCIATE: the 512-channel
+    map is never stored) against the evaluation order of models/pcn.py:168-173 (W2 (W1 a), VNP_ENC_AS_WRITTEN=1): same arg-max
+    choices, outputs equal to fp32 re-association noise (1e-5 of the largest element), every parameter gradient equal to 1e-4 of its largest element (worst tensors: the
+    ill-conditioned first_conv[0] directions, see test_gpu_e2e.py)."""
+    from types import SimpleNamespace
+    from vn_pointcloudcompletion_amd import ops
+    from vn_pointcloudcompletion_amd.pcn import VN_PointNet
+    torch.manual_seed(5)
+    enc = VN_PointNet(SimpleNamespace(num_coarse=Mc), latent_dim=256).cuda().train()
+    sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
+    g = torch.Generator().manual_seed(B * N)
+    xyz = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    cot_c, cot_g = torch.randn(B, Mc, 3, generator=g).cuda(), torch.randn(B, 512, 3, 1, generator=g).cuda()
+    res = {}
+    keep = ops.ENC_LINEAR_REASSOCIATE
+    try:
+        for mode in (True, False):
+            ops.ENC_LINEAR_REASSOCIATE = mode
+            enc.load_state_dict(sd0)
+            enc.zero_grad(set_to_none=True)
+            ops.TRACE = tr = {}
+            coarse, fg = enc(xyz)
+            ((coarse * cot_c).sum() + (fg * cot_g).sum()).backward()
+            ops.TRACE = None
+            assert (tr.get("linear_folded_onto_producer", 0) == 1) == mode, tr
+            res[mode] = (coarse.detach(), fg.detach(), [i.clone() for i in tr["pool_idx"]],
+                         {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in enc.state_dict().items() if "running" in k})
+    finally:
+        ops.ENC_LINEAR_REASSOCIATE, ops.TRACE = keep, None
+    for a, b in zip(res[True][2], res[False][2]):
+        assert torch.equal(a, b)                                  # same arg-max points in both pools
+    eo = (relerr(res[True][0], res[False][0]), relerr(res[True][1], res[False][1]))
+    assert res[True][3].keys() == res[False][3].keys()
+    eg = sorted(((relerr(gr, res[False][3][k]), k) for k, gr in res[True][3].items()), reverse=True)
+    print(f"coarse {eo[0]:.1e}, global feature {eo[1]:.1e}; worst gradients: " + ", ".join(f"{k} {e:.1e}" for e, k in eg[:3]))
+    assert max(eo) < 1e-5, eo               # fp32 re-association noise behind two BatchNorm layers over B*N norms
+    for e, k in eg:
+        assert e < 1e-4, (k, e)
+    for k, v in res[True][4].items():
+        assert relerr(v, res[False][4][k]) < 1e-6, k
 
 
 @pytest.mark.parametrize("nb,n,W", [(3, 1248, 40), (2, 2048, 64), (2, 1031, 16), (1, 7, 5), (4, 4992, 24)])

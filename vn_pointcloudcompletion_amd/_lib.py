@@ -43,6 +43,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 and all(os.path.getmtime(o) >= os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+        cmd += os.environ.get("VNP_EXTRA_HIPCC_FLAGS", "").split()          # measurement builds (-DVNP_EXPERIMENT_...)
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

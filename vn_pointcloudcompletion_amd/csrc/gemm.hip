@@ -46,30 +46,41 @@ static int vnp_num_cus()
     return n;
 }
 
+// VNP_GEMM_NO_XCD_SPLIT=1: split-K items in (slice, tile) order as before (A/B measurement of VnpGemmArgs::xcd_split)
+static bool vnp_no_xcd_split()
+{
+    static const bool v = getenv("VNP_GEMM_NO_XCD_SPLIT") != nullptr;
+    return v;
+}
+
 // out[r][c] (+)= sum_z ws[z][r][c]; ws slabs are dense [M, N].  A workgroup = 64 consecutive outputs x 4 slab lanes: lane q sums the
 // slabs z = q, q + 4, ... with four loads in flight, the four partial sums meet in LDS in a fixed order (deterministic).  (One thread
 // per output walking all nsplit slabs was a dependent chain of up to 256 loads: 19 us per call at 1 TB/s, 109 calls per step in config 5.)
+// The slabs are summed in DOUBLE (the kernel is bound by its loads): a weight gradient over 10^5 - 10^6 rows then carries the fp32
+// rounding of its K-slices only, which average out over the slabs, instead of another sqrt(nsplit) 2^-24 of the running total —
+// it matters where the gradient is multiplied on into a cancelling product (ops.WeightProductFn).
 __global__ void __launch_bounds__(256) vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit, long long slab, float* __restrict__ C,
                                                                int M, int N, int ldc, int accumulate)
 {
-    __shared__ float part[4][64];
+    __shared__ double part[4][64];
     const long long total = (long long)M * N;
     const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
         const long long i = base + ox;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (i < total) {
             const float* src = ws + i;
             int z = q;
             for (; z + 12 < nsplit; z += 16) {
-                s0 += src[(size_t)z * slab]; s1 += src[(size_t)(z + 4) * slab]; s2 += src[(size_t)(z + 8) * slab]; s3 += src[(size_t)(z + 12) * slab];
+                const float v0 = src[(size_t)z * slab], v1 = src[(size_t)(z + 4) * slab], v2 = src[(size_t)(z + 8) * slab], v3 = src[(size_t)(z + 12) * slab];
+                s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
             }
-            for (; z < nsplit; z += 4) s0 += src[(size_t)z * slab];
+            for (; z < nsplit; z += 4) s0 += (double)src[(size_t)z * slab];
         }
         part[q][ox] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (q == 0 && i < total) {
-            const float s = (part[0][ox] + part[1][ox]) + (part[2][ox] + part[3][ox]);
+            const float s = (float)((part[0][ox] + part[1][ox]) + (part[2][ox] + part[3][ox]));
             const int r = (int)(i / N), c = (int)(i % N);
             float* dst = C + (size_t)r * ldc + c;
             *dst = accumulate ? *dst + s : s;
@@ -251,6 +262,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         p.C = C; p.ldc = ldc; p.slab = 0; p.accumulate = accumulate;
     }
     p.nsplit = nsplit; p.nbatch = nbatch;
+    p.xcd_split = (nsplit > 1 && nsplit % 8 == 0 && nbatch == 1 && vnp_gemm_get_mode() == 0 && !vnp_no_xcd_split()) ? 1 : 0;
     p.col_group = 8;                     // measured: +3 % at N = 2048 (B panels of 8 column tiles stay in the XCD's L2)
     p.pool_val = nullptr; p.pool_idx = nullptr; p.pool_x = nullptr; p.pool_gs = 0;
     const int bm = op_a == 0 ? 192 : 128;

@@ -32,6 +32,10 @@ struct VnpGemmArgs {
     // PREC = 1 (two fp16 planes, three products): device words holding the bit pattern of max |A|, max |B| over the whole operand
     // (vnp_absmax, or emitted by the kernel that produced the operand); the kernel derives its power-of-two operand scales from them
     const unsigned* amax_a; const unsigned* amax_b;
+    // split kernel, split-K with few output tiles (weight gradients): all tiles of one K-slice go to ONE XCD (workgroup w runs on
+    // XCD w % 8), so that the slice's A / B rows are fetched into that XCD's L2 once and shared by its tiles, instead of every XCD
+    // streaming its own column blocks of the whole K range (nsplit % 8 == 0, one batch)
+    int xcd_split;
 };
 
 template <int R, int BK, bool KC, int NV>

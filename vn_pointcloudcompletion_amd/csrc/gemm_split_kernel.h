@@ -276,9 +276,16 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
 
     int m0, n0, kt0, kt1, split, batch;
     auto set_item = [&](int w) {                            // same XCD-aware walk as vnp_gemm_kernel
-        const int sbi = w / nwg, t = w - sbi * nwg;
-        const int q = nwg >> 3, r = nwg & 7, x = t & 7;
-        const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+        int sbi, wg;
+        if (p.xcd_split) {                                  // (K-slice, tile) -> XCD = slice % 8, see VnpGemmArgs::xcd_split
+            const int j = w >> 3;
+            wg = j % nwg; sbi = (j / nwg) * 8 + (w & 7);
+        } else {
+            sbi = w / nwg;
+            const int t = w - sbi * nwg;
+            const int q = nwg >> 3, r = nwg & 7, x = t & 7;
+            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+        }
         // column tiles in groups of cg: (group, row panel, column in group), column fastest
         const int cg = (p.col_group > 0 && p.col_group < nbn) ? p.col_group : nbn;
         const int full = (nbn / cg) * cg * nbm;

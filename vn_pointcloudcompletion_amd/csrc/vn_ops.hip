@@ -196,8 +196,15 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
 // trades a written-then-re-read map for a second read of the inputs: 6 maps instead of 7 in the rank-1 form (2R + 2R2W against
 // 2R2W + 2R1W), 8 = 8 in the matrix form but with 6 reads / 2 writes instead of 5 / 3 (reads stream faster: hbm_yardstick).
 // gradients only: v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the ~12-instruction IEEE sequences (the rank-1 form was issue-bound)
+#ifdef VNP_EXPERIMENT_IEEE_GRADS          // accuracy probe only: IEEE division / sqrt in the gradient kernels too
+#define BDIV(a, b) ((a) / (b))
+#define BSQRT(a) sqrtf(a)
+#define VNP_GRAD_HW 0
+#else
 #define BDIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
 #define BSQRT(a) __builtin_amdgcn_sqrtf(a)
+#define VNP_GRAD_HW 1
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __restrict__ go, int ldgo,
                                                                const float* __restrict__ go_row, const float* __restrict__ go_col,
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
                                                                float2* __restrict__ partial, float* __restrict__ gw_partial, int chunk,
                                                                const float* __restrict__ S, float inv_count, float* __restrict__ colsum)
 {
-    __shared__ float2 red[4][64];
+    __shared__ double2 red[4][64];             // S1 / S2 are carried in double (as in vnp_fold_fused_kernel; free in an HBM-bound pass)
     __shared__ float red3[4][64];
     __shared__ float red6[4][6][64];
     float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // MODE 2 + colsum: sums over the chunk's points of (dL/dp, dL/dd) per component
@@ -217,7 +224,8 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
     const int c = blockIdx.x * 64 + cx;
     const long long p0 = (long long)blockIdx.y * chunk;
     const long long p1 = min(P, p0 + chunk);
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    double s1 = 0.0, s2 = 0.0;
+    float s3 = 0.f;
     if (c < C) {
         float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, gc = 0.f;
         if (mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
             if (MODE == 2 && colsum) { cs[0] += g0; cs[1] += g1; cs[2] += g2; }
             if (MODE != 2 && mean) {
                 const float gnh = BDIV(g0 * x0 + g1 * x1 + g2 * x2, n);     // dL/dnhat = (gq . p) / n
-                s1 += gnh; s2 += gnh * xh;
+                s1 += (double)gnh; s2 += (double)(gnh * xh);
             }
         }
     }
@@ -311,12 +319,12 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
         }
     }
     if (MODE != 2 && (partial || gw_partial)) {
-        red[py][cx] = make_float2(s1, s2);
+        red[py][cx] = make_double2(s1, s2);
         red3[py][cx] = s3;
         __syncthreads();
         if (py == 0 && c < C) {
-            float2 a = red[0][cx], b = red[1][cx], e = red[2][cx], f = red[3][cx];
-            if (partial) partial[(size_t)blockIdx.y * C + c] = make_float2((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y));
+            const double2 a = red[0][cx], b = red[1][cx], e = red[2][cx], f = red[3][cx];
+            if (partial) partial[(size_t)blockIdx.y * C + c] = make_float2((float)((a.x + b.x) + (e.x + f.x)), (float)((a.y + b.y) + (e.y + f.y)));
             if (gw_partial) gw_partial[(size_t)blockIdx.y * C + c] = (red3[0][cx] + red3[1][cx]) + (red3[2][cx] + red3[3][cx]);
         }
     }
@@ -812,8 +820,8 @@ struct VnpFoldArgs {
 
 // two-lane helpers of the packed backward body (PK): one thread evaluates two seed points per step on v_pk_*_f32
 __device__ __forceinline__ vnp_f2 vnp_sq3(vnp_f2 a, vnp_f2 b, vnp_f2 c) { return a * a + b * b + c * c; }
-__device__ __forceinline__ vnp_f2 vnp_rcp2(vnp_f2 v) { return vnp_f2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])}; }
-__device__ __forceinline__ vnp_f2 vnp_sqrt2(vnp_f2 v) { return vnp_f2{__builtin_amdgcn_sqrtf(v[0]), __builtin_amdgcn_sqrtf(v[1])}; }
+__device__ __forceinline__ vnp_f2 vnp_rcp2(vnp_f2 v) { return VNP_GRAD_HW ? vnp_f2{__builtin_amdgcn_rcpf(v[0]), __builtin_amdgcn_rcpf(v[1])} : vnp_f2{1.f / v[0], 1.f / v[1]}; }
+__device__ __forceinline__ vnp_f2 vnp_sqrt2(vnp_f2 v) { return VNP_GRAD_HW ? vnp_f2{__builtin_amdgcn_sqrtf(v[0]), __builtin_amdgcn_sqrtf(v[1])} : vnp_f2{sqrtf(v[0]), sqrtf(v[1])}; }
 
 // PK (backward modes, even S): the loop over a coarse point's S seed points takes two per step with packed fp32 arithmetic — the same
 // formulas lane by lane; only the order in which the per-thread sums collect their terms changes (even and odd seed points separately)
@@ -823,9 +831,13 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     static_assert(!PK || MODE >= 2, "the packed body exists for the backward modes");
     // the backward modes (gradients) use v_rcp_f32 / v_sqrt_f32 (1 ulp each) where the forward modes keep IEEE division and sqrtf so that statistics and
     // outputs stay bit-identical to the unfused path
-#define FDIV(a, b) (MODE >= 2 ? (a) * __builtin_amdgcn_rcpf(b) : (a) / (b))
-#define FSQRT(a) (MODE >= 2 ? __builtin_amdgcn_sqrtf(a) : sqrtf(a))
-    __shared__ float red[4][5][2][64];
+#define FDIV(a, b) ((MODE >= 2 && VNP_GRAD_HW) ? (a) * __builtin_amdgcn_rcpf(b) : (a) / (b))
+#define FSQRT(a) ((MODE >= 2 && VNP_GRAD_HW) ? __builtin_amdgcn_sqrtf(a) : sqrtf(a))
+    __shared__ float red[4][2][64];                               // MODE 0
+    // backward sums are carried in double from one coarse point to the next (the 16 seed points of a coarse point are summed in fp32):
+    // S1 / S2 enter every row's gradient through m1, m2 times gamma * rstd — rstd is 10^2..10^3 here, the norms of a sample share their
+    // dominant term — as an error common to all rows; ten conversions and adds per coarse point cost nothing next to ~2400 VALU ops
+    __shared__ double redd[MODE >= 2 ? 4 : 1][5][2][64];
     __shared__ int cnt[4];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cx;
@@ -842,8 +854,8 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     const float m1 = (MODE == 3 && a.sums) ? a.sums[2 * (live ? j : 0)] * a.inv_count : 0.f;
     const float m2 = (MODE == 3 && a.sums) ? a.sums[2 * (live ? j : 0) + 1] * a.inv_count : 0.f;
     float wmean = 0.f, wm2 = 0.f; int wk = 0;                      // MODE 0
-    float s1 = 0.f, s2 = 0.f;                                      // MODE 2
-    float acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};          // MODE 3: [feat|dir][bias t0..2, seed, coarse]
+    double s1 = 0.0, s2 = 0.0;                                     // MODE 2
+    double acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};         // MODE 3: [feat|dir][bias t0..2, seed, coarse]
     for (long long cp = cp0 + py; cp < cp1; cp += 4) {
         const int b = (int)(cp / a.Mc);
         const float c0 = a.coarse[cp * 3], c1 = a.coarse[cp * 3 + 1], c2 = a.coarse[cp * 3 + 2];
@@ -911,11 +923,11 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
                 vacc[1][4] += h0 * c0 + h1 * c1 + h2 * c2;
                 vgc0 += r0 * wcf + h0 * wcd; vgc1 += r1 * wcf + h1 * wcd; vgc2 += r2 * wcf + h2 * wcd;
             }
-            s1 += vs1[0] + vs1[1]; s2 += vs2[0] + vs2[1];
+            s1 += (double)vs1[0] + (double)vs1[1]; s2 += (double)vs2[0] + (double)vs2[1];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 5; ++r) acc[h][r] += vacc[h][r][0] + vacc[h][r][1];
+                for (int r = 0; r < 5; ++r) acc[h][r] += (double)vacc[h][r][0] + (double)vacc[h][r][1];
             gc0 = vgc0[0] + vgc0[1]; gc1 = vgc1[0] + vgc1[1]; gc2 = vgc2[0] + vgc2[1];
         } else
         for (int s = 0; s < S; ++s) {
@@ -979,26 +991,26 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
         }
     }
     if (MODE == 0) {
-        red[py][0][0][cx] = wmean; red[py][1][0][cx] = wm2;
+        red[py][0][cx] = wmean; red[py][1][cx] = wm2;
         if (cx == 0) cnt[py] = (int)((cp1 - cp0 - py + 3) / 4 > 0 ? ((cp1 - cp0 - py + 3) / 4) * S : 0);
         __syncthreads();
         if (py == 0 && live) {
-            double na = cnt[0], ma = red[0][0][0][cx], Ma = red[0][1][0][cx];
+            double na = cnt[0], ma = red[0][0][cx], Ma = red[0][1][cx];
 #pragma unroll
-            for (int q = 1; q < 4; ++q) vnp_chan_merge(na, ma, Ma, (double)cnt[q], (double)red[q][0][0][cx], (double)red[q][1][0][cx]);
+            for (int q = 1; q < 4; ++q) vnp_chan_merge(na, ma, Ma, (double)cnt[q], (double)red[q][0][cx], (double)red[q][1][cx]);
             a.partial[(size_t)blockIdx.y * C + j] = make_float2((float)ma, (float)Ma);
         }
     } else if (MODE == 2) {
-        red[py][0][0][cx] = s1; red[py][1][0][cx] = s2;
+        redd[py][0][0][cx] = s1; redd[py][1][0][cx] = s2;
         __syncthreads();
         if (py == 0 && live)
-            a.partial[(size_t)blockIdx.y * C + j] = make_float2((red[0][0][0][cx] + red[1][0][0][cx]) + (red[2][0][0][cx] + red[3][0][0][cx]),
-                                                                (red[0][1][0][cx] + red[1][1][0][cx]) + (red[2][1][0][cx] + red[3][1][0][cx]));
+            a.partial[(size_t)blockIdx.y * C + j] = make_float2((float)((redd[0][0][0][cx] + redd[1][0][0][cx]) + (redd[2][0][0][cx] + redd[3][0][0][cx])),
+                                                                (float)((redd[0][1][0][cx] + redd[1][1][0][cx]) + (redd[2][1][0][cx] + redd[3][1][0][cx])));
     } else if (MODE == 3) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) red[py][r][h][cx] = acc[h][r];
+            for (int r = 0; r < 5; ++r) redd[py][r][h][cx] = acc[h][r];
         __syncthreads();
         if (py == 0 && live) {
 #pragma unroll
@@ -1006,7 +1018,7 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
 #pragma unroll
                 for (int r = 0; r < 5; ++r)
                     a.part5[((size_t)blockIdx.y * 5 + r) * 2 * C + h * C + j] =
-                        (red[0][r][h][cx] + red[1][r][h][cx]) + (red[2][r][h][cx] + red[3][r][h][cx]);
+                        (float)((redd[0][r][h][cx] + redd[1][r][h][cx]) + (redd[2][r][h][cx] + redd[3][r][h][cx]));
         }
     }
 }
@@ -1084,8 +1096,8 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
 {
     // the backward modes use v_rcp_f32 / v_sqrt_f32 (1 ulp each) as the other gradient kernels do; the forward modes keep IEEE division
     // and sqrtf, so statistics and outputs stay bit-identical to the materialising path
-#define EDIV(x, y) (MODE >= 2 ? (x) * __builtin_amdgcn_rcpf(y) : (x) / (y))
-#define ESQRT(x) (MODE >= 2 ? __builtin_amdgcn_sqrtf(x) : sqrtf(x))
+#define EDIV(x, y) ((MODE >= 2 && VNP_GRAD_HW) ? (x) * __builtin_amdgcn_rcpf(y) : (x) / (y))
+#define ESQRT(x) ((MODE >= 2 && VNP_GRAD_HW) ? __builtin_amdgcn_sqrtf(x) : sqrtf(x))
     __shared__ float2 red[4][64];
     __shared__ int cnt[4];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;

@@ -40,6 +40,14 @@ POOL_SCREEN_PASS = _os.environ.get("VNP_POOL_SCREEN_PASS", "fp16")
 # BatchNorm + leaky backward in two read-heavy passes (sums, then final gradients) instead of bwd1 -> reduce -> bwd2, which writes
 # dL/dq and reads it back (VNP_BN_BWD_TWO_PASS=0 keeps that form); same arithmetic term for term
 BN_BWD_TWO_PASS = _os.environ.get("VNP_BN_BWD_TWO_PASS", "1") != "0"
+# A VNLinear whose output feeds ONLY a VNMaxPool and (concatenated with the pooled feature) a VNLinearLeakyReLU — encoder
+# first_conv[1] -> maxpool1 / second_conv[0], models/pcn.py:168-173 — is a linear map in front of linear maps: W2 (W1 a) is evaluated
+# as (W2 W1) a, contracting over first_conv[1]'s 128 INPUT channels instead of its 512 outputs (4x fewer FLOPs in the layer's three
+# big GEMMs), and the 512-channel tensor is never stored.  Same arithmetic up to fp32 re-association, like POOL_DIRECTION_REASSOCIATE;
+# VNP_ENC_AS_WRITTEN=1 keeps the reference's evaluation order.
+ENC_LINEAR_REASSOCIATE = _os.environ.get("VNP_ENC_AS_WRITTEN", "0") != "1"
+# VNLinear -> VNMaxPool with a small contraction (K < this): the full fused epilogue costs less than the screened search's fixed passes
+POOL_SCREEN_MIN_K = 256
 # Opt-in (VNP_GEMM_FP16X2=1): large aligned GEMMs (K >= 64) on two fp16 planes of the power-of-two scaled operands and three MFMA products
 # (vnp_gemm_ex; normwise error against fp64 at or below an fp32 sgemm's) instead of three bf16 planes and six products.  Off by default:
 # operand precision is narrowed to 22-23 bits, and the absmax pass over each operand costs what the GEMM saves.
@@ -373,9 +381,23 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
     return tuple(res)
 
 
-def _wgrad(gy, x):
-    """dW [Cout, Cin] = gy[R, Cout]^T x[R, Cin]  (TN GEMM, split over the R rows)."""
-    return gemm(gy, x, op_a=1, op_b=1)
+WGRAD_SLICE_TILES = 64          # K-tiles (of 32 rows) per split-K slice of a weight gradient that is multiplied on (see _wgrad)
+WGRAD_SLAB_BYTES = 128 << 20    # ... as long as the slabs stay under this
+
+
+def _wgrad(gy, x, fine=False):
+    """dW [Cout, Cin] = gy[R, Cout]^T x[R, Cin]  (TN GEMM, split over the R rows; the slices are summed in double,
+    vnp_reduce_slabs_kernel).  ``fine``: the layer was folded onto its producer (WeightProductFn), so dW is multiplied on into a
+    product that cancels (measured at config 2: the factor's relative error is amplified ~300x); a slice then accumulates at most
+    WGRAD_SLICE_TILES * 32 rows in fp32 on the matrix pipe, which keeps the gradient's rounding error at
+    ~sqrt(2048) 2^-24 / sqrt(slices) of its terms however many rows it sums."""
+    nsplit = None
+    if fine:
+        M, N, nk = gy.shape[1], x.shape[1], (gy.shape[0] + 31) // 32
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        auto = max(1, min(nk // 4, 512 // tiles)) if (tiles < 256 and nk >= 8) else 1
+        nsplit = max(auto, min((nk + WGRAD_SLICE_TILES - 1) // WGRAD_SLICE_TILES, max(1, WGRAD_SLAB_BYTES // (M * N * 4))))
+    return gemm(gy, x, op_a=1, op_b=1, nsplit=nsplit)
 
 
 # ------------------------------------------------------------------------------- autograd Functions
@@ -400,6 +422,40 @@ class SplitColsFn(Function):
 
 def split_cols(W, *sizes):
     return SplitColsFn.apply(W, *sizes)
+
+
+class WeightProductFn(Function):
+    """(Wf W1, Wd W1) for weights Wf, Wd [C, K1] and W1 [K1, K0]: the layer that follows a VNLinear, folded onto that VNLinear's input
+    channels (ENC_LINEAR_REASSOCIATE).  One GEMM over [Wf; Wd] forward, two backward; all of them a few hundred MFLOP."""
+
+    @staticmethod
+    def forward(ctx, Wf, Wd, W1):
+        Wcat = torch.cat([Wf, Wd], dim=0)
+        W1 = _rows(W1)
+        prod = gemm(Wcat, W1, op_b=1)                       # [2C, K0]
+        ctx.save_for_backward(Wcat, W1)
+        ctx.C = Wf.shape[0]
+        return prod[:ctx.C], prod[ctx.C:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gf, gd):
+        Wcat, W1 = ctx.saved_tensors
+        C = ctx.C
+        if gf is None or gd is None:
+            ref = gf if gf is not None else gd
+            gf = gf if gf is not None else torch.zeros_like(ref)
+            gd = gd if gd is not None else torch.zeros_like(ref)
+        base, K0 = gf._base, W1.shape[1]
+        if (base is not None and base is gd._base and base.shape == (2 * C, K0) and base.is_contiguous() and gf.shape == (C, K0)
+                and gd.shape == (C, K0) and gf.data_ptr() == base.data_ptr() and gd.data_ptr() == base.data_ptr() + 4 * C * K0):
+            g = base                        # the two halves of one [2C, K0] weight gradient (VNLinearLeakyFn.backward): no copy
+        else:
+            g = torch.cat([gf, gd], dim=0)
+        g = _rows(g)
+        gWcat = gemm(g, W1) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None      # [2C, K1] = g W1^T
+        gW1 = gemm(Wcat, g, op_a=1, op_b=1) if ctx.needs_input_grad[2] else None                  # [K1, K0] = Wcat^T g
+        return (gWcat[:C] if gWcat is not None else None), (gWcat[C:] if gWcat is not None else None), gW1
 
 
 class ToRowsFn(Function):
@@ -478,10 +534,12 @@ class VNLinearLeakyFn(Function):
     ``bias`` [B*3, 2C] (feat | dir halves) carries the de-duplicated broadcast input channels."""
 
     @staticmethod
-    def forward(ctx, x, Wf, Wd, gamma, beta, running_mean, running_var, bias, rows_per_group, training, ns):
+    def forward(ctx, x, Wf, Wd, gamma, beta, running_mean, running_var, bias, rows_per_group, training, ns, folded=False):
+        """``folded``: Wf, Wd are products with the producing VNLinear's weight (WeightProductFn): finer split-K for their gradient."""
         x = _rows(x)
         R = x.shape[0]
         C = Wf.shape[0]
+        ctx.folded = bool(folded)
         pd = torch.empty((R, 2 * C), device=x.device, dtype=torch.float32)
         if bias is not None:
             bias = _rows(bias)
@@ -507,9 +565,9 @@ class VNLinearLeakyFn(Function):
         gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None          # dX = [dP | dD] [Wf; Wd]
         gWf = gWd = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gW = _wgrad(gpd, x)                                                     # [2C, Cin] in one split-K launch
+            gW = _wgrad(gpd, x, fine=ctx.folded)                                    # [2C, Cin] in one split-K launch
             gWf, gWd = gW[:C], gW[C:]
-        return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None
+        return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None, None
 
 
 class VNLinearLeakyOutFn(Function):
@@ -763,7 +821,9 @@ class VNLinearMaxPoolFn(Function):
             Wcat = torch.stack([_rows(W).view(C // 32, 32, K), Wp.view(C // 32, 32, K)], dim=1).reshape(2 * C, K)
             skey = (x.device.index, G, gs, C, K)
             # the selection pass keeps a group's 32-point blocks in registers (gs <= 2048); back off after a fallback (see above)
-            screened = POOL_SCREENED and gs <= 2048 and (POOL_SCREEN_STATS is not None or _screen_allowed(skey))
+            # (a short contraction — first_conv[1] -> maxpool1, K = 128 — is cheaper on the full epilogue than the search's fixed passes)
+            screened = (POOL_SCREENED and gs <= 2048 and (K >= POOL_SCREEN_MIN_K or POOL_SCREEN_STATS is not None)
+                        and (POOL_SCREEN_STATS is not None or _screen_allowed(skey)))
             entry = "vnp_linear_pool_screened_fwd" if screened else "vnp_linear_pool_fwd"
             nb = _lib.lib().vnp_linear_pool_screened_ws_bytes(G, gs, C, K) if screened else _lib.lib().vnp_linear_pool_ws_bytes(G, gs, C)
             ws = torch.empty((nb + 7) // 8, device=x.device, dtype=torch.int64)

@@ -58,15 +58,22 @@ class VN_PointNet(nn.Module):
         B, N, _ = xyz.shape
         x = xyz.contiguous().float().reshape(B * N * 3, 1)                       # rows layout with C = 1 IS xyz
         a1 = self.first_conv[0].forward_rows(x)
-        # first_conv[1]'s output f [B*N*3, 512] feeds maxpool1 AND second_conv[0]: when the shapes allow, one GEMM stores f and pools
-        # in its epilogue; in any case the pool's sparse gradient is added into second_conv[0]'s input gradient in place
         W1 = self.first_conv[1].map_to_feat.weight
-        if ops.VNLinearPoolTapFn.supported(a1, W1, B, N):
-            f, g1, _ = ops.VNLinearPoolTapFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)
+        if ops.ENC_LINEAR_REASSOCIATE:
+            # first_conv[1] is a linear map whose output f = W1 a1 [B*N*3, 512] feeds maxpool1 and — behind the concatenation —
+            # second_conv[0]'s linear maps (pcn.py:168-173): the pool takes f from its fused GEMM without storing it, and
+            # second_conv[0] contracts (W W1) with a1 over first_conv[1]'s 128 input channels instead of W with f over 512
+            g1, _ = ops.VNLinearMaxPoolFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)      # g1 [B*3, 512]
+            f = self.second_conv[0].forward_rows(a1, global_rows=g1, rows_per_group=N * 3, pre_linear=W1)
         else:
-            f = self.first_conv[1].forward_rows(a1)
-            f, g1 = self.maxpool1.forward_rows_tap(f, B, N, producer=(a1, self.first_conv[1]))   # g1 [B*3, 512]
-        f = self.second_conv[0].forward_rows(f, global_rows=g1, rows_per_group=N * 3)
+            # as written: f is stored.  When the shapes allow, one GEMM stores f and pools in its epilogue; in any case the pool's
+            # sparse gradient is added into second_conv[0]'s input gradient in place
+            if ops.VNLinearPoolTapFn.supported(a1, W1, B, N):
+                f, g1, _ = ops.VNLinearPoolTapFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)
+            else:
+                f = self.first_conv[1].forward_rows(a1)
+                f, g1 = self.maxpool1.forward_rows_tap(f, B, N, producer=(a1, self.first_conv[1]))   # g1 [B*3, 512]
+            f = self.second_conv[0].forward_rows(f, global_rows=g1, rows_per_group=N * 3)
         # second_conv[1] + maxpool2 fused: the linear output has no other consumer, so its (one-point-per-channel)
         # gradient is never materialised (ops.VNLinearMaxPoolFn)
         g2, _ = ops.VNLinearMaxPoolFn.apply(f, self.second_conv[1].map_to_feat.weight,

@@ -125,10 +125,12 @@ class VNLinearLeakyReLU(nn.Module):
         self.batchnorm = VNBatchNorm(out_channels, dim=dim)
         self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
 
-    def forward_rows(self, rows, global_rows=None, rows_per_group=0, global_first=True):
+    def forward_rows(self, rows, global_rows=None, rows_per_group=0, global_first=True, pre_linear=None):
         """``global_rows`` [G*3, Cg]: per-group features standing for Cg of the input channels, i.e. the layer acts on
         cat([global.expand(n), x], dim=1) (``global_first``, models/pcn.py:172) or cat([x, global.expand(n)], dim=1)
-        (models/pcn.py:486,488) without materialising the broadcast; a group is ``rows_per_group``/3 consecutive points."""
+        (models/pcn.py:486,488) without materialising the broadcast; a group is ``rows_per_group``/3 consecutive points.
+        ``pre_linear`` [Cx, K0]: the per-point input x is the (never materialised) output ``rows @ pre_linear.T`` of a VNLinear; the
+        layer's weights are folded onto that layer's K0 input channels (ops.ENC_LINEAR_REASSOCIATE)."""
         bn = self.batchnorm.bn
         self.batchnorm._tick()
         Wf, Wd = self.map_to_feat.weight, self.map_to_dir.weight
@@ -144,8 +146,11 @@ class VNLinearLeakyReLU(nn.Module):
                 (Wf, Wfg), (Wd, Wdg) = ops.split_cols(Wf, cx, cg), ops.split_cols(Wd, cx, cg)
             bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
                               ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
+        if pre_linear is not None:
+            ops._trace("linear_folded_onto_producer")
+            Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
-                                         rows_per_group, self.training, self.negative_slope)
+                                         rows_per_group, self.training, self.negative_slope, pre_linear is not None)
 
     def forward(self, x):
         rows, meta = to_rows(x)
