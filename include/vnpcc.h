@@ -271,6 +271,26 @@ int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const f
                    float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
                    float* part5, float* gcoarse, int coarse_per_chunk);
 
+/* VNLinearLeakyReLU on a map whose VN vectors are all parallel to ONE unit direction u per point (the layer behind VN_PointNet's
+ * single-channel first layer, models/pcn.py:165-173 + models/vn_layers.py:46-74), on per-POINT operands:
+ *   p[(n,t)][c] = u[n][t] v[n][c] + bias[g(n)*3+t][c],   d[(n,t)][c] = u[n][t] v[n][C+c] + bias[g(n)*3+t][C+c],   g(n) = n / points_per_group
+ * v [P][ldv] = h [W_f ; W_d]^T is ONE row per point (vnp_gemm on points: a third of the rows layout's FLOPs); p, d are rebuilt in registers.
+ *   mode 0: partial [nchunk][C][2] = (mean, M2) of |p|+eps per chunk of chunk_points points   (then vnp_vn_bn_finalize_chunked)
+ *   mode 1: out [P*3][ldo] = leaky(bn(p), d)                                                   (rows layout)
+ *   mode 2: partial [nchunk][C][2] = (sum g_nhat, sum g_nhat*xhat) from the upstream gradient go [P*3][ldgo]
+ *   mode 3: gv [P][ldgv]: gv[n][c] = sum_t u_t dL/dp_t, gv[n][C+c] = sum_t u_t dL/dd_t; colsum (nullable) [nchunk][3][2C] = per-chunk
+ *           sums of (dL/dp | dL/dd) per component (the bias gradient); S [C][2] = reduced mode-2 partials (NULL: eval-mode BatchNorm)
+ * bias (nullable) [G*3][ldb]; with a bias chunk_points must divide points_per_group.  4 <= chunk_points <= 1024. */
+int vnp_vn_dir_layer(hipStream_t st, int mode, const float* v, int ldv, const float* u, const float* bias, int ldb,
+                     long long P, int C, int points_per_group, int chunk_points,
+                     const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                     float* out, int ldo, const float* go, int ldgo, float* partial, const float* S, long long count,
+                     float* gv, int ldgv, float* colsum);
+/* u[n] = xyz[n] / |xyz[n]| (0 for the origin), [P][3] */
+int vnp_unit_dirs(hipStream_t st, const float* xyz, long long P, float* u);
+/* expand = 0: h[n][c] = sum_t u[n][t] rows[(n,t)][c];  expand = 1: rows[(n,t)][c] = u[n][t] h[n][c];  expand = 2: rows += u h */
+int vnp_dir_contract(hipStream_t st, float* rows, int ldr, const float* u, float* h, int ldh, long long P, int C, int expand);
+
 /* ---- small reductions -------------------------------------------------------------------------------------- */
 /* out[r] = sum_c X[r][c]*w[c] (+ add[((r/3)/add_group)*3 + r%3]) : final VNLinear(C->1) + point_feat (pcn.py:387) */
 int vnp_rowdot(hipStream_t st, const float* X, int ldx, const float* w, long long R, int C,

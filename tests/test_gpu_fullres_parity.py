@@ -87,7 +87,8 @@ def test_benchmark_code_paths_were_taken(run):
     if _lib.get_gemm_mode() != "split":
         pytest.skip("VNP_GEMM_MODE=fp32: the fused epilogues belong to the split kernel; the parity asserts below still run")
     tr = run.tr
-    assert tr.get("pd_gemm_stats_epilogue", 0) == 2 and tr.get("pd_gemm_plain", 0) == 1, tr    # second_conv[0], final_conv[1]; first_conv[0] has K = 1
+    # final_conv[1]: statistics in the GEMM epilogue; first_conv[0] has K = 1; second_conv[0] runs on per-point scalars (vnp_vn_dir_layer)
+    assert tr.get("pd_gemm_stats_epilogue", 0) == 1 and tr.get("pd_gemm_plain", 0) == 1 and tr.get("dir_layer", 0) == 1, tr
     # maxpool2 (K = 1024): screened search; maxpool1 (K = 128): full fused epilogue, its 512-channel input never stored and
     # second_conv[0] folded onto first_conv[1]'s input channels
     assert tr.get("linear_pool_screened", 0) == 1 and "linear_pool_unfused" not in tr and tr.get("linear_pool_fused_epilogue", 0) == 1, tr

@@ -482,9 +482,10 @@ def test_linear_pool_tap_fused_equals_linear_then_tap(lib_built, G, gs, C, K):
 @pytest.mark.parametrize("B,N,Mc", [(2, 256, 64), (2, 2048, 128)])
 def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
     """VN_PointNet with second_conv[0] folded onto first_conv[1]'s input channels ((W2 W1) a, ops.ENC_LINEAR_REASSOCIATE: the 512-channel
-    map is never stored) against the evaluation order of models/pcn.py:168-173 (W2 (W1 a), VNP_ENC_AS_WRITTEN=1): same arg-max
-    choices, outputs equal to fp32 re-association noise (1e-5 of the largest element), every parameter gradient equal to 1e-4 of its largest element (worst tensors: the
-    ill-conditioned first_conv[0] directions, see test_gpu_e2e.py)."""
+    map is never stored) — on per-point scalars (ops.ENC_DIR_LAYER, vnp_vn_dir_layer: every vector behind the single-channel first layer
+    is parallel to its point's direction) and in the rows layout — against the evaluation order of models/pcn.py:168-173 (W2 (W1 a),
+    VNP_ENC_AS_WRITTEN=1): same arg-max choices, outputs equal to fp32 re-association noise (1e-5 of the largest element), every
+    parameter gradient equal to 1e-4 of its largest element (1e-3 in the coarse head, see below)."""
     from types import SimpleNamespace
     from vn_pointcloudcompletion_amd import ops
     from vn_pointcloudcompletion_amd.pcn import VN_PointNet
@@ -492,36 +493,93 @@ def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
     enc = VN_PointNet(SimpleNamespace(num_coarse=Mc), latent_dim=256).cuda().train()
     sd0 = {k: v.clone() for k, v in enc.state_dict().items()}
     g = torch.Generator().manual_seed(B * N)
-    xyz = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    xyz = torch.rand(B, N, 3, generator=g) - 0.5
+    xyz[0, 3] = 0.0                                                # a point at the origin: direction 0, pre-activations = bias
+    xyz = xyz.cuda()
     cot_c, cot_g = torch.randn(B, Mc, 3, generator=g).cuda(), torch.randn(B, 512, 3, 1, generator=g).cuda()
     res = {}
-    keep = ops.ENC_LINEAR_REASSOCIATE
+    keep = ops.ENC_LINEAR_REASSOCIATE, ops.ENC_DIR_LAYER
     try:
-        for mode in (True, False):
-            ops.ENC_LINEAR_REASSOCIATE = mode
+        for mode, (fold, dirl) in {"dir": (True, True), "rows": (True, False), "as_written": (False, False)}.items():
+            ops.ENC_LINEAR_REASSOCIATE, ops.ENC_DIR_LAYER = fold, dirl
             enc.load_state_dict(sd0)
             enc.zero_grad(set_to_none=True)
             ops.TRACE = tr = {}
             coarse, fg = enc(xyz)
             ((coarse * cot_c).sum() + (fg * cot_g).sum()).backward()
             ops.TRACE = None
-            assert (tr.get("linear_folded_onto_producer", 0) == 1) == mode, tr
+            assert (tr.get("linear_folded_onto_producer", 0) == 1) == fold and (tr.get("dir_layer", 0) == 1) == dirl, tr
             res[mode] = (coarse.detach(), fg.detach(), [i.clone() for i in tr["pool_idx"]],
                          {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None},
                          {k: v.clone() for k, v in enc.state_dict().items() if "running" in k})
     finally:
-        ops.ENC_LINEAR_REASSOCIATE, ops.TRACE = keep, None
-    for a, b in zip(res[True][2], res[False][2]):
-        assert torch.equal(a, b)                                  # same arg-max points in both pools
-    eo = (relerr(res[True][0], res[False][0]), relerr(res[True][1], res[False][1]))
-    assert res[True][3].keys() == res[False][3].keys()
-    eg = sorted(((relerr(gr, res[False][3][k]), k) for k, gr in res[True][3].items()), reverse=True)
-    print(f"coarse {eo[0]:.1e}, global feature {eo[1]:.1e}; worst gradients: " + ", ".join(f"{k} {e:.1e}" for e, k in eg[:3]))
-    assert max(eo) < 1e-5, eo               # fp32 re-association noise behind two BatchNorm layers over B*N norms
-    for e, k in eg:
-        assert e < 1e-4, (k, e)
-    for k, v in res[True][4].items():
-        assert relerr(v, res[False][4][k]) < 1e-6, k
+        (ops.ENC_LINEAR_REASSOCIATE, ops.ENC_DIR_LAYER), ops.TRACE = keep, None
+    ref = res["as_written"]
+    for mode in ("dir", "rows"):
+        r = res[mode]
+        for a, b in zip(r[2], ref[2]):
+            assert torch.equal(a, b), mode                             # same arg-max points in both pools
+        eo = (relerr(r[0], ref[0]), relerr(r[1], ref[1]))
+        assert r[3].keys() == ref[3].keys()
+        eg = sorted(((relerr(gr, ref[3][k]), k) for k, gr in r[3].items()), reverse=True)
+        print(f"{mode}: coarse {eo[0]:.1e}, global feature {eo[1]:.1e}; worst gradients: " + ", ".join(f"{k} {e:.1e}" for e, k in eg[:3]))
+        assert max(eo) < 1e-5, (mode, eo)       # fp32 re-association noise behind two BatchNorm layers over B*N norms
+        for e, k in eg:
+            # 1e-4, and 1e-3 for the coarse head's mlp (96 rows): there a leaky projection whose <q, d> is within rounding of zero
+            # switches branch between two evaluation orders, and its direction weight's gradient moves by that one term
+            assert e < (1e-3 if k.startswith("mlp.") else 1e-4), (mode, k, e)
+        for k, v in r[4].items():
+            assert relerr(v, ref[4][k]) < 1e-6, (mode, k)
+
+
+@pytest.mark.parametrize("P,K,C,ppg", [(512, 32, 64, 256), (4096, 128, 192, 2048), (300, 16, 40, 0)])
+def test_dir_layer_equals_rows_layer(lib_built, P, K, C, ppg):
+    """vnp_vn_dir_layer / VNDirLinearLeakyFn on per-point scalars h against VNLinearLeakyFn on the expanded rows u (x) h: output, input
+    gradient (contracted with u), weight / BatchNorm / bias gradients and running statistics; train and eval mode."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(P + K)
+    xyz = torch.randn(P, 3, generator=g)
+    xyz[5] = 0.0
+    u = ops.unit_dirs(xyz.cuda())
+    assert torch.allclose(u[5], torch.zeros(3, device="cuda")) and relerr(u.norm(dim=1)[6:], torch.ones(P - 6)) < 1e-6
+    # feature scalars v_p = h Wf^T bounded away from zero (same-signed terms, a random sign per channel): where v_p is the tiny
+    # remainder of cancelling terms, the rows path's p = (u_t h) Wf^T leaves the direction u by its rounding error / |p| and its
+    # gradient — of order 1 / |p| perpendicular to p — leaks into the component along u, while here p is parallel to u by
+    # construction and the contraction with u removes that part exactly (measured on such a sample: |p| = 1.8e-5, out differs by 1 %
+    # between the two paths and the rows path's input gradient is dominated by that one element)
+    h = (torch.rand(P, K, generator=g) + 0.5).cuda()
+    Wf = ((torch.rand(C, K, generator=g) + 0.1) / K * (torch.randint(0, 2, (C, 1), generator=g) * 2 - 1)).cuda()
+    Wd = (torch.randn(C, K, generator=g) / K ** 0.5).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    G = P // ppg if ppg else 0
+    bias = torch.randn(G * 3, 2 * C, generator=g).cuda() if ppg else None
+    cot = torch.randn(P * 3, C, generator=g).cuda()
+    if not ops.VNDirLinearLeakyFn.supported(P, C, ppg, bias is not None):
+        pytest.skip("chunk does not divide the group")
+    for training in (True, False):
+        outs = {}
+        for name in ("dir", "rows"):
+            hr, Wfr, Wdr, gr, br = (t.clone().requires_grad_(True) for t in (h, Wf, Wd, gamma, beta))
+            bir = bias.clone().requires_grad_(True) if bias is not None else None
+            rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda") * 0.7
+            if name == "dir":
+                out = ops.VNDirLinearLeakyFn.apply(hr, u, Wfr, Wdr, gr, br, rm, rv, bir, ppg, training, 0.2)
+            else:
+                rows = (u.unsqueeze(2) * hr.unsqueeze(1)).reshape(P * 3, K)                 # test-side expansion (torch glue)
+                out = ops.VNLinearLeakyFn.apply(rows, Wfr, Wdr, gr, br, rm, rv, bir, ppg * 3, training, 0.2)
+            (out * cot).sum().backward()
+            outs[name] = [out.detach(), hr.grad, Wfr.grad, Wdr.grad, gr.grad, br.grad, rm, rv] + ([bir.grad] if bias is not None else [])
+        names = ["out", "gh", "gWf", "gWd", "ggamma", "gbeta", "running_mean", "running_var", "gbias"]
+        # relative L2 error of each tensor
+        def l2(a, b):
+            a, b = a.double().cpu(), b.double().cpu()
+            return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        errs = {nm: l2(a, b) for nm, a, b in zip(names, outs["dir"], outs["rows"])}
+        print(f"training={training}: " + ", ".join(f"{k} {e:.1e}" for k, e in errs.items()))
+        for nm, e in errs.items():
+            # gradients: 3e-4 — with same-signed features the norms of a channel vary little over the batch, and the BatchNorm backward's
+            # cancelling sums amplify the two paths' different rounding (measured 9e-5 on the input gradient of the third case)
+            assert e < (2e-5 if nm in ("out", "running_mean", "running_var") else 3e-4), (training, nm, e)
 
 
 @pytest.mark.parametrize("nb,n,W", [(3, 1248, 40), (2, 2048, 64), (2, 1031, 16), (1, 7, 5), (4, 4992, 24)])

@@ -46,6 +46,9 @@ BN_BWD_TWO_PASS = _os.environ.get("VNP_BN_BWD_TWO_PASS", "1") != "0"
 # big GEMMs), and the 512-channel tensor is never stored.  Same arithmetic up to fp32 re-association, like POOL_DIRECTION_REASSOCIATE;
 # VNP_ENC_AS_WRITTEN=1 keeps the reference's evaluation order.
 ENC_LINEAR_REASSOCIATE = _os.environ.get("VNP_ENC_AS_WRITTEN", "0") != "1"
+# ... and, since every VN vector behind VN_PointNet's single-channel first layer is parallel to its point's direction, run that layer on
+# per-point scalars (VNDirLinearLeakyFn: a third of the GEMM rows, no [P*3, 2C] pre-activation tensor); VNP_ENC_DIR_LAYER=0 keeps the rows form
+ENC_DIR_LAYER = _os.environ.get("VNP_ENC_DIR_LAYER", "1") != "0"
 # VNLinear -> VNMaxPool with a small contraction (K < this): the full fused epilogue costs less than the screened search's fixed passes
 POOL_SCREEN_MIN_K = 256
 # Opt-in (VNP_GEMM_FP16X2=1): large aligned GEMMs (K >= 64) on two fp16 planes of the power-of-two scaled operands and three MFMA products
@@ -568,6 +571,112 @@ class VNLinearLeakyFn(Function):
             gW = _wgrad(gpd, x, fine=ctx.folded)                                    # [2C, Cin] in one split-K launch
             gWf, gWd = gW[:C], gW[C:]
         return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None, None
+
+
+def unit_dirs(xyz):
+    """[.., 3] points -> [P, 3] unit directions x / |x| (0 for the origin); no gradient (a function of the input cloud only)."""
+    x = xyz.detach().reshape(-1, 3).contiguous().float()
+    _lib.require_gpu(x)
+    u = torch.empty_like(x)
+    call("vnp_unit_dirs", ptr(x), x.shape[0], ptr(u))
+    return u
+
+
+class DirContractFn(Function):
+    """rows [P*3, C] whose VN vectors are parallel to the point's unit direction u -> their scalars h [P, C] = sum_t u_t rows_t
+    (rows = u (x) h); backward: the adjoint u_t gh.  See VNDirLinearLeakyFn."""
+
+    @staticmethod
+    def forward(ctx, rows, u):
+        rows = _rows(rows)
+        P, C = rows.shape[0] // 3, rows.shape[1]
+        h = torch.empty((P, C), device=rows.device, dtype=torch.float32)
+        call("vnp_dir_contract", ptr(rows), _ld(rows), ptr(u), ptr(h), C, P, C, 0)
+        ctx.save_for_backward(u)
+        return h
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gh):
+        (u,) = ctx.saved_tensors
+        gh = _rows(gh)
+        P, C = gh.shape
+        g = torch.empty((P * 3, C), device=gh.device, dtype=torch.float32)
+        call("vnp_dir_contract", ptr(g), C, ptr(u), ptr(gh), _ld(gh), P, C, 1)
+        return g, None
+
+
+class VNDirLinearLeakyFn(Function):
+    """VNLinearLeakyReLU (models/vn_layers.py:46-74) on a map whose VN vectors are all parallel to one unit direction u per point — the
+    layer behind VN_PointNet's single-channel first layer (models/pcn.py:165-173): input h [P, K] (one scalar per point and channel, the
+    map is u (x) h), output in the rows layout [P*3, C].  The GEMMs run on points, a third of the rows layout's FLOPs, and the layer's
+    passes rebuild p = u v_p + bias, d = u v_d + bias from v = h [Wf; Wd]^T [P, 2C] in registers (vnp_vn_dir_layer): the [P*3, 2C]
+    pre-activations (1.6 GB at config 2) and their gradient are never written."""
+
+    @staticmethod
+    def supported(P, C, points_per_group, has_bias):
+        chunk, _ = _chunk_pc(P, C)
+        return (not has_bias) or (points_per_group > 0 and points_per_group % chunk == 0 and P % points_per_group == 0)
+
+    @staticmethod
+    def forward(ctx, h, u, Wf, Wd, gamma, beta, running_mean, running_var, bias, points_per_group, training, ns, folded=False):
+        h = _rows(h)
+        P, C = h.shape[0], Wf.shape[0]
+        dev = h.device
+        if bias is not None:
+            bias = _rows(bias)
+        Wcat = torch.cat([Wf, Wd], dim=0)
+        v = gemm(h, Wcat, nsplit=1)                                   # [P, 2C]
+        chunk, nch = _chunk_pc(P, C)
+        common = (ptr(v), 2 * C, ptr(u), ptr(bias), _ld(bias) if bias is not None else 0, P, C, points_per_group, chunk)
+        if training:
+            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_vn_dir_layer", 0, *common, None, None, None, None, ns, None, 0, None, 0, ptr(part), None, 0, None, 0, None)
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize_chunked", ptr(part), nch, chunk, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                 BN_MOMENTUM, BN_EPS)
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+        out = torch.empty((P * 3, C), device=dev, dtype=torch.float32)
+        call("vnp_vn_dir_layer", 1, *common, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns, ptr(out), C, None, 0, None, None, 0,
+             None, 0, None)
+        _trace("dir_layer")
+        ctx.save_for_backward(h, u, Wcat, v, bias, gamma, beta, mean, rstd)
+        ctx.cfg = (C, points_per_group, training, ns, bool(folded), chunk, nch)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        h, u, Wcat, v, bias, gamma, beta, mean, rstd = ctx.saved_tensors
+        C, ppg, training, ns, folded, chunk, nch = ctx.cfg
+        P = h.shape[0]
+        dev = h.device
+        go = _rows(go)
+        common = (ptr(v), 2 * C, ptr(u), ptr(bias), _ld(bias) if bias is not None else 0, P, C, ppg, chunk)
+        stats = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
+        part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+        call("vnp_vn_dir_layer", 2, *common, *stats, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, 0, None)
+        S = torch.empty((C, 2), device=dev, dtype=torch.float32)
+        call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
+        want_gb = bias is not None and ctx.needs_input_grad[8]
+        gv = torch.empty((P, 2 * C), device=dev, dtype=torch.float32)
+        cs_part = torch.empty((nch, 3, 2 * C), device=dev, dtype=torch.float32) if want_gb else None
+        call("vnp_vn_dir_layer", 3, *common, *stats, None, 0, ptr(go), _ld(go), None, ptr(S) if training else None, P,
+             ptr(gv), 2 * C, ptr(cs_part))
+        gb = None
+        if want_gb:
+            nb, cps = P // ppg, ppg // chunk
+            gb = reduce_rows(cs_part.view(nb, cps, 6 * C), nb, cps, 6 * C).view(nb * 3, 2 * C)
+        gh = gemm(gv, Wcat, op_b=1) if ctx.needs_input_grad[0] else None
+        gWf = gWd = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            gW = _wgrad(gv, h, fine=folded)
+            gWf, gWd = gW[:C], gW[C:]
+        return gh, None, gWf, gWd, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, gb, None, None, None, None
 
 
 class VNLinearLeakyOutFn(Function):

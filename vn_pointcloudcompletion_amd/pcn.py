@@ -64,7 +64,16 @@ class VN_PointNet(nn.Module):
             # second_conv[0]'s linear maps (pcn.py:168-173): the pool takes f from its fused GEMM without storing it, and
             # second_conv[0] contracts (W W1) with a1 over first_conv[1]'s 128 input channels instead of W with f over 512
             g1, _ = ops.VNLinearMaxPoolFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)      # g1 [B*3, 512]
-            f = self.second_conv[0].forward_rows(a1, global_rows=g1, rows_per_group=N * 3, pre_linear=W1)
+            l2 = self.second_conv[0]
+            if (ops.ENC_DIR_LAYER and not l2.share_nonlinearity
+                    and ops.VNDirLinearLeakyFn.supported(B * N, l2.map_to_feat.weight.shape[0], N, True)):
+                # first_conv[0] has ONE input channel, the point itself: each of its output vectors is a multiple of the point's unit
+                # direction u, a1 = u (x) h.  second_conv[0] then runs on the per-point scalars h (a third of the GEMM rows) and
+                # rebuilds its pre-activations u v + bias in registers (ops.VNDirLinearLeakyFn)
+                u = ops.unit_dirs(xyz)
+                f = l2.forward_dir(ops.DirContractFn.apply(a1, u), u, global_rows=g1, points_per_group=N, pre_linear=W1)
+            else:
+                f = l2.forward_rows(a1, global_rows=g1, rows_per_group=N * 3, pre_linear=W1)
         else:
             # as written: f is stored.  When the shapes allow, one GEMM stores f and pools in its epilogue; in any case the pool's
             # sparse gradient is added into second_conv[0]'s input gradient in place

@@ -152,6 +152,26 @@ class VNLinearLeakyReLU(nn.Module):
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                          rows_per_group, self.training, self.negative_slope, pre_linear is not None)
 
+    def forward_dir(self, h, u, global_rows=None, points_per_group=0, pre_linear=None):
+        """The layer on a map u (x) h whose VN vectors are parallel to one unit direction ``u`` [P, 3] per point, given as per-point
+        scalars ``h`` [P, K] (ops.VNDirLinearLeakyFn); ``global_rows`` / ``pre_linear`` as in forward_rows (global channels first).
+        Returns rows [P*3, C]."""
+        bn = self.batchnorm.bn
+        self.batchnorm._tick()
+        Wf, Wd = self.map_to_feat.weight, self.map_to_dir.weight
+        bias = None
+        if global_rows is not None:
+            cg = global_rows.shape[1]
+            cx = Wf.shape[1] - cg
+            (Wfg, Wf), (Wdg, Wd) = ops.split_cols(Wf, cg, cx), ops.split_cols(Wd, cg, cx)
+            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
+                              ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
+        if pre_linear is not None:
+            ops._trace("linear_folded_onto_producer")
+            Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
+        return ops.VNDirLinearLeakyFn.apply(h, u, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
+                                            points_per_group, self.training, self.negative_slope, pre_linear is not None)
+
     def forward(self, x):
         rows, meta = to_rows(x)
         return from_rows(self.forward_rows(rows), meta)
