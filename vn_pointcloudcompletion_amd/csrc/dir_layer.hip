@@ -74,61 +74,79 @@ __global__ void __launch_bounds__(256) vnp_dir_layer_kernel(const VnpDirArgs a)
     double s1 = 0.0, s2 = 0.0;                                // MODE 2
     float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // MODE 3
     if (live) {
-        for (long long pt = p0 + py; pt < p1; pt += 4) {
-            const float u0 = a.u[pt * 3], u1 = a.u[pt * 3 + 1], u2 = a.u[pt * 3 + 2];
-            const float vp = __builtin_nontemporal_load(a.v + (size_t)pt * a.ldv + c);
-            const float x0 = fmaf(u0, vp, bp0), x1 = fmaf(u1, vp, bp1), x2 = fmaf(u2, vp, bp2);
-            const float n = DSQRT(vnp_dl_sq3(x0, x1, x2)) + VNP_EPS;
-            if (MODE == 0) {
-                ++wk;
-                const float dl = n - wmean;
-                wmean += dl / (float)wk;
-                wm2 += dl * (n - wmean);
-                continue;
-            }
-            const float vd = __builtin_nontemporal_load(a.v + (size_t)pt * a.ldv + C + c);
-            const float d0 = fmaf(u0, vd, bd0), d1 = fmaf(u1, vd, bd1), d2 = fmaf(u2, vd, bd2);
-            const float xh = (n - mu) * rs;
-            const float s = DDIV(xh * ga + be, n);
-            const float q0 = x0 * s, q1 = x1 * s, q2 = x2 * s;
-            const float dot = q0 * d0 + q1 * d1 + q2 * d2;
-            if (MODE == 1) {
-                float o0 = q0, o1 = q1, o2 = q2;
-                if (dot < 0.f) {
-                    const float al = (1.f - a.ns) * dot / (vnp_dl_sq3(d0, d1, d2) + VNP_EPS);
-                    o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
+        // U points in flight per thread (their loads are issued before the first dependent arithmetic): with one point per iteration
+        // the passes ran at 1.6 - 2.9 TB/s, latency-bound on 65536 points x 1024 channels
+        constexpr int U = MODE <= 1 ? 4 : 2;
+        for (long long pt0 = p0 + py; pt0 < p1; pt0 += 4 * U) {
+            float u0[U], u1[U], u2[U], vp[U], vd[U], g0[U], g1[U], g2[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const long long pt = pt0 + 4 * i;
+                const bool ok = pt < p1;
+                const long long q = ok ? pt : p0;                  // a valid address; the lane's result is dropped below
+                u0[i] = a.u[q * 3]; u1[i] = a.u[q * 3 + 1]; u2[i] = a.u[q * 3 + 2];
+                vp[i] = __builtin_nontemporal_load(a.v + (size_t)q * a.ldv + c);
+                vd[i] = MODE >= 1 ? __builtin_nontemporal_load(a.v + (size_t)q * a.ldv + C + c) : 0.f;
+                if (MODE >= 2) {
+                    const float* rg = a.go + (size_t)q * 3 * a.ldgo + c;
+                    g0[i] = __builtin_nontemporal_load(rg); g1[i] = __builtin_nontemporal_load(rg + a.ldgo); g2[i] = __builtin_nontemporal_load(rg + 2 * (size_t)a.ldgo);
                 }
-                float* o = a.out + (size_t)pt * 3 * a.ldo + c;
-                __builtin_nontemporal_store(o0, o); __builtin_nontemporal_store(o1, o + a.ldo); __builtin_nontemporal_store(o2, o + 2 * (size_t)a.ldo);
-                continue;
             }
-            const float* rg = a.go + (size_t)pt * 3 * a.ldgo + c;
-            float g0 = __builtin_nontemporal_load(rg), g1 = __builtin_nontemporal_load(rg + a.ldgo), g2 = __builtin_nontemporal_load(rg + 2 * (size_t)a.ldgo);
-            float e0 = 0.f, e1 = 0.f, e2 = 0.f;                 // dL/dd
-            if (dot < 0.f) {
-                const float cc = 1.f - a.ns;
-                const float inv = DDIV(1.f, vnp_dl_sq3(d0, d1, d2) + VNP_EPS);
-                const float al = dot * inv;
-                const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
-                const float k1 = cc * gdd * inv;
-                e0 = -cc * (al * g0 + gdd * (q0 * inv - 2.f * al * inv * d0));
-                e1 = -cc * (al * g1 + gdd * (q1 * inv - 2.f * al * inv * d1));
-                e2 = -cc * (al * g2 + gdd * (q2 * inv - 2.f * al * inv * d2));
-                g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;    // now dL/dq
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const long long pt = pt0 + 4 * i;
+                if (pt >= p1) break;
+                const float x0 = fmaf(u0[i], vp[i], bp0), x1 = fmaf(u1[i], vp[i], bp1), x2 = fmaf(u2[i], vp[i], bp2);
+                const float n = DSQRT(vnp_dl_sq3(x0, x1, x2)) + VNP_EPS;
+                if (MODE == 0) {
+                    ++wk;
+                    const float dl = n - wmean;
+                    wmean += dl / (float)wk;
+                    wm2 += dl * (n - wmean);
+                    continue;
+                }
+                const float d0 = fmaf(u0[i], vd[i], bd0), d1 = fmaf(u1[i], vd[i], bd1), d2 = fmaf(u2[i], vd[i], bd2);
+                const float xh = (n - mu) * rs;
+                const float s = DDIV(xh * ga + be, n);
+                const float q0 = x0 * s, q1 = x1 * s, q2 = x2 * s;
+                const float dot = q0 * d0 + q1 * d1 + q2 * d2;
+                if (MODE == 1) {
+                    float o0 = q0, o1 = q1, o2 = q2;
+                    if (dot < 0.f) {
+                        const float al = (1.f - a.ns) * dot / (vnp_dl_sq3(d0, d1, d2) + VNP_EPS);
+                        o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
+                    }
+                    float* o = a.out + (size_t)pt * 3 * a.ldo + c;
+                    __builtin_nontemporal_store(o0, o); __builtin_nontemporal_store(o1, o + a.ldo); __builtin_nontemporal_store(o2, o + 2 * (size_t)a.ldo);
+                    continue;
+                }
+                float h0 = g0[i], h1 = g1[i], h2 = g2[i];           // dL/dout, turned into dL/dq and then dL/dp below
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f;                 // dL/dd
+                if (dot < 0.f) {
+                    const float cc = 1.f - a.ns;
+                    const float inv = DDIV(1.f, vnp_dl_sq3(d0, d1, d2) + VNP_EPS);
+                    const float al = dot * inv;
+                    const float gdd = h0 * d0 + h1 * d1 + h2 * d2;
+                    const float k1 = cc * gdd * inv;
+                    e0 = -cc * (al * h0 + gdd * (q0 * inv - 2.f * al * inv * d0));
+                    e1 = -cc * (al * h1 + gdd * (q1 * inv - 2.f * al * inv * d1));
+                    e2 = -cc * (al * h2 + gdd * (q2 * inv - 2.f * al * inv * d2));
+                    h0 -= k1 * d0; h1 -= k1 * d1; h2 -= k1 * d2;
+                }
+                const float gs = h0 * x0 + h1 * x1 + h2 * x2;
+                const float gnh = DDIV(gs, n);
+                if (MODE == 2) { s1 += (double)gnh; s2 += (double)(gnh * xh); continue; }
+                // MODE 3: dL/dp = s * dL/dq + gn * p / |p|
+                const float pn = n - VNP_EPS;
+                const float nh = xh * ga + be;
+                const float gn = ga * rs * (gnh - m1 - xh * m2) - DDIV(gs * nh, n * n);
+                const float k = pn > 0.f ? DDIV(gn, pn) : 0.f;
+                h0 = s * h0 + k * x0; h1 = s * h1 + k * x1; h2 = s * h2 + k * x2;
+                float* gr = a.gv + (size_t)pt * a.ldgv + c;
+                __builtin_nontemporal_store(u0[i] * h0 + u1[i] * h1 + u2[i] * h2, gr);
+                __builtin_nontemporal_store(u0[i] * e0 + u1[i] * e1 + u2[i] * e2, gr + C);
+                cs[0] += h0; cs[1] += h1; cs[2] += h2; cs[3] += e0; cs[4] += e1; cs[5] += e2;
             }
-            const float gs = g0 * x0 + g1 * x1 + g2 * x2;
-            const float gnh = DDIV(gs, n);
-            if (MODE == 2) { s1 += (double)gnh; s2 += (double)(gnh * xh); continue; }
-            // MODE 3: dL/dp = s * dL/dq + gn * p / |p|
-            const float pn = n - VNP_EPS;
-            const float nh = xh * ga + be;
-            const float gn = ga * rs * (gnh - m1 - xh * m2) - DDIV(gs * nh, n * n);
-            const float k = pn > 0.f ? DDIV(gn, pn) : 0.f;
-            g0 = s * g0 + k * x0; g1 = s * g1 + k * x1; g2 = s * g2 + k * x2;
-            float* gr = a.gv + (size_t)pt * a.ldgv + c;
-            __builtin_nontemporal_store(u0 * g0 + u1 * g1 + u2 * g2, gr);
-            __builtin_nontemporal_store(u0 * e0 + u1 * e1 + u2 * e2, gr + C);
-            cs[0] += g0; cs[1] += g1; cs[2] += g2; cs[3] += e0; cs[4] += e1; cs[5] += e2;
         }
     }
     if (MODE == 0) {

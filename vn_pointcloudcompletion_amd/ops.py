@@ -614,8 +614,17 @@ class VNDirLinearLeakyFn(Function):
     pre-activations (1.6 GB at config 2) and their gradient are never written."""
 
     @staticmethod
+    def _chunk(P, C):
+        """Points per workgroup of vnp_vn_dir_layer: 1024, halved (down to 64) until the grid has 4096 workgroups — the operands are
+        one row per POINT, so a grid sized like the rows-layout passes' (>= 1024 workgroups) would half-fill the chip."""
+        chunk, cols = 1024, (C + 63) // 64
+        while chunk > 64 and ((P + chunk - 1) // chunk) * cols < 4096:
+            chunk //= 2
+        return chunk, (P + chunk - 1) // chunk
+
+    @staticmethod
     def supported(P, C, points_per_group, has_bias):
-        chunk, _ = _chunk_pc(P, C)
+        chunk, _ = VNDirLinearLeakyFn._chunk(P, C)
         return (not has_bias) or (points_per_group > 0 and points_per_group % chunk == 0 and P % points_per_group == 0)
 
     @staticmethod
@@ -627,7 +636,7 @@ class VNDirLinearLeakyFn(Function):
             bias = _rows(bias)
         Wcat = torch.cat([Wf, Wd], dim=0)
         v = gemm(h, Wcat, nsplit=1)                                   # [P, 2C]
-        chunk, nch = _chunk_pc(P, C)
+        chunk, nch = VNDirLinearLeakyFn._chunk(P, C)
         common = (ptr(v), 2 * C, ptr(u), ptr(bias), _ld(bias) if bias is not None else 0, P, C, points_per_group, chunk)
         if training:
             part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
