@@ -18,6 +18,7 @@
 // K order inside an MFMA pair is permuted identically for A and B (lane half h takes k = 8q+4h+s), so a lane's
 // four consecutive K values come from ONE 16-byte LDS read.
 #include "gemm_split_kernel.h"
+#include "screen_wide_kernel.h"
 
 // 0 = bf16x3 split (fp32-grade), 1 = fp32 MFMA.  The library's only process-wide setting: an atomic switch that every vnp_gemm*
 // call reads once on entry (a concurrent vnp_gemm_set_mode affects later calls, never a launch in progress).
@@ -758,7 +759,18 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
         p.screen_eps = 9.78e-4f + 7.2f * (float)K * 5.9605e-8f;
         p.screen_abs = 3.0e-8f * sqrtf((float)K) * 1.01f;
         p.A = (const float*)x16; p.B = (const float*)w16; p.lda = K; p.ldb = K;          // the pass reads the fp16 images (halves)
-        hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, st, p);
+        static const bool narrow = getenv("VNP_SCREEN_WIDE") != nullptr && getenv("VNP_SCREEN_WIDE")[0] == '0';
+        if ((2 * C) % 256 == 0 && !narrow) {
+            // 192 x 256 tiles on eight waves, one workgroup per CU: 0.70x the operand bytes per MFMA (screen_wide_kernel.h); same slots
+            const long long iw = (M / 192) * (2LL * C / 256);
+            const long long cw = vnp_num_cus();
+            constexpr int wide_lds = 2 * (2 * (192 * 64 + 128) + 2 * (256 * 64 + 128));          // two stages of a 192 x 256 x 64 fp16 tile
+            static std::atomic<unsigned long long> wide_ok{0};
+            hipError_t ew = vnp_allow_dynamic_lds(wide_ok, (const void*)vnp_screen_f16_wide_kernel, wide_lds);
+            if (ew != hipSuccess) return (int)ew;
+            hipLaunchKernelGGL(vnp_screen_f16_wide_kernel, dim3((unsigned)(iw < cw ? iw : cw)), dim3(512), wide_lds, st, p);
+        } else
+            hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, st, p);
     } else {
         // THREE bf16 products: dropped (h l)+(l h)+(m m)+... <= 3.05 * 2^-18 of |w||f| per term, plus the worst-case fp32 rounding of
         // BOTH accumulations in any summation order (3K and 6K terms, unit roundoff 2^-24, terms <= 1.01 |w||f|)
