@@ -314,3 +314,25 @@ def test_absmax_word(_mode):
     v = x[:, 4:24]                                                     # strided view: ld 36, 20 columns
     assert ops.amax_word(v).view(torch.float32).item() == v.abs().max().item()
     assert ops.amax_word(x[:, 1:5]) is None                            # misaligned: callers keep the six-product path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,nsplit", [(512, 256, 16384, 64), (2048, 128, 12288, 96), (256, 128, 4096, 8), (384, 200, 5000, 24),
+                                           (128, 128, 2048, 16), (640, 384, 8192, 12)])
+def test_split_k_weight_gradient_forms(lib_built, M, N, K, nsplit):
+    """TN (weight-gradient) GEMMs with explicit K-slice counts: multiples of 8 take the one-slice-per-XCD item order
+    (VnpGemmArgs::xcd_split), the others the (slice, tile) order; aligned and ragged shapes; the slabs are summed in double.  Every
+    output element must be the full sum over K whatever the order — checked against fp64 — and identical between two slice counts
+    up to the fp32 rounding of the slices."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g).cuda()
+    B = torch.randn(K, N, generator=g).cuda()
+    ref = A.double().t() @ B.double()
+    C = ops.gemm(A, B, op_a=1, op_b=1, nsplit=nsplit)
+    C1 = ops.gemm(A, B, op_a=1, op_b=1, nsplit=max(1, nsplit // 3))
+    assert relerr(C, ref) < 2e-5 and relerr(C1, ref) < 2e-5 and relerr(C, C1) < 2e-5
+    # accumulate into an existing gradient through the slab reduction
+    out = torch.ones(M, N, device="cuda")
+    ops.gemm(A, B, op_a=1, op_b=1, nsplit=nsplit, out=out, accumulate=True)
+    assert relerr(out, ref + 1.0) < 2e-5
