@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, relerr, require_split_gemm, t
+from conftest import fp32_mode_slack, load_golden, relerr, require_split_gemm, t
 
 pytestmark = pytest.mark.gpu
 TOL = 3e-5
@@ -527,7 +527,7 @@ def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
         for e, k in eg:
             # 1e-4, and 1e-3 for the coarse head's mlp (96 rows): there a leaky projection whose <q, d> is within rounding of zero
             # switches branch between two evaluation orders, and its direction weight's gradient moves by that one term
-            assert e < (1e-3 if k.startswith("mlp.") else 1e-4), (mode, k, e)
+            assert e < (1e-3 if k.startswith("mlp.") else 1e-4) * fp32_mode_slack(), (mode, k, e)
         for k, v in r[4].items():
             assert relerr(v, ref[4][k]) < 1e-6, (mode, k)
 
