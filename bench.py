@@ -199,9 +199,10 @@ def roofline_other(B, N, Mc, Md):
              lambda: ops.ChamferFn.apply(dense, gt), 2.0 * B * Md * Md, B * 2 * Md * 12 + B * 2 * Md * 8,
              "exact search over Morton-binned chunks with box lower bounds visits 5-17 % of the pairs, so the full-scan-equivalent "
              "rate exceeds the VALU peak; bit-identical outputs (tests/test_gpu_chamfer.py)")
-        valu("vnp_knn_matrix (k = 16 graph on 2048 x 2048 coordinates, config 3 first layer)", lambda: ops.knn_indices(part, part, 16),
-             1.0 * B * N * N, B * N * 12 * 2 + B * N * 16 * 4 + 2.0 * B * N * N * 4,
-             "distance matrix once (written + re-read: 2*N*N*4 B per cloud) then 16 selection passes per row")
+        valu("vnp_knn_coords_kernel (k = 16 graph on 2048 x 2048 coordinates, config 3 first layer)", lambda: ops.knn_indices(part, part, 16),
+             1.0 * B * N * N, B * N * 12 * 2 + B * N * 16 * 4,
+             "one wave per query: distances in registers, threshold selection (k-th smallest lane minimum), no distance matrix; "
+             "~10 lane-ops per pair for the distance + ~15 per pair-equivalent for the two cross-lane sorts and the compaction")
 
     # HBM-bound passes on decoder-sized operands: P = B*Md points, C = 256 channels, (p | d) pairs [P*3, 512]
     P, C = B * Md, 256

@@ -230,3 +230,30 @@ def test_edge_conv_fused_equals_unfused(lib_built, P, k, C, Pu, training):
     for name, a, b in zip(names, res[0], res[1]):
         scale = b.abs().max().item() + 1e-12
         assert (a - b).abs().max().item() <= 2e-5 * scale, (name, (a - b).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("Nr,Nq,k", [(2048, 2048, 20), (512, 512, 16), (128, 128, 16), (700, 300, 8), (4096, 100, 32), (40, 40, 40), (70, 33, 64)])
+def test_knn_coords_kernel_equals_matrix_path(lib_built, Nr, Nq, k):
+    """vnp_knn_coords_kernel (coordinate graphs: one wave per query, distances in registers, threshold selection) against the
+    distance-matrix path: identical indices and distance bits, including exact duplicates (more candidates than the 64-entry list:
+    the k-pass fallback), a reference set smaller than the wave, and k equal to the set size."""
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    k = min(k, Nr)
+    g = torch.Generator().manual_seed(Nr + Nq + k)
+    r = (torch.rand(3, Nr, 3, generator=g) - 0.5).cuda()
+    q = (r[:, :Nq] if Nq <= Nr else torch.rand(3, Nq, 3, generator=g) - 0.5).contiguous().cuda()
+    r[1, : Nr // 2] = r[1, Nr // 2: 2 * (Nr // 2)]                  # sample 1: every point twice -> exact ties everywhere
+    r[2] = r[2, :1]                                                # sample 2: all points identical -> every distance ties
+    q = q.contiguous()
+    out = []
+    for matrix in (False, True):
+        idx = torch.empty(3, Nq, k, device="cuda", dtype=torch.int32)
+        dist = torch.empty(3, Nq, k, device="cuda")
+        if matrix:
+            ws = torch.empty(3 * Nq * Nr, device="cuda")
+            call("vnp_knn_matrix", 3, 3, ptr(r), Nr, ptr(q), Nq, k, ptr(idx), ptr(dist), ptr(ws))
+        else:
+            call("vnp_knn", 3, 3, ptr(r), Nr, ptr(q), Nq, k, ptr(idx), ptr(dist))
+        out.append((idx, dist))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1].view(torch.int32), out[1][1].view(torch.int32))

@@ -217,11 +217,139 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
     return vnp_last_error();
 }
 
+// Coordinate graphs (D = 3, the kNN of every VN-DGCNN layer and of the VN-PoinTr grouper's first stage): one wave per query, the
+// sample's reference cloud staged once per workgroup in LDS, NO distance matrix.  Lane l holds the distances to references
+// l, l + 64, ... in registers (same fmaf form as vnp_knn_kernel<3>: identical bits).  Selection by a threshold instead of k scans or
+// a full sort: the k-th smallest of the 64 LANE MINIMA (one bitonic sort across the wave) is an upper bound T of the k-th smallest
+// distance (the k smallest lane minima are k distinct elements <= T); the candidates d <= T — about 1.15 k of them on spread-out
+// clouds — are compacted into a wave-private LDS list, sorted by (distance, index) across the wave and the first k written out: exact
+// ties included, the same (distance, index) order as the other kernels.  More than 64 candidates (many exact ties) or fewer than k
+// (NaN coordinates) take k selection passes over the registers, the semantics of vnp_knn_select_kernel.
+#define KNC_WAVES 4
+#define KNC_QPW 16           // queries per wave and workgroup: the 24 KB staging of a 2048-point cloud is shared by 64 queries
+template <typename T> __device__ __forceinline__ void vnp_knc_cswap(float& d, int& i, int j, bool keep_min)
+{
+    const float od = __shfl_xor(d, j); const int oi = __shfl_xor(i, j);
+    const bool other_less = od < d || (od == d && oi < i);
+    if (other_less == keep_min) { d = od; i = oi; }
+}
+template <int NPL>
+__global__ void __launch_bounds__(64 * KNC_WAVES) vnp_knn_coords_kernel(const float* __restrict__ ref, int Nr, const float* __restrict__ qry, int Nq,
+                                                                       int k, int* __restrict__ idx_out, float* __restrict__ dist_out)
+{
+    extern __shared__ __attribute__((aligned(16))) float knc_sm[];
+    float* rs = knc_sm;                                        // [Nr][3]
+    float* ld = knc_sm + (size_t)NPL * 64 * 3;                 // [KNC_WAVES][64] candidate distances
+    int* li = (int*)(ld + KNC_WAVES * 64);                     // [KNC_WAVES][64] candidate indices
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* rb = ref + (size_t)b * Nr * 3;
+    for (int i = threadIdx.x; i < Nr * 3; i += 64 * KNC_WAVES) rs[i] = rb[i];
+    __syncthreads();
+    float* wd = ld + wave * 64;
+    int* wi = li + wave * 64;
+    for (int it = 0; it < KNC_QPW; ++it) {
+        const int q = (blockIdx.x * KNC_QPW + it) * KNC_WAVES + wave;
+        if (q >= Nq) break;                                    // wave-uniform; no workgroup barrier below
+        const float* qp = qry + ((size_t)b * Nq + q) * 3;
+        const float q0 = qp[0], q1 = qp[1], q2 = qp[2];
+        float v[NPL];
+        float m = INFINITY;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            const int i = lane + 64 * u;
+            float dd = INFINITY;
+            if (i < Nr) {
+                const float dx = rs[i * 3] - q0, dy = rs[i * 3 + 1] - q1, dz = rs[i * 3 + 2] - q2;
+                dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            }
+            v[u] = dd;
+            m = fminf(m, dd);
+        }
+        // ascending bitonic sort of the lane minima across the wave; T = the k-th smallest of them (k <= 64)
+        float sm_ = m; int si = lane;
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1)
+                vnp_knc_cswap<int>(sm_, si, j, ((lane & j) == 0) == ((lane & kk) == 0));
+        const float T = __shfl(sm_, k - 1);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) cnt += (v[u] <= T) ? 1 : 0;
+        int incl = cnt;                                        // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const int total = __shfl(incl, 63);
+        const size_t obase = ((size_t)b * Nq + q) * k;
+        if (total >= k && total <= 64) {
+            int pos = incl - cnt;
+#pragma unroll
+            for (int u = 0; u < NPL; ++u)
+                if (v[u] <= T) { wd[pos] = v[u]; wi[pos] = lane + 64 * u; ++pos; }
+            __builtin_amdgcn_wave_barrier();
+            float cd = lane < total ? wd[lane] : INFINITY;
+            int ci = lane < total ? wi[lane] : 0x7fffffff;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1)
+                    vnp_knc_cswap<int>(cd, ci, j, ((lane & j) == 0) == ((lane & kk) == 0));
+            if (lane < k) {
+                idx_out[obase + lane] = ci;
+                if (dist_out) dist_out[obase + lane] = cd;
+            }
+        } else {
+            float last_d = -1.f; int last_i = -1;
+            for (int p = 0; p < k; ++p) {
+                float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                for (int u = 0; u < NPL; ++u) {
+                    const int i = lane + 64 * u;
+                    const float dd = v[u];
+                    const bool after = dd > last_d || (dd == last_d && i > last_i);
+                    if (i < Nr && after && (dd < best || (dd == best && i < bi))) { best = dd; bi = i; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                last_d = best; last_i = bi;
+                if (lane == 0) {
+                    idx_out[obase + p] = bi == 0x7fffffff ? 0 : bi;
+                    if (dist_out) dist_out[obase + p] = best;
+                }
+            }
+        }
+    }
+}
+
+template <int NPL>
+static int vnp_knn_coords_launch(hipStream_t st, int B, const float* ref, int Nr, const float* qry, int Nq, int k, int* idx, float* dist)
+{
+    static std::atomic<unsigned long long> ok{0};
+    const int lds = NPL * 64 * 3 * 4 + KNC_WAVES * 64 * 8;
+    hipError_t e = vnp_allow_dynamic_lds(ok, (const void*)vnp_knn_coords_kernel<NPL>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((vnp_knn_coords_kernel<NPL>), dim3(vnp_cdiv(Nq, KNC_WAVES * KNC_QPW), B), dim3(64 * KNC_WAVES), lds, st,
+                       ref, Nr, qry, Nq, k, idx, dist);
+    return vnp_last_error();
+}
+
 // idx [B][Nq][k] (indices local to the sample), dist (optional) squared distances.  k <= Nr.
 extern "C" int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k,
                        int* idx, float* dist)
 {
     if (!ref || !qry || !idx || B <= 0 || D <= 0 || Nr <= 0 || Nq <= 0 || k <= 0 || k > Nr || B > 65535) return VNP_EINVAL;
+    static const bool no_coords = getenv("VNP_KNN_COORDS") != nullptr && getenv("VNP_KNN_COORDS")[0] == '0';
+    if (D == 3 && Nr <= 4096 && k <= 64 && !no_coords) {
+        // one wave per query on register-resident distances, threshold selection (vnp_knn_coords_kernel)
+        if (Nr <= 512)  return vnp_knn_coords_launch<8>(st, B, ref, Nr, qry, Nq, k, idx, dist);
+        if (Nr <= 1024) return vnp_knn_coords_launch<16>(st, B, ref, Nr, qry, Nq, k, idx, dist);
+        if (Nr <= 2048) return vnp_knn_coords_launch<32>(st, B, ref, Nr, qry, Nq, k, idx, dist);
+        return vnp_knn_coords_launch<64>(st, B, ref, Nr, qry, Nq, k, idx, dist);
+    }
     if (D == 3) {
         const int tile = 1024;
         hipLaunchKernelGGL((vnp_knn_kernel<3>), dim3(vnp_cdiv(Nq, KNN_THREADS), B), dim3(KNN_THREADS), (size_t)tile * 3 * 4, st,

@@ -1237,6 +1237,10 @@ class ChamferFn(Function):
 
 
 # ------------------------------------------------------------------------------- graph ops (configs 3, 5)
+# coordinate graphs (D = 3) on the fused one-wave-per-query kernel; VNP_KNN_COORDS=0 keeps the distance-matrix path (A/B)
+KNN_COORDS = os.environ.get("VNP_KNN_COORDS", "1") != "0"
+
+
 def knn_indices(ref, query, k, return_dist=False):
     """ref [B,Nr,D], query [B,Nq,D] (point-major, fp32, contiguous) -> idx [B,Nq,k] int32 local indices, sorted by
     (squared distance, index).  Replaces KNN_CUDA (models/dgcnn.py:11,236)."""
@@ -1246,7 +1250,11 @@ def knn_indices(ref, query, k, return_dist=False):
     Nq = query.shape[1]
     idx = torch.empty((B, Nq, k), device=ref.device, dtype=torch.int32)
     dist = torch.empty((B, Nq, k), device=ref.device, dtype=torch.float32) if return_dist else None
-    if Nr <= 16384 and Nq * Nr >= 4096 and B * Nq * Nr <= (1 << 29):
+    if D == 3 and Nr <= 4096 and k <= 64 and KNN_COORDS:
+        # coordinate graphs: one wave per query on register-resident distances with a threshold selection, no distance matrix
+        # (vnp_knn_coords_kernel behind vnp_knn; same bits and order)
+        call("vnp_knn", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist))
+    elif Nr <= 16384 and Nq * Nr >= 4096 and B * Nq * Nr <= (1 << 29):
         # distance matrix once + per-row selection instead of k full passes per query (same bits as vnp_knn; ~50x faster for the
         # feature-space graphs at D = 192, ~3x for coordinates)
         ws = torch.empty(B * Nq * Nr, device=ref.device, dtype=torch.float32)
