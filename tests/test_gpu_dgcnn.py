@@ -257,3 +257,16 @@ def test_knn_coords_kernel_equals_matrix_path(lib_built, Nr, Nq, k):
         out.append((idx, dist))
     assert torch.equal(out[0][0], out[1][0])
     assert torch.equal(out[0][1].view(torch.int32), out[1][1].view(torch.int32))
+    # independent of either kernel: (distance, index) strictly ascending, and it IS the k-nearest set (fp64, as above)
+    idx, dist = out[0]
+    li = idx.long()
+    lex = (dist[..., 1:] > dist[..., :-1]) | ((dist[..., 1:] == dist[..., :-1]) & (li[..., 1:] > li[..., :-1]))
+    assert lex.all()
+    d64 = ((q.double()[:, :, None] - r.double()[:, None]) ** 2).sum(-1)
+    mine = d64.gather(2, li)
+    assert torch.allclose(dist.double(), mine, rtol=1e-5, atol=1e-12)
+    kth = d64.sort(dim=-1)[0][..., k - 1]
+    assert (mine[..., -1] <= kth * (1 + 1e-6) + 1e-12).all()
+    # exact ties (samples 1 and 2) resolve to the lowest indices: among equal distances no unselected index lies below a selected one
+    same = d64[2, 0]                                               # sample 2: every reference at the same distance
+    assert torch.equal(idx[2, 0].cpu(), torch.arange(k, dtype=torch.int32)) and float(same.max() - same.min()) == 0.0

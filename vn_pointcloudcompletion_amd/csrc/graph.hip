@@ -199,6 +199,9 @@ __global__ void __launch_bounds__(64) vnp_knn_select_sorted_kernel(const float* 
     }
 }
 
+template <int NPL>
+__global__ void vnp_knn_select_threshold_kernel(const float* __restrict__ dist, int Nr, int k, int* __restrict__ idx_out, float* __restrict__ dist_out);
+
 // Same contract as vnp_knn with a caller-provided distance matrix: ws of B*Nq*Nr floats.  Any D; Nr <= 16384.
 extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const float* qry, int Nq, int k,
                               int* idx, float* dist, float* ws)
@@ -210,6 +213,15 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
     hipError_t e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_knn_select_kernel, 16384 * 4);
     if (e != hipSuccess) return (int)e;
     const dim3 rows((unsigned)((long long)B * Nq));
+    static const bool sorted_cols = getenv("VNP_KNN_SORTED_COLUMNS") != nullptr;          // A/B: the sorted-column selection
+    // threshold selection (vnp_knc_select, defined with the coordinate kernel below): k <= 64
+    if (k <= 64 && Nr <= 4096 && !sorted_cols) {
+        if (Nr <= 512)       hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<8>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+        else if (Nr <= 1024) hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<16>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+        else if (Nr <= 2048) hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<32>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+        else                 hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<64>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
+        return vnp_last_error();
+    }
     if (Nr <= 512)       hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<8>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
     else if (Nr <= 1024) hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<16>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
     else if (Nr <= 2048) hipLaunchKernelGGL(vnp_knn_select_sorted_kernel<32>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
@@ -233,6 +245,70 @@ template <typename T> __device__ __forceinline__ void vnp_knc_cswap(float& d, in
     const bool other_less = od < d || (od == d && oi < i);
     if (other_less == keep_min) { d = od; i = oi; }
 }
+// Threshold selection of the k smallest of a wave's 64 * NPL register-resident values v[u] (element index lane + 64 u; INFINITY past Nr),
+// m = the lane's minimum: see vnp_knn_coords_kernel.  wd / wi: 64-entry wave-private LDS lists.  Writes io[0..k) (and dio) in
+// (value, index) ascending order.
+template <int NPL>
+__device__ __forceinline__ void vnp_knc_select(const float (&v)[NPL], float m, int Nr, int k, int lane, float* wd, int* wi, int* io, float* dio)
+{
+    // ascending bitonic sort of the lane minima across the wave; T = the k-th smallest of them (k <= 64)
+    float sm_ = m; int si = lane;
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1)
+            vnp_knc_cswap<int>(sm_, si, j, ((lane & j) == 0) == ((lane & kk) == 0));
+    const float T = __shfl(sm_, k - 1);
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) cnt += (v[u] <= T) ? 1 : 0;
+    int incl = cnt;                                        // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int total = __shfl(incl, 63);
+        if (total >= k && total <= 64) {
+        int pos = incl - cnt;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u)
+            if (v[u] <= T) { wd[pos] = v[u]; wi[pos] = lane + 64 * u; ++pos; }
+        __builtin_amdgcn_wave_barrier();
+        float cd = lane < total ? wd[lane] : INFINITY;
+        int ci = lane < total ? wi[lane] : 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1)
+                vnp_knc_cswap<int>(cd, ci, j, ((lane & j) == 0) == ((lane & kk) == 0));
+        if (lane < k) {
+            io[lane] = ci;
+            if (dio) dio[lane] = cd;
+        }
+    } else {
+        float last_d = -1.f; int last_i = -1;
+        for (int p = 0; p < k; ++p) {
+            float best = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int u = 0; u < NPL; ++u) {
+                const int i = lane + 64 * u;
+                const float dd = v[u];
+                const bool after = dd > last_d || (dd == last_d && i > last_i);
+                if (i < Nr && after && (dd < best || (dd == best && i < bi))) { best = dd; bi = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            last_d = best; last_i = bi;
+            if (lane == 0) {
+                io[p] = bi == 0x7fffffff ? 0 : bi;
+                if (dio) dio[p] = best;
+            }
+        }
+    }
+}
+
 template <int NPL>
 __global__ void __launch_bounds__(64 * KNC_WAVES) vnp_knn_coords_kernel(const float* __restrict__ ref, int Nr, const float* __restrict__ qry, int Nq,
                                                                        int k, int* __restrict__ idx_out, float* __restrict__ dist_out)
@@ -265,64 +341,25 @@ __global__ void __launch_bounds__(64 * KNC_WAVES) vnp_knn_coords_kernel(const fl
             v[u] = dd;
             m = fminf(m, dd);
         }
-        // ascending bitonic sort of the lane minima across the wave; T = the k-th smallest of them (k <= 64)
-        float sm_ = m; int si = lane;
-#pragma unroll
-        for (int kk = 2; kk <= 64; kk <<= 1)
-#pragma unroll
-            for (int j = kk >> 1; j > 0; j >>= 1)
-                vnp_knc_cswap<int>(sm_, si, j, ((lane & j) == 0) == ((lane & kk) == 0));
-        const float T = __shfl(sm_, k - 1);
-        int cnt = 0;
-#pragma unroll
-        for (int u = 0; u < NPL; ++u) cnt += (v[u] <= T) ? 1 : 0;
-        int incl = cnt;                                        // inclusive prefix sum over the lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        const int total = __shfl(incl, 63);
-        const size_t obase = ((size_t)b * Nq + q) * k;
-        if (total >= k && total <= 64) {
-            int pos = incl - cnt;
-#pragma unroll
-            for (int u = 0; u < NPL; ++u)
-                if (v[u] <= T) { wd[pos] = v[u]; wi[pos] = lane + 64 * u; ++pos; }
-            __builtin_amdgcn_wave_barrier();
-            float cd = lane < total ? wd[lane] : INFINITY;
-            int ci = lane < total ? wi[lane] : 0x7fffffff;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int kk = 2; kk <= 64; kk <<= 1)
-#pragma unroll
-                for (int j = kk >> 1; j > 0; j >>= 1)
-                    vnp_knc_cswap<int>(cd, ci, j, ((lane & j) == 0) == ((lane & kk) == 0));
-            if (lane < k) {
-                idx_out[obase + lane] = ci;
-                if (dist_out) dist_out[obase + lane] = cd;
-            }
-        } else {
-            float last_d = -1.f; int last_i = -1;
-            for (int p = 0; p < k; ++p) {
-                float best = INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-                for (int u = 0; u < NPL; ++u) {
-                    const int i = lane + 64 * u;
-                    const float dd = v[u];
-                    const bool after = dd > last_d || (dd == last_d && i > last_i);
-                    if (i < Nr && after && (dd < best || (dd == best && i < bi))) { best = dd; bi = i; }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-                    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-                }
-                last_d = best; last_i = bi;
-                if (lane == 0) {
-                    idx_out[obase + p] = bi == 0x7fffffff ? 0 : bi;
-                    if (dist_out) dist_out[obase + p] = best;
-                }
-            }
-        }
+        vnp_knc_select<NPL>(v, m, Nr, k, lane, wd, wi, idx_out + ((size_t)b * Nq + q) * k, dist_out ? dist_out + ((size_t)b * Nq + q) * k : nullptr);
     }
+}
+
+// the same selection for rows of a precomputed distance matrix (feature-space graphs, any D): one wave per row
+template <int NPL>
+__global__ void __launch_bounds__(64) vnp_knn_select_threshold_kernel(const float* __restrict__ dist, int Nr, int k, int* __restrict__ idx_out,
+                                                                     float* __restrict__ dist_out)
+{
+    __shared__ float wd[64];
+    __shared__ int wi[64];
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* d = dist + row * Nr;
+    float v[NPL];
+    float m = INFINITY;
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) { const int i = lane + 64 * u; v[u] = i < Nr ? d[i] : INFINITY; m = fminf(m, v[u]); }
+    vnp_knc_select<NPL>(v, m, Nr, k, lane, wd, wi, idx_out + row * k, dist_out ? dist_out + row * k : nullptr);
 }
 
 template <int NPL>
