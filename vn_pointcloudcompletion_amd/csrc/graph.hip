@@ -238,7 +238,9 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
 // ties included, the same (distance, index) order as the other kernels.  More than 64 candidates (many exact ties) or fewer than k
 // (NaN coordinates) take k selection passes over the registers, the semantics of vnp_knn_select_kernel.
 #define KNC_WAVES 4
-#define KNC_QPW 16           // queries per wave and workgroup: the 24 KB staging of a 2048-point cloud is shared by 64 queries
+#define KNC_QPW 16           // queries per wave and workgroup at most: the 24 KB staging of a 2048-point cloud is shared by 64 queries
+                             // (fewer when the graph is small: a wave walks its queries one after the other, and 128-point graphs left
+                             // the chip to 64 workgroups of 16 dependent rounds each)
 template <typename T> __device__ __forceinline__ void vnp_knc_cswap(float& d, int& i, int j, bool keep_min)
 {
     const float od = __shfl_xor(d, j); const int oi = __shfl_xor(i, j);
@@ -311,7 +313,7 @@ __device__ __forceinline__ void vnp_knc_select(const float (&v)[NPL], float m, i
 
 template <int NPL>
 __global__ void __launch_bounds__(64 * KNC_WAVES) vnp_knn_coords_kernel(const float* __restrict__ ref, int Nr, const float* __restrict__ qry, int Nq,
-                                                                       int k, int* __restrict__ idx_out, float* __restrict__ dist_out)
+                                                                       int k, int qpw, int* __restrict__ idx_out, float* __restrict__ dist_out)
 {
     extern __shared__ __attribute__((aligned(16))) float knc_sm[];
     float* rs = knc_sm;                                        // [Nr][3]
@@ -323,8 +325,8 @@ __global__ void __launch_bounds__(64 * KNC_WAVES) vnp_knn_coords_kernel(const fl
     __syncthreads();
     float* wd = ld + wave * 64;
     int* wi = li + wave * 64;
-    for (int it = 0; it < KNC_QPW; ++it) {
-        const int q = (blockIdx.x * KNC_QPW + it) * KNC_WAVES + wave;
+    for (int it = 0; it < qpw; ++it) {
+        const int q = (blockIdx.x * qpw + it) * KNC_WAVES + wave;
         if (q >= Nq) break;                                    // wave-uniform; no workgroup barrier below
         const float* qp = qry + ((size_t)b * Nq + q) * 3;
         const float q0 = qp[0], q1 = qp[1], q2 = qp[2];
@@ -369,8 +371,11 @@ static int vnp_knn_coords_launch(hipStream_t st, int B, const float* ref, int Nr
     const int lds = NPL * 64 * 3 * 4 + KNC_WAVES * 64 * 8;
     hipError_t e = vnp_allow_dynamic_lds(ok, (const void*)vnp_knn_coords_kernel<NPL>, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vnp_knn_coords_kernel<NPL>), dim3(vnp_cdiv(Nq, KNC_WAVES * KNC_QPW), B), dim3(64 * KNC_WAVES), lds, st,
-                       ref, Nr, qry, Nq, k, idx, dist);
+    // queries per wave: as many as keep ~1024 workgroups on the chip, at most KNC_QPW
+    long long qpw = (long long)B * Nq / (KNC_WAVES * 1024);
+    qpw = qpw < 1 ? 1 : qpw > KNC_QPW ? KNC_QPW : qpw;
+    hipLaunchKernelGGL((vnp_knn_coords_kernel<NPL>), dim3(vnp_cdiv(Nq, KNC_WAVES * (int)qpw), B), dim3(64 * KNC_WAVES), lds, st,
+                       ref, Nr, qry, Nq, k, (int)qpw, idx, dist);
     return vnp_last_error();
 }
 
