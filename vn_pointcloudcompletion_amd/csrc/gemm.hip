@@ -269,7 +269,11 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     // activations on M: 192-row tiles; a row count that 128 divides but 192 does not (65536 points: the per-point GEMMs of
     // vnp_vn_dir_layer) takes 128-row tiles on the aligned kernel instead of 192-row tiles on the bounds-checked one (120 -> 165 TFLOP/s)
     const bool rows128 = op_a == 0 && vnp_gemm_get_mode() == 0 && M % 192 != 0 && M % 128 == 0 && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a;
-    const int bm = (op_a == 0 && !rows128) ? 192 : 128;
+    // ... and the per-sample layers (M = 3 B = 96 rows: coarse head, decoder bias) 96-row tiles instead of half-empty 192-row ones
+    const bool rows96 = op_a == 0 && vnp_gemm_get_mode() == 0 && M == 96 && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a && !bias &&
+                        (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && nbatch == 1 &&
+                        getenv("VNP_GEMM_NO_ROWS96") == nullptr;
+    const int bm = rows96 ? 96 : (op_a == 0 && !rows128) ? 192 : 128;
     const long long items = (long long)vnp_cdiv(M, bm) * vnp_cdiv(N, 128) * nsplit * nbatch;
     if (items > 2147483647LL) return VNP_EINVAL;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
@@ -293,7 +297,11 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p);   \
         }                                                                                                               \
     } while (0)
-    if (rows128 && fast) {
+    if (rows96) {
+        if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, true, true>), grid, block, 0, stream, p);
+        else           hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, false, true>), grid, block, 0, stream, p);
+    }
+    else if (rows128 && fast) {
         if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<128, 128, true, true, true>), grid, block, 0, stream, p);
         else           hipLaunchKernelGGL((vnp_gemm_split_kernel<128, 128, true, false, true>), grid, block, 0, stream, p);
     }
