@@ -286,8 +286,16 @@ int vnp_vn_dir_layer(hipStream_t st, int mode, const float* v, int ldv, const fl
                      const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
                      float* out, int ldo, const float* go, int ldgo, float* partial, const float* S, long long count,
                      float* gv, int ldgv, float* colsum);
-/* u[n] = xyz[n] / |xyz[n]| (0 for the origin), [P][3] */
+/* the same with scalar_io != 0: the layer's OUTPUT is parallel to u as well (bias == NULL: the single-channel first layer of VN_PointNet,
+ * models/pcn.py:165-167), so out [P][ldo] = sum_t u_t out_t and go [P][ldgo] (dL/dout_t = u_t go) are one scalar per (point, channel) */
+int vnp_vn_dir_layer_ex(hipStream_t st, int mode, const float* v, int ldv, const float* u, const float* bias, int ldb,
+                        long long P, int C, int points_per_group, int chunk_points,
+                        const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                        float* out, int ldo, const float* go, int ldgo, float* partial, const float* S, long long count,
+                        float* gv, int ldgv, float* colsum, int scalar_io);
+/* u[n] = xyz[n] / |xyz[n]| (0 for the origin), [P][3]; _r: also r[n] = |xyz[n]| (r may be NULL) */
 int vnp_unit_dirs(hipStream_t st, const float* xyz, long long P, float* u);
+int vnp_unit_dirs_r(hipStream_t st, const float* xyz, long long P, float* u, float* r);
 /* expand = 0: h[n][c] = sum_t u[n][t] rows[(n,t)][c];  expand = 1: rows[(n,t)][c] = u[n][t] h[n][c];  expand = 2: rows += u h */
 int vnp_dir_contract(hipStream_t st, float* rows, int ldr, const float* u, float* h, int ldh, long long P, int C, int expand);
 

@@ -112,7 +112,9 @@ _SIGNATURES = {
     "vnp_fold_fused": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll,
                        _vp, _vp, _i],
     "vnp_vn_dir_layer": [_i, _vp, _i, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _i, _vp],
+    "vnp_vn_dir_layer_ex": [_i, _vp, _i, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _i, _vp, _i],
     "vnp_unit_dirs": [_vp, _ll, _vp],
+    "vnp_unit_dirs_r": [_vp, _ll, _vp, _vp],
     "vnp_dir_contract": [_vp, _i, _vp, _vp, _i, _ll, _i, _i],
     "vnp_rowdot": [_vp, _i, _vp, _ll, _i, _vp, _i, _vp],
     "vnp_group_sum3": [_vp, _ll, _i, _vp, _i],

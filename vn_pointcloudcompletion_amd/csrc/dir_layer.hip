@@ -31,6 +31,8 @@ struct VnpDirArgs {
     const float* S; float inv_count;      // MODE 3: reduced sums [C][2] (nullptr in eval mode)
     float* gv; int ldgv;                  // MODE 3: [P, 2C]
     float* colsum;                        // MODE 3: [nchunk][3][2C] or nullptr
+    int scalar_io;                        // the OUTPUT is parallel to u as well (no bias: the single-channel first layer itself): out and go
+                                          // are per-point scalars [P][C] (out = sum_t u_t out_t; dL/dout_t = u_t go) instead of rows [P*3][C]
 };
 
 __device__ __forceinline__ float vnp_dl_sq3(float a, float b, float c) { return a * a + b * b + c * c; }
@@ -88,8 +90,13 @@ __global__ void __launch_bounds__(256) vnp_dir_layer_kernel(const VnpDirArgs a)
                 vp[i] = __builtin_nontemporal_load(a.v + (size_t)q * a.ldv + c);
                 vd[i] = MODE >= 1 ? __builtin_nontemporal_load(a.v + (size_t)q * a.ldv + C + c) : 0.f;
                 if (MODE >= 2) {
-                    const float* rg = a.go + (size_t)q * 3 * a.ldgo + c;
-                    g0[i] = __builtin_nontemporal_load(rg); g1[i] = __builtin_nontemporal_load(rg + a.ldgo); g2[i] = __builtin_nontemporal_load(rg + 2 * (size_t)a.ldgo);
+                    if (a.scalar_io) {
+                        const float gh = __builtin_nontemporal_load(a.go + (size_t)q * a.ldgo + c);
+                        g0[i] = u0[i] * gh; g1[i] = u1[i] * gh; g2[i] = u2[i] * gh;
+                    } else {
+                        const float* rg = a.go + (size_t)q * 3 * a.ldgo + c;
+                        g0[i] = __builtin_nontemporal_load(rg); g1[i] = __builtin_nontemporal_load(rg + a.ldgo); g2[i] = __builtin_nontemporal_load(rg + 2 * (size_t)a.ldgo);
+                    }
                 }
             }
 #pragma unroll
@@ -116,6 +123,7 @@ __global__ void __launch_bounds__(256) vnp_dir_layer_kernel(const VnpDirArgs a)
                         const float al = (1.f - a.ns) * dot / (vnp_dl_sq3(d0, d1, d2) + VNP_EPS);
                         o0 -= al * d0; o1 -= al * d1; o2 -= al * d2;
                     }
+                    if (a.scalar_io) { __builtin_nontemporal_store(u0[i] * o0 + u1[i] * o1 + u2[i] * o2, a.out + (size_t)pt * a.ldo + c); continue; }
                     float* o = a.out + (size_t)pt * 3 * a.ldo + c;
                     __builtin_nontemporal_store(o0, o); __builtin_nontemporal_store(o1, o + a.ldo); __builtin_nontemporal_store(o2, o + 2 * (size_t)a.ldo);
                     continue;
@@ -185,12 +193,14 @@ __global__ void __launch_bounds__(256) vnp_dir_layer_kernel(const VnpDirArgs a)
 
 // mode 0: statistics partials [nchunk][C][2]; 1: forward; 2: backward sums [nchunk][C][2]; 3: backward gradients.
 // chunk_points must divide points_per_group when bias is given (a chunk takes its bias rows from one group).
-extern "C" int vnp_vn_dir_layer(hipStream_t st, int mode, const float* v, int ldv, const float* u, const float* bias, int ldb,
-                                long long P, int C, int points_per_group, int chunk_points,
-                                const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
-                                float* out, int ldo, const float* go, int ldgo, float* partial, const float* S, long long count,
-                                float* gv, int ldgv, float* colsum)
+// scalar_io != 0 (bias must be NULL): the layer's OUTPUT is parallel to u too, so out [P][ldo] and go [P][ldgo] are per-point scalars
+extern "C" int vnp_vn_dir_layer_ex(hipStream_t st, int mode, const float* v, int ldv, const float* u, const float* bias, int ldb,
+                                   long long P, int C, int points_per_group, int chunk_points,
+                                   const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                                   float* out, int ldo, const float* go, int ldgo, float* partial, const float* S, long long count,
+                                   float* gv, int ldgv, float* colsum, int scalar_io)
 {
+    if (scalar_io && bias) return VNP_EINVAL;
     if (!v || !u || P <= 0 || C <= 0 || mode < 0 || mode > 3 || chunk_points < 4 || chunk_points > 1024) return VNP_EINVAL;
     if (bias && (points_per_group <= 0 || points_per_group % chunk_points != 0 || P % points_per_group != 0)) return VNP_EINVAL;
     if (mode > 0 && (!mean || !rstd || !gamma || !beta)) return VNP_EINVAL;
@@ -205,6 +215,7 @@ extern "C" int vnp_vn_dir_layer(hipStream_t st, int mode, const float* v, int ld
     a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
     a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo; a.partial = (float2*)partial;
     a.S = S; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f; a.gv = gv; a.ldgv = ldgv; a.colsum = colsum;
+    a.scalar_io = scalar_io ? 1 : 0;
     dim3 grid(vnp_cdiv(C, 64), vnp_cdiv(P, chunk_points)), block(256);
     if (mode == 0) hipLaunchKernelGGL(vnp_dir_layer_kernel<0>, grid, block, 0, st, a);
     else if (mode == 1) hipLaunchKernelGGL(vnp_dir_layer_kernel<1>, grid, block, 0, st, a);
@@ -213,8 +224,18 @@ extern "C" int vnp_vn_dir_layer(hipStream_t st, int mode, const float* v, int ld
     return vnp_last_error();
 }
 
-// u[n] = x[n] / |x[n]|  (0 for the origin)
-__global__ void __launch_bounds__(256) vnp_unit_dirs_kernel(const float* __restrict__ xyz, long long P, float* __restrict__ u)
+extern "C" int vnp_vn_dir_layer(hipStream_t st, int mode, const float* v, int ldv, const float* u, const float* bias, int ldb,
+                                long long P, int C, int points_per_group, int chunk_points,
+                                const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                                float* out, int ldo, const float* go, int ldgo, float* partial, const float* S, long long count,
+                                float* gv, int ldgv, float* colsum)
+{
+    return vnp_vn_dir_layer_ex(st, mode, v, ldv, u, bias, ldb, P, C, points_per_group, chunk_points, mean, rstd, gamma, beta, negative_slope,
+                               out, ldo, go, ldgo, partial, S, count, gv, ldgv, colsum, 0);
+}
+
+// u[n] = x[n] / |x[n]|  (0 for the origin); r (nullable) [P] = |x[n]|
+__global__ void __launch_bounds__(256) vnp_unit_dirs_kernel(const float* __restrict__ xyz, long long P, float* __restrict__ u, float* __restrict__ rr)
 {
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     if (n >= P) return;
@@ -222,14 +243,17 @@ __global__ void __launch_bounds__(256) vnp_unit_dirs_kernel(const float* __restr
     const float r = sqrtf(vnp_dl_sq3(x0, x1, x2));
     const float inv = r > 0.f ? 1.f / r : 0.f;
     u[n * 3] = x0 * inv; u[n * 3 + 1] = x1 * inv; u[n * 3 + 2] = x2 * inv;
+    if (rr) rr[n] = r;
 }
 
-extern "C" int vnp_unit_dirs(hipStream_t st, const float* xyz, long long P, float* u)
+extern "C" int vnp_unit_dirs_r(hipStream_t st, const float* xyz, long long P, float* u, float* r)
 {
     if (!xyz || !u || P <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_unit_dirs_kernel, dim3(vnp_cdiv(P, 256)), dim3(256), 0, st, xyz, P, u);
+    hipLaunchKernelGGL(vnp_unit_dirs_kernel, dim3(vnp_cdiv(P, 256)), dim3(256), 0, st, xyz, P, u, r);
     return vnp_last_error();
 }
+
+extern "C" int vnp_unit_dirs(hipStream_t st, const float* xyz, long long P, float* u) { return vnp_unit_dirs_r(st, xyz, P, u, nullptr); }
 
 // h[n][c] = sum_t u_t(n) a[(n, t)][c]   (the scalar of a map whose vectors are parallel to u);   expand = 0
 // a[(n, t)][c] (+)= u_t(n) h[n][c]       (its adjoint, and the way back to the rows layout);       expand = 1 (accumulate: 2)

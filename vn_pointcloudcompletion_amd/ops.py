@@ -49,6 +49,9 @@ ENC_LINEAR_REASSOCIATE = _os.environ.get("VNP_ENC_AS_WRITTEN", "0") != "1"
 # ... and, since every VN vector behind VN_PointNet's single-channel first layer is parallel to its point's direction, run that layer on
 # per-point scalars (VNDirLinearLeakyFn: a third of the GEMM rows, no [P*3, 2C] pre-activation tensor); VNP_ENC_DIR_LAYER=0 keeps the rows form
 ENC_DIR_LAYER = _os.environ.get("VNP_ENC_DIR_LAYER", "1") != "0"
+# ... and the single-channel first layer itself on the per-point scalar |x| (scalar output); VNP_ENC_FIRST_LAYER_SCALAR=0 keeps it in the
+# rows layout and takes the scalars by contraction with the unit directions
+ENC_FIRST_LAYER_SCALAR = _os.environ.get("VNP_ENC_FIRST_LAYER_SCALAR", "1") != "0"
 # VNLinear -> VNMaxPool with a small contraction (K < this): the full fused epilogue costs less than the screened search's fixed passes
 POOL_SCREEN_MIN_K = 256
 # Opt-in (VNP_GEMM_FP16X2=1): large aligned GEMMs (K >= 64) on two fp16 planes of the power-of-two scaled operands and three MFMA products
@@ -573,13 +576,39 @@ class VNLinearLeakyFn(Function):
         return gx, gWf, gWd, ggamma, gbeta, None, None, gb, None, None, None, None
 
 
-def unit_dirs(xyz):
-    """[.., 3] points -> [P, 3] unit directions x / |x| (0 for the origin); no gradient (a function of the input cloud only)."""
+def unit_dirs(xyz, return_norm=False):
+    """[.., 3] points -> [P, 3] unit directions x / |x| (0 for the origin) and, with ``return_norm``, the norms |x| [P, 1]; no gradient
+    (functions of the input cloud only)."""
     x = xyz.detach().reshape(-1, 3).contiguous().float()
     _lib.require_gpu(x)
     u = torch.empty_like(x)
-    call("vnp_unit_dirs", ptr(x), x.shape[0], ptr(u))
-    return u
+    r = torch.empty((x.shape[0], 1), device=x.device, dtype=torch.float32) if return_norm else None
+    call("vnp_unit_dirs_r", ptr(x), x.shape[0], ptr(u), ptr(r))
+    return (u, r) if return_norm else u
+
+
+class DirExpandFn(Function):
+    """Per-point scalars h [P, C] of a map parallel to the unit directions u -> its rows u (x) h [P*3, C]; backward: the contraction
+    sum_t u_t g_t (the adjoint; DirContractFn the other way round)."""
+
+    @staticmethod
+    def forward(ctx, h, u):
+        h = _rows(h)
+        P, C = h.shape
+        rows = torch.empty((P * 3, C), device=h.device, dtype=torch.float32)
+        call("vnp_dir_contract", ptr(rows), C, ptr(u), ptr(h), _ld(h), P, C, 1)
+        ctx.save_for_backward(u)
+        return rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (u,) = ctx.saved_tensors
+        g = _rows(g)
+        P, C = g.shape[0] // 3, g.shape[1]
+        gh = torch.empty((P, C), device=g.device, dtype=torch.float32)
+        call("vnp_dir_contract", ptr(g), _ld(g), ptr(u), ptr(gh), C, P, C, 0)
+        return gh, None
 
 
 class DirContractFn(Function):
@@ -628,7 +657,13 @@ class VNDirLinearLeakyFn(Function):
         return (not has_bias) or (points_per_group > 0 and points_per_group % chunk == 0 and P % points_per_group == 0)
 
     @staticmethod
-    def forward(ctx, h, u, Wf, Wd, gamma, beta, running_mean, running_var, bias, points_per_group, training, ns, folded=False):
+    def forward(ctx, h, u, Wf, Wd, gamma, beta, running_mean, running_var, bias, points_per_group, training, ns, folded=False,
+                scalar_out=False):
+        """``scalar_out`` (needs ``bias is None``): the output is parallel to u as well — the single-channel first layer itself — and is
+        returned as per-point scalars [P, C]; the upstream gradient then comes as [P, C] too."""
+        if scalar_out and bias is not None:
+            raise _lib.VnpError("VNDirLinearLeakyFn: scalar_out needs a layer without per-sample bias")
+        sio = 1 if scalar_out else 0
         h = _rows(h)
         P, C = h.shape[0], Wf.shape[0]
         dev = h.device
@@ -640,7 +675,7 @@ class VNDirLinearLeakyFn(Function):
         common = (ptr(v), 2 * C, ptr(u), ptr(bias), _ld(bias) if bias is not None else 0, P, C, points_per_group, chunk)
         if training:
             part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-            call("vnp_vn_dir_layer", 0, *common, None, None, None, None, ns, None, 0, None, 0, ptr(part), None, 0, None, 0, None)
+            call("vnp_vn_dir_layer_ex", 0, *common, None, None, None, None, ns, None, 0, None, 0, ptr(part), None, 0, None, 0, None, sio)
             mean = torch.empty(C, device=dev, dtype=torch.float32)
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
             call("vnp_vn_bn_finalize_chunked", ptr(part), nch, chunk, C, P, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
@@ -649,33 +684,33 @@ class VNDirLinearLeakyFn(Function):
             mean = running_mean
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
             call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
-        out = torch.empty((P * 3, C), device=dev, dtype=torch.float32)
-        call("vnp_vn_dir_layer", 1, *common, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns, ptr(out), C, None, 0, None, None, 0,
-             None, 0, None)
-        _trace("dir_layer")
+        out = torch.empty((P if scalar_out else P * 3, C), device=dev, dtype=torch.float32)
+        call("vnp_vn_dir_layer_ex", 1, *common, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns, ptr(out), C, None, 0, None, None, 0,
+             None, 0, None, sio)
+        _trace("dir_layer_scalar_out" if scalar_out else "dir_layer")
         ctx.save_for_backward(h, u, Wcat, v, bias, gamma, beta, mean, rstd)
-        ctx.cfg = (C, points_per_group, training, ns, bool(folded), chunk, nch)
+        ctx.cfg = (C, points_per_group, training, ns, bool(folded), chunk, nch, sio)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, go):
         h, u, Wcat, v, bias, gamma, beta, mean, rstd = ctx.saved_tensors
-        C, ppg, training, ns, folded, chunk, nch = ctx.cfg
+        C, ppg, training, ns, folded, chunk, nch, sio = ctx.cfg
         P = h.shape[0]
         dev = h.device
         go = _rows(go)
         common = (ptr(v), 2 * C, ptr(u), ptr(bias), _ld(bias) if bias is not None else 0, P, C, ppg, chunk)
         stats = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
         part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
-        call("vnp_vn_dir_layer", 2, *common, *stats, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, 0, None)
+        call("vnp_vn_dir_layer_ex", 2, *common, *stats, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, 0, None, sio)
         S = torch.empty((C, 2), device=dev, dtype=torch.float32)
         call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
         want_gb = bias is not None and ctx.needs_input_grad[8]
         gv = torch.empty((P, 2 * C), device=dev, dtype=torch.float32)
         cs_part = torch.empty((nch, 3, 2 * C), device=dev, dtype=torch.float32) if want_gb else None
-        call("vnp_vn_dir_layer", 3, *common, *stats, None, 0, ptr(go), _ld(go), None, ptr(S) if training else None, P,
-             ptr(gv), 2 * C, ptr(cs_part))
+        call("vnp_vn_dir_layer_ex", 3, *common, *stats, None, 0, ptr(go), _ld(go), None, ptr(S) if training else None, P,
+             ptr(gv), 2 * C, ptr(cs_part), sio)
         gb = None
         if want_gb:
             nb, cps = P // ppg, ppg // chunk
@@ -685,7 +720,7 @@ class VNDirLinearLeakyFn(Function):
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             gW = _wgrad(gv, h, fine=folded)
             gWf, gWd = gW[:C], gW[C:]
-        return gh, None, gWf, gWd, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, gb, None, None, None, None
+        return gh, None, gWf, gWd, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, gb, None, None, None, None, None
 
 
 class VNLinearLeakyOutFn(Function):

@@ -13,7 +13,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .vn_layers import VNLinear, VNLinearAndLeakyReLU, VNLinearLeakyReLU, VNMaxPool
 
 
@@ -56,22 +56,33 @@ class VN_PointNet(nn.Module):
 
     def forward(self, xyz):
         B, N, _ = xyz.shape
-        x = xyz.contiguous().float().reshape(B * N * 3, 1)                       # rows layout with C = 1 IS xyz
-        a1 = self.first_conv[0].forward_rows(x)
         W1 = self.first_conv[1].map_to_feat.weight
+        l1, l2 = self.first_conv[0], self.second_conv[0]
+        dir_ok = (ops.ENC_LINEAR_REASSOCIATE and ops.ENC_DIR_LAYER and not l1.share_nonlinearity and not l2.share_nonlinearity
+                  and ops.VNDirLinearLeakyFn.supported(B * N, l2.map_to_feat.weight.shape[0], N, True))
+        # first_conv[0] has ONE input channel, the point itself (x = u |x| with the unit direction u): each of its output vectors is a
+        # multiple of u, a1 = u (x) h, and second_conv[0] — folded onto first_conv[1]'s 128 input channels, see below — runs on the
+        # per-point scalars h and rebuilds its pre-activations u v + bias in registers (ops.VNDirLinearLeakyFn)
+        if dir_ok and ops.ENC_FIRST_LAYER_SCALAR and _lib.get_gemm_mode() == "split":
+            # the first layer itself on the per-point scalar |x|, returning h (scalar_out); the rows u (x) h are written once, for
+            # maxpool1's fused GEMM.  (Default GEMM mode only: VNP_GEMM_MODE=fp32 is the conservative comparison path and keeps the
+            # first layer in the rows layout)
+            u, r = ops.unit_dirs(xyz, return_norm=True)
+            h = l1.forward_dir(r, u, scalar_out=True)                                # [B*N, 128]
+            a1 = ops.DirExpandFn.apply(h, u)                                         # [B*N*3, 128]
+        else:
+            x = xyz.contiguous().float().reshape(B * N * 3, 1)                       # rows layout with C = 1 IS xyz
+            a1 = l1.forward_rows(x)
+            if dir_ok:
+                u = ops.unit_dirs(xyz)
+                h = ops.DirContractFn.apply(a1, u)
         if ops.ENC_LINEAR_REASSOCIATE:
             # first_conv[1] is a linear map whose output f = W1 a1 [B*N*3, 512] feeds maxpool1 and — behind the concatenation —
             # second_conv[0]'s linear maps (pcn.py:168-173): the pool takes f from its fused GEMM without storing it, and
             # second_conv[0] contracts (W W1) with a1 over first_conv[1]'s 128 input channels instead of W with f over 512
             g1, _ = ops.VNLinearMaxPoolFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)      # g1 [B*3, 512]
-            l2 = self.second_conv[0]
-            if (ops.ENC_DIR_LAYER and not l2.share_nonlinearity
-                    and ops.VNDirLinearLeakyFn.supported(B * N, l2.map_to_feat.weight.shape[0], N, True)):
-                # first_conv[0] has ONE input channel, the point itself: each of its output vectors is a multiple of the point's unit
-                # direction u, a1 = u (x) h.  second_conv[0] then runs on the per-point scalars h (a third of the GEMM rows) and
-                # rebuilds its pre-activations u v + bias in registers (ops.VNDirLinearLeakyFn)
-                u = ops.unit_dirs(xyz)
-                f = l2.forward_dir(ops.DirContractFn.apply(a1, u), u, global_rows=g1, points_per_group=N, pre_linear=W1)
+            if dir_ok:
+                f = l2.forward_dir(h, u, global_rows=g1, points_per_group=N, pre_linear=W1)
             else:
                 f = l2.forward_rows(a1, global_rows=g1, rows_per_group=N * 3, pre_linear=W1)
         else:
@@ -82,7 +93,7 @@ class VN_PointNet(nn.Module):
             else:
                 f = self.first_conv[1].forward_rows(a1)
                 f, g1 = self.maxpool1.forward_rows_tap(f, B, N, producer=(a1, self.first_conv[1]))   # g1 [B*3, 512]
-            f = self.second_conv[0].forward_rows(f, global_rows=g1, rows_per_group=N * 3)
+            f = l2.forward_rows(f, global_rows=g1, rows_per_group=N * 3)
         # second_conv[1] + maxpool2 fused: the linear output has no other consumer, so its (one-point-per-channel)
         # gradient is never materialised (ops.VNLinearMaxPoolFn)
         g2, _ = ops.VNLinearMaxPoolFn.apply(f, self.second_conv[1].map_to_feat.weight,

@@ -152,10 +152,11 @@ class VNLinearLeakyReLU(nn.Module):
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                          rows_per_group, self.training, self.negative_slope, pre_linear is not None)
 
-    def forward_dir(self, h, u, global_rows=None, points_per_group=0, pre_linear=None):
+    def forward_dir(self, h, u, global_rows=None, points_per_group=0, pre_linear=None, scalar_out=False):
         """The layer on a map u (x) h whose VN vectors are parallel to one unit direction ``u`` [P, 3] per point, given as per-point
         scalars ``h`` [P, K] (ops.VNDirLinearLeakyFn); ``global_rows`` / ``pre_linear`` as in forward_rows (global channels first).
-        Returns rows [P*3, C]."""
+        Returns rows [P*3, C], or — ``scalar_out``, for a layer without ``global_rows``, whose output is parallel to u again — the
+        per-point scalars [P, C] of its output."""
         bn = self.batchnorm.bn
         self.batchnorm._tick()
         Wf, Wd = self.map_to_feat.weight, self.map_to_dir.weight
@@ -170,7 +171,7 @@ class VNLinearLeakyReLU(nn.Module):
             ops._trace("linear_folded_onto_producer")
             Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
         return ops.VNDirLinearLeakyFn.apply(h, u, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
-                                            points_per_group, self.training, self.negative_slope, pre_linear is not None)
+                                            points_per_group, self.training, self.negative_slope, pre_linear is not None, scalar_out)
 
     def forward(self, x):
         rows, meta = to_rows(x)
