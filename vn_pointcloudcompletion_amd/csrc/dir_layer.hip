@@ -16,6 +16,8 @@
 //           (dL/dp | dL/dd) per component (-> the bias gradient)
 // The per-element arithmetic is that of vnp_bn_leaky_fwd / bwd1<1> / bwd1<2> (vn_ops.hip) term for term; like there, the gradient
 // modes use v_rcp_f32 / v_sqrt_f32 and the forward modes IEEE division and sqrtf.  u gets no gradient (it depends on the input only).
+// scalar_io (vnp_vn_dir_layer_ex; bias == NULL): the first layer itself — its input is the point, h = |x|, and without a bias its OUTPUT
+// is parallel to u again — returns per-point scalars sum_t u_t out_t [P][C] and takes the upstream gradient as scalars (dL/dout_t = u_t g).
 // block = 64 channels x 4 point lanes; grid = (ceil(C / 64), ceil(P / chunk)); a chunk never straddles two groups (the host checks).
 #include "vnp_common.h"
 

@@ -241,7 +241,8 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
 #define KNC_QPW 16           // queries per wave and workgroup at most: the 24 KB staging of a 2048-point cloud is shared by 64 queries
                              // (fewer when the graph is small: a wave walks its queries one after the other, and 128-point graphs left
                              // the chip to 64 workgroups of 16 dependent rounds each)
-template <typename T> __device__ __forceinline__ void vnp_knc_cswap(float& d, int& i, int j, bool keep_min)
+// one compare-exchange step of a bitonic network across the wave on (value, index) pairs: lane keeps the smaller pair iff keep_min
+__device__ __forceinline__ void vnp_knc_cswap(float& d, int& i, int j, bool keep_min)
 {
     const float od = __shfl_xor(d, j); const int oi = __shfl_xor(i, j);
     const bool other_less = od < d || (od == d && oi < i);
@@ -259,7 +260,7 @@ __device__ __forceinline__ void vnp_knc_select(const float (&v)[NPL], float m, i
     for (int kk = 2; kk <= 64; kk <<= 1)
 #pragma unroll
         for (int j = kk >> 1; j > 0; j >>= 1)
-            vnp_knc_cswap<int>(sm_, si, j, ((lane & j) == 0) == ((lane & kk) == 0));
+            vnp_knc_cswap(sm_, si, j, ((lane & j) == 0) == ((lane & kk) == 0));
     const float T = __shfl(sm_, k - 1);
     int cnt = 0;
 #pragma unroll
@@ -281,7 +282,7 @@ __device__ __forceinline__ void vnp_knc_select(const float (&v)[NPL], float m, i
         for (int kk = 2; kk <= 64; kk <<= 1)
 #pragma unroll
             for (int j = kk >> 1; j > 0; j >>= 1)
-                vnp_knc_cswap<int>(cd, ci, j, ((lane & j) == 0) == ((lane & kk) == 0));
+                vnp_knc_cswap(cd, ci, j, ((lane & j) == 0) == ((lane & kk) == 0));
         if (lane < k) {
             io[lane] = ci;
             if (dio) dio[lane] = cd;
