@@ -296,6 +296,15 @@ int vnp_vn_dir_layer_ex(hipStream_t st, int mode, const float* v, int ldv, const
 /* u[n] = xyz[n] / |xyz[n]| (0 for the origin), [P][3]; _r: also r[n] = |xyz[n]| (r may be NULL) */
 int vnp_unit_dirs(hipStream_t st, const float* xyz, long long P, float* u);
 int vnp_unit_dirs_r(hipStream_t st, const float* xyz, long long P, float* u, float* r);
+/* VNLinear -> VNMaxPool on a map u (x) h (maxpool1 behind the single-channel first layer, models/pcn.py:168-169): y [P][ldy] holds
+ * y = h W^T in columns [0, C) and y' = h (Wd W)^T in [C, 2C); the score of a point is y y'.  idx [G][C] = first arg-max inside each
+ * group of gs consecutive points, out [G*3][ldo] = u[n*][t] y[n*][c].  _bwd: the gradient of y has one entry per (group, channel);
+ * gW (nullable) [C][ldgw] = dL/dW, gh (nullable) [G*gs][ldgh] = dL/dh (zero-filled inside); order / pts [G][C]: the channels of a
+ * group sorted by their picked point, and that point (stable sort of idx, as for vnp_pool_lin_bwd). */
+int vnp_dir_pool_fwd(hipStream_t st, const float* y, int ldy, const float* u, long long G, int gs, int C, int* idx, float* out, int ldo);
+int vnp_dir_pool_bwd(hipStream_t st, const float* gout, int ldgo, const float* u, const int* idx, const int* order, const int* pts,
+                     const float* h, int ldh, const float* W, int ldw, long long G, int gs, int C, int Ci,
+                     float* gW, int ldgw, float* gh, int ldgh);
 /* expand = 0: h[n][c] = sum_t u[n][t] rows[(n,t)][c];  expand = 1: rows[(n,t)][c] = u[n][t] h[n][c];  expand = 2: rows += u h */
 int vnp_dir_contract(hipStream_t st, float* rows, int ldr, const float* u, float* h, int ldh, long long P, int C, int expand);
 

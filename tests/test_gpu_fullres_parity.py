@@ -90,9 +90,9 @@ def test_benchmark_code_paths_were_taken(run):
     # final_conv[1]: statistics in the GEMM epilogue; first_conv[0] and second_conv[0] run on per-point scalars (vnp_vn_dir_layer)
     assert tr.get("pd_gemm_stats_epilogue", 0) == 1 and "pd_gemm_plain" not in tr, tr
     assert tr.get("dir_layer", 0) == 1 and tr.get("dir_layer_scalar_out", 0) == 1, tr
-    # maxpool2 (K = 1024): screened search; maxpool1 (K = 128): full fused epilogue, its 512-channel input never stored and
+    # maxpool2 (K = 1024): screened search; maxpool1 (K = 128): on per-point scalars, its 512-channel input never stored and
     # second_conv[0] folded onto first_conv[1]'s input channels
-    assert tr.get("linear_pool_screened", 0) == 1 and "linear_pool_unfused" not in tr and tr.get("linear_pool_fused_epilogue", 0) == 1, tr
+    assert tr.get("linear_pool_screened", 0) == 1 and "linear_pool_unfused" not in tr and tr.get("dir_pool", 0) == 1, tr
     assert tr.get("linear_folded_onto_producer", 0) == 1 and "linear_pool_tap_fused" not in tr and "pool_tap" not in tr, tr
     assert tr.get("fold_layer0_fused", 0) == 1 and "fold_layer0_unfused" not in tr, tr
     assert tr.get("decoder_tail_fused", 0) == 1, tr

@@ -548,6 +548,30 @@ def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
             assert relerr(v, ref[4][k]) < 1e-6, (mode, k)
 
 
+@pytest.mark.parametrize("G,gs,C,K", [(2, 2048, 512, 128), (3, 100, 40, 24)])
+def test_dir_pool_equals_rows_pool(lib_built, G, gs, C, K):
+    """DirLinearMaxPoolFn (VNLinear -> VNMaxPool on per-point scalars: scores y y') against VNLinearMaxPoolFn on the expanded rows
+    u (x) h: same picks (generic h: no rounding-level ties), pooled vectors, dL/dh and dL/dW; the origin (u = 0) scores 0 in both."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(G + gs + C)
+    P = G * gs
+    xyz = torch.randn(P, 3, generator=g)
+    xyz[3] = 0.0
+    u = ops.unit_dirs(xyz.cuda())
+    h = torch.randn(P, K, generator=g).cuda()
+    W = (torch.randn(C, K, generator=g) / K ** 0.5).cuda()
+    Wd = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    cot = torch.randn(G * 3, C, generator=g).cuda()
+    hr, Wr = h.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    out, idx = ops.DirLinearMaxPoolFn.apply(hr, u, Wr, Wd, G, gs)
+    (out * cot).sum().backward()
+    hr2, Wr2 = h.clone().requires_grad_(True), W.clone().requires_grad_(True)
+    out2, idx2 = ops.VNLinearMaxPoolFn.apply(ops.DirExpandFn.apply(hr2, u), Wr2, Wd, G, gs)
+    (out2 * cot).sum().backward()
+    assert torch.equal(idx, idx2)
+    assert relerr(out, out2) < 2e-6 and relerr(hr.grad, hr2.grad) < 1e-5 and relerr(Wr.grad, Wr2.grad) < 1e-5
+
+
 def test_first_layer_on_scalars_equals_rows(lib_built):
     """VN_PointNet.first_conv[0] (ONE input channel: the point) on the per-point scalar |x| with scalar output (forward_dir,
     scalar_out) against the rows layout: h = sum_t u_t a1_t to rounding, and the same weight / BatchNorm gradients and running

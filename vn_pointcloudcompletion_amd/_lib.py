@@ -116,6 +116,8 @@ _SIGNATURES = {
     "vnp_unit_dirs": [_vp, _ll, _vp],
     "vnp_unit_dirs_r": [_vp, _ll, _vp, _vp],
     "vnp_dir_contract": [_vp, _i, _vp, _vp, _i, _ll, _i, _i],
+    "vnp_dir_pool_fwd": [_vp, _i, _vp, _ll, _i, _i, _vp, _vp, _i],
+    "vnp_dir_pool_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _i, _vp, _i],
     "vnp_rowdot": [_vp, _i, _vp, _ll, _i, _vp, _i, _vp],
     "vnp_group_sum3": [_vp, _ll, _i, _vp, _i],
     "vnp_colsum": [_vp, _ll, _ll, _i, _ll, _i, _vp, _vp],

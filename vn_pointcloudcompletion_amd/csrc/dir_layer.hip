@@ -284,3 +284,115 @@ extern "C" int vnp_dir_contract(hipStream_t st, float* rows, int ldr, const floa
                        rows, ldr, u, h, ldh, P, C, expand);
     return vnp_last_error();
 }
+
+// ------------------------------------------------------------------------------------------------ VNLinear -> VNMaxPool on scalars
+// maxpool1 behind the single-channel first layer (models/pcn.py:168-169, models/vn_layers.py:153-167): the pooled map is u (x) y with
+// y = h W^T, its direction u (x) y' with y' = h (Wd W)^T, so a point's score <x, d> = y y' |u|^2 = y y' needs no components at all.
+// y [P][ldy]: columns [0, C) = y, [C, 2C) = y'.  Group g = points [g gs, (g + 1) gs).  idx[g][c] = first arg-max over the group of
+// y y' (the origin, u = 0, has y = 0: score 0, as in the rows form), out[(g*3+t)][c] = u[n*][t] y[n*][c].
+// block = 64 channels x 16 point lanes; grid (ceil(C / 64), G)
+__global__ void __launch_bounds__(1024) vnp_dir_pool_fwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ u, int gs, int C,
+                                                               int* __restrict__ idx, float* __restrict__ out, int ldo)
+{
+    __shared__ float rv[16][64];
+    __shared__ int ri[16][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const long long g = blockIdx.y;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    if (c < C) {
+        const float* base = y + (size_t)g * gs * ldy + c;
+        for (int n = py; n < gs; n += 16) {
+            const float s = base[(size_t)n * ldy] * base[(size_t)n * ldy + C];
+            if (s > best || bi == 0x7fffffff) { best = s; bi = n; }
+        }
+    }
+    rv[py][cx] = best; ri[py][cx] = bi;
+    __syncthreads();
+    if (py == 0 && c < C) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float v = rv[q][cx]; const int i = ri[q][cx];
+            if (i != 0x7fffffff && (v > best || (v == best && i < bi) || bi == 0x7fffffff)) { best = v; bi = i; }
+        }
+        idx[(size_t)g * C + c] = bi;
+        const size_t n = (size_t)g * gs + bi;
+        const float yv = y[n * ldy + c];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) out[((size_t)g * 3 + t) * ldo + c] = u[n * 3 + t] * yv;
+    }
+}
+
+extern "C" int vnp_dir_pool_fwd(hipStream_t st, const float* y, int ldy, const float* u, long long G, int gs, int C, int* idx, float* out, int ldo)
+{
+    if (!y || !u || !idx || !out || G <= 0 || G > 65535 || gs <= 0 || C <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_dir_pool_fwd_kernel, dim3(vnp_cdiv(C, 64), (unsigned)G), dim3(1024), 0, st, y, ldy, u, gs, C, idx, out, ldo);
+    return vnp_last_error();
+}
+
+// backward of y = h W^T under the pool: dL/dy has ONE entry per (group, channel), gy = sum_t u[n*][t] gout[(g*3+t)][c] at n* = idx[g][c].
+// gW[c][:] = sum_g gy(g, c) h[n*(g, c)][:]                                     grid (C), 256 threads over Ci
+__global__ void __launch_bounds__(256) vnp_dir_pool_bwd_w_kernel(const float* __restrict__ gout, int ldgo, const float* __restrict__ u,
+                                                                const int* __restrict__ idx, const float* __restrict__ h, int ldh,
+                                                                int G, int gs, int C, int Ci, float* __restrict__ gW, int ldgw)
+{
+    const int c = blockIdx.x;
+    for (int k = threadIdx.x; k < Ci; k += 256) {
+        float acc = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const size_t n = (size_t)g * gs + idx[(size_t)g * C + c];
+            const float gy = u[n * 3] * gout[((size_t)g * 3) * ldgo + c] + u[n * 3 + 1] * gout[((size_t)g * 3 + 1) * ldgo + c] +
+                             u[n * 3 + 2] * gout[((size_t)g * 3 + 2) * ldgo + c];
+            acc += gy * h[n * ldh + k];
+        }
+        gW[(size_t)c * ldgw + k] = acc;
+    }
+}
+
+// gh[n][:] = sum over the channels that picked point n of gy W[c][:]; `order`[g][j] lists the channels of group g sorted by their
+// picked point, `pts`[g][j] that point: block (j, g) owns the run of equal points starting at j (blocks inside a run exit), so every
+// picked point's row is written exactly once, without atomics; all other rows of gh were zero-filled beforehand (as vnp_pool_lin_bwd)
+__global__ void __launch_bounds__(128) vnp_dir_pool_bwd_x_kernel(const float* __restrict__ gout, int ldgo, const float* __restrict__ u,
+                                                                const int* __restrict__ order, const int* __restrict__ pts,
+                                                                const float* __restrict__ W, int ldw, int gs, int C, int Ci,
+                                                                float* __restrict__ gh, int ldgh)
+{
+    const int j0 = blockIdx.x, g = blockIdx.y;
+    const int* pg = pts + (size_t)g * C;
+    const int nloc = pg[j0];
+    if (j0 > 0 && pg[j0 - 1] == nloc) return;
+    int j1 = j0 + 1;
+    while (j1 < C && pg[j1] == nloc) ++j1;
+    const int* og = order + (size_t)g * C;
+    const size_t n = (size_t)g * gs + nloc;
+    const float u0 = u[n * 3], u1 = u[n * 3 + 1], u2 = u[n * 3 + 2];
+    for (int k = threadIdx.x; k < Ci; k += 128) {
+        float acc = 0.f;
+        for (int j = j0; j < j1; ++j) {
+            const int c = og[j];
+            const float gy = u0 * gout[((size_t)g * 3) * ldgo + c] + u1 * gout[((size_t)g * 3 + 1) * ldgo + c] + u2 * gout[((size_t)g * 3 + 2) * ldgo + c];
+            acc += gy * W[(size_t)c * ldw + k];
+        }
+        gh[n * ldgh + k] = acc;
+    }
+}
+
+// gW (nullable) [C][ldgw], gh (nullable) [G gs][ldgh] (zero-filled here); order / pts [G][C] int32 from a stable sort of idx per group
+extern "C" int vnp_dir_pool_bwd(hipStream_t st, const float* gout, int ldgo, const float* u, const int* idx, const int* order, const int* pts,
+                                const float* h, int ldh, const float* W, int ldw, long long G, int gs, int C, int Ci,
+                                float* gW, int ldgw, float* gh, int ldgh)
+{
+    if (!gout || !u || !idx || G <= 0 || G > 65535 || gs <= 0 || C <= 0 || Ci <= 0) return VNP_EINVAL;
+    if (gW) {
+        if (!h) return VNP_EINVAL;
+        hipLaunchKernelGGL(vnp_dir_pool_bwd_w_kernel, dim3(C), dim3(256), 0, st, gout, ldgo, u, idx, h, ldh, (int)G, gs, C, Ci, gW, ldgw);
+    }
+    if (gh) {
+        if (!order || !pts || !W) return VNP_EINVAL;
+        hipError_t e = ldgh == Ci ? hipMemsetAsync(gh, 0, (size_t)G * gs * Ci * 4, st)
+                                  : hipMemset2DAsync(gh, (size_t)ldgh * 4, 0, (size_t)Ci * 4, (size_t)G * gs, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(vnp_dir_pool_bwd_x_kernel, dim3(C, (unsigned)G), dim3(128), 0, st, gout, ldgo, u, order, pts, W, ldw, gs, C, Ci, gh, ldgh);
+    }
+    return vnp_last_error();
+}

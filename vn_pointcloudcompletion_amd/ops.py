@@ -635,6 +635,50 @@ class DirContractFn(Function):
         return g, None
 
 
+class DirLinearMaxPoolFn(Function):
+    """VNLinear followed by VNMaxPool (its only consumer) on a map u (x) h given as per-point scalars h [P, K] — maxpool1 behind
+    VN_PointNet's single-channel first layer (models/pcn.py:168-169, models/vn_layers.py:153-167).  The pooled map is u (x) y with
+    y = h W^T and its direction u (x) y' with y' = h (Wd W)^T, so a point's score <x, d> is y y': one GEMM on points over [W ; Wd W] and an
+    arg-max over scalars (vnp_dir_pool_fwd) instead of a GEMM with a pooling epilogue over three rows per point.  Returns the pooled
+    rows [G*3, C] and the indices.  Backward: one entry of dL/dy per (group, channel), gathered into dL/dh and dL/dW (vnp_dir_pool_bwd);
+    Wd receives no gradient (the arg-max detaches it in the reference as well)."""
+
+    @staticmethod
+    def forward(ctx, h, u, W, Wd, G, gs):
+        h = _rows(h)
+        C, K = W.shape
+        dev = h.device
+        Wcat = torch.cat([_rows(W), gemm(Wd, W, op_b=1)], dim=0)              # [2C, K]
+        y = gemm(h, Wcat, nsplit=1)                                            # [P, 2C]
+        idx = torch.empty((G, C), device=dev, dtype=torch.int32)
+        out = torch.empty((G * 3, C), device=dev, dtype=torch.float32)
+        call("vnp_dir_pool_fwd", ptr(y), 2 * C, ptr(u), G, gs, C, ptr(idx), ptr(out), C)
+        _trace("dir_pool", idx)
+        ctx.save_for_backward(h, u, W, idx)
+        ctx.cfg = (G, gs, C)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, _gidx):
+        h, u, W, idx = ctx.saved_tensors
+        G, gs, C = ctx.cfg
+        gout = _rows(gout)
+        K = h.shape[1]
+        dev = h.device
+        gW = torch.empty((C, K), device=dev, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        gh = order = pts = None
+        if ctx.needs_input_grad[0]:
+            gh = torch.empty((G * gs, K), device=dev, dtype=torch.float32)
+            pts64, order64 = torch.sort(idx, dim=1, stable=True)        # index bookkeeping only
+            pts, order = pts64.int().contiguous(), order64.int().contiguous()
+        Wc = _rows(W)
+        call("vnp_dir_pool_bwd", ptr(gout), _ld(gout), ptr(u), ptr(idx), ptr(order), ptr(pts), ptr(h), _ld(h), ptr(Wc), _ld(Wc),
+             G, gs, C, K, ptr(gW), K, ptr(gh), K)
+        return gh, None, gW, None, None, None
+
+
 class VNDirLinearLeakyFn(Function):
     """VNLinearLeakyReLU (models/vn_layers.py:46-74) on a map whose VN vectors are all parallel to one unit direction u per point — the
     layer behind VN_PointNet's single-channel first layer (models/pcn.py:165-173): input h [P, K] (one scalar per point and channel, the

@@ -64,12 +64,11 @@ class VN_PointNet(nn.Module):
         # multiple of u, a1 = u (x) h, and second_conv[0] — folded onto first_conv[1]'s 128 input channels, see below — runs on the
         # per-point scalars h and rebuilds its pre-activations u v + bias in registers (ops.VNDirLinearLeakyFn)
         if dir_ok and ops.ENC_FIRST_LAYER_SCALAR and _lib.get_gemm_mode() == "split":
-            # the first layer itself on the per-point scalar |x|, returning h (scalar_out); the rows u (x) h are written once, for
-            # maxpool1's fused GEMM.  (Default GEMM mode only: VNP_GEMM_MODE=fp32 is the conservative comparison path and keeps the
+            # the first layer itself on the per-point scalar |x|, returning h (scalar_out).  (Default GEMM mode only: VNP_GEMM_MODE=fp32 is the conservative comparison path and keeps the
             # first layer in the rows layout)
             u, r = ops.unit_dirs(xyz, return_norm=True)
             h = l1.forward_dir(r, u, scalar_out=True)                                # [B*N, 128]
-            a1 = ops.DirExpandFn.apply(h, u)                                         # [B*N*3, 128]
+            a1 = None                                                                # the rows u (x) h are never needed
         else:
             x = xyz.contiguous().float().reshape(B * N * 3, 1)                       # rows layout with C = 1 IS xyz
             a1 = l1.forward_rows(x)
@@ -80,7 +79,11 @@ class VN_PointNet(nn.Module):
             # first_conv[1] is a linear map whose output f = W1 a1 [B*N*3, 512] feeds maxpool1 and — behind the concatenation —
             # second_conv[0]'s linear maps (pcn.py:168-173): the pool takes f from its fused GEMM without storing it, and
             # second_conv[0] contracts (W W1) with a1 over first_conv[1]'s 128 input channels instead of W with f over 512
-            g1, _ = ops.VNLinearMaxPoolFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)      # g1 [B*3, 512]
+            if a1 is None:
+                # ... and maxpool1 on the scalars too: a point's score is (h W1^T)(h (Wd W1)^T), no components involved
+                g1, _ = ops.DirLinearMaxPoolFn.apply(h, u, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)   # g1 [B*3, 512]
+            else:
+                g1, _ = ops.VNLinearMaxPoolFn.apply(a1, W1, self.maxpool1.map_to_dir.weight.detach(), B, N)
             if dir_ok:
                 f = l2.forward_dir(h, u, global_rows=g1, points_per_group=N, pre_linear=W1)
             else:
