@@ -5,16 +5,20 @@ of vn_pointnet + vn_foldingnet on synthetic (B,2048,3) -> (B,16384,3) clouds, fp
     python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: this process starts the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the dominant kernel, the GEMM, timed per
-launch with HIP events on its launch stream), `roofline_other` (the non-GEMM kernels the north star names: Chamfer, kNN,
-BatchNorm/leaky passes — each timed alone with HIP events and priced on the bound that applies to it), `chamfer_op` (the one
-shape the reference tree publishes a number for) and `cpu_baseline` (the torch-CPU oracle on a bounded sample).
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the dominant kernel, vnp_gemm_split_kernel: EXECUTED
+work over KERNEL time — HIP events recorded by the library around each launch of that kernel on its launch stream, so the figure is
+Σflops / Σduration over the vnp_gemm_split_kernel rows of a rocprofv3 kernel trace of the same command, profiles/rNN_bench_kernel_stats.csv),
+`roofline_other` (the arg-max pool's screening pass on the fp16 pipe it uses; Chamfer — the pruned search priced on the pairs it
+actually evaluates, counted by the kernel — and kNN on the fp32 VALU bound; the BatchNorm / leaky passes and the streaming kernels of
+the degenerate matrix shapes on the HBM bound), `chamfer_op` (the one shape the reference tree publishes a number for) and
+`cpu_baseline` (the torch-CPU oracle on a bounded sample).  No entry prices a kernel on work it does not execute; the algorithmic and
+SURVEY §8(d) views of the matrix work ride along under `roofline.views` without a `frac` of their own.
 
 GEMM arithmetic: fp32 operands and fp32 results; by default each operand is split EXACTLY into three bf16
 terms and six bf16 MFMA products are accumulated in fp32 (error vs fp64 at or below the fp32-input MFMA's — asserted by
 tests/test_gpu_gemm.py::test_split_is_fp32_grade).  The roofline is priced on the bf16 pipe actually used: peak = 2500/6
-TFLOP/s of fp32-equivalent work.  At N = 1 the same step is also timed with the fp32-input MFMA kernels
-(VNP_GEMM_MODE=fp32) and reported beside it as `fp32_mfma_mode`.
+TFLOP/s of fp32-equivalent work (the executed bf16 rate is 6 x achieved).  At N = 1 the same step is also timed with the fp32-input
+MFMA kernels (VNP_GEMM_MODE=fp32) and reported beside it as `fp32_mfma_mode`.
 """
 import argparse
 import json
@@ -195,10 +199,21 @@ def roofline_other(B, N, Mc, Md):
         valu("vnp_chamfer_fwd (brute force; coarse loss 1024 x 16384, both directions)", lambda: ops.ChamferFn.apply(coarse, gt),
              2.0 * B * Mc * Md, B * (Mc + Md) * 12 + B * (Mc + Md) * 8,
              "pairs = 2*n*m per cloud (two one-sided scans, like chamfer3D.cu); peak = 78.6 T lane-op/s (one VALU op per lane per clock)")
-        valu("vnp_chamfer_fwd_pruned (dense loss 16384 x 16384; pairs = the 2*n*m a full scan would evaluate)",
-             lambda: ops.ChamferFn.apply(dense, gt), 2.0 * B * Md * Md, B * 2 * Md * 12 + B * 2 * Md * 8,
-             "exact search over Morton-binned chunks with box lower bounds visits 5-17 % of the pairs, so the full-scan-equivalent "
-             "rate exceeds the VALU peak; bit-identical outputs (tests/test_gpu_chamfer.py)")
+        # the pruned search is priced on the pairs it EVALUATES: the kernel counts them (ws + 8, include/vnpcc.h)
+        stats = []
+        ops.CHAMFER_STATS = stats
+        ops.ChamferFn.apply(dense, gt)
+        ops.CHAMFER_STATS = None
+        torch.cuda.synchronize()
+        visited = float(stats[0].item())
+        valu("vnp_chamfer_pruned_kernel + vnp_chamfer_bin_kernel (dense loss 16384 x 16384, uniform random clouds)",
+             lambda: ops.ChamferFn.apply(dense, gt), visited, B * 2 * Md * 12 + B * 2 * Md * 8,
+             "exact search over Morton-binned chunks with box lower bounds; pairs = the (query, target) evaluations the kernel counted "
+             "(bit-identical outputs to the full scan: tests/test_gpu_chamfer.py); time includes the binning pass")
+        out[-1]["pairs_evaluated"] = visited
+        out[-1]["pairs_of_a_full_scan"] = 2.0 * B * Md * Md
+        out[-1]["visited_fraction"] = round(visited / (2.0 * B * Md * Md), 4)
+        out[-1]["full_scan_equivalent_pairs_per_s"] = 2.0 * B * Md * Md / (out[-1]["ms"] * 1e-3)
         valu("vnp_knn_coords_kernel (k = 16 graph on 2048 x 2048 coordinates, config 3 first layer)", lambda: ops.knn_indices(part, part, 16),
              1.0 * B * N * N, B * N * 12 * 2 + B * N * 16 * 4,
              "one wave per query: distances in registers, threshold selection (k-th smallest lane minimum), no distance matrix; "
@@ -344,6 +359,8 @@ def main():
     else:
         allreduce = {"backend": None, "bytes_per_step": 0, "mode": "none (single rank)"}
 
+    pool_paths = dict(ops.POOL_PATH_COUNTS)
+
     # the same step on the fp32-input MFMA kernels, outside the timed region (single GPU only; a comparison, not `value`)
     fp32_mode = None
     gemm_mode = _lib.get_gemm_mode()
@@ -362,46 +379,63 @@ def main():
         dt32 = time.perf_counter() - t1
         ops.GEMM_PROFILE = None
         _lib.set_gemm_mode("split")
-        f32 = sum(x[1] for x in prof32)
-        t32 = sum(x[4].elapsed_time(x[5]) for x in prof32) * 1e-3
+        mf = [(x[1], x[4].seconds()) for x in prof32 if x[4].kind == 1]
+        f32 = sum(f for f, _ in mf)
+        t32 = sum(t for _, t in mf)
         fp32_mode = {"ms_per_step": dt32 / n32 * 1e3, "value": B * Md * n32 / dt32, "steps": n32, "warmup": 3,
                      "roofline": {"bound": "mfma", "kernel": "vnp_gemm_kernel<*> (v_mfma_f32_32x32x2_f32)",
                                   "achieved": round(f32 / t32 / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(f32 / t32 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
+                                  "frac": round(f32 / t32 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "ms_per_step": t32 / n32 * 1e3,
+                                  "launches_per_step": len(mf) // n32}}
 
+    screen_entry, degenerate_entry = None, None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * Md * args.steps / elapsed
-        # dominant kernel: the GEMM; per-variant algorithmic FLOP / s from the per-launch HIP events
+        # every matrix-product launch of the timed steps: (variant, 2MNK, nsplit, shape, timer); timer.kind says what its dominant
+        # kernel was (include/vnpcc.h: vnp_gemm_profile_next) and timer.seconds() how long THAT KERNEL ran
+        recs = [(v, f, ns, shp, t.kind, t.seconds()) for v, f, ns, shp, t in prof]
+        main_kind = 0 if gemm_mode == "split" else 1
+        mfma = [r for r in recs if r[4] == main_kind and r[5] is not None]           # launches of the dominant kernel
+        tot_f, tot_t, nlaunch = sum(r[1] for r in mfma), sum(r[5] for r in mfma), len(mfma)
+        achieved = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
         agg = {}
-        for variant, flops, nsplit, shape, e0, e1 in prof:
-            a = agg.setdefault(variant, [0.0, 0.0, 0])
-            a[0] += flops
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += 1
+        for v, f, ns, shp, kind, t in mfma:
+            a = agg.setdefault(v, [0.0, 0.0, 0])
+            a[0] += f; a[1] += t; a[2] += 1
         if os.environ.get("VNP_BENCH_SHAPES"):
             per = {}
-            for variant, flops, nsplit, shape, e0, e1 in prof:
-                a = per.setdefault((variant, shape, nsplit), [0.0, 0.0, 0])
-                a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
-            for (variant, shape, nsplit), a in sorted(per.items(), key=lambda kv: -kv[1][1]):
-                print(f"  {variant} M={shape[0]:8d} N={shape[1]:5d} K={shape[2]:8d} split={nsplit:4d} x{a[2] // args.steps:2d}/step "
+            for v, f, ns, shp, kind, t in recs:
+                if t is None:
+                    continue
+                a = per.setdefault((v, kind, shp, ns), [0.0, 0.0, 0])
+                a[0] += f; a[1] += t; a[2] += 1
+            for (v, kind, shp, ns), a in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                print(f"  {v} kind={kind} M={shp[0]:8d} N={shp[1]:5d} K={shp[2]:8d} split={ns:4d} x{a[2] // args.steps:2d}/step "
                       f"{a[1] / args.steps * 1e3:7.3f} ms/step {a[0] / a[1] / 1e12:6.1f} TF/s", file=sys.stderr)
-        # the headline kernel is the 6-product split GEMM; the screened arg-max pool (one call per step: 3-product bracketing
-        # GEMM + candidate passes) executes about half of its algorithmic products, so it is reported beside it, not inside it
-        SCR = "NT-pool-screened"
-        tot_f = sum(a[0] for k, a in agg.items() if k != SCR)
-        tot_t = sum(a[1] for k, a in agg.items() if k != SCR)
-        nlaunch = sum(a[2] for k, a in agg.items() if k != SCR)
-        six_achieved = tot_f / tot_t / 1e12 if tot_t > 0 else 0.0
-        all_f, all_t = sum(a[0] for a in agg.values()), sum(a[1] for a in agg.values())
-        # headline: ALGORITHMIC flops of all matrix work (SURVEY §8d counts the pool's direction GEMM in the per-cloud figure) over
-        # its launch time; beside it the same figure for the six-product launches alone and the EXECUTED-equivalent rate, in which
-        # the screened pool counts for the products it actually issues (1 of 6 with the fp16 pass, 3 of 6 with bf16x3)
-        achieved = all_f / all_t / 1e12 if all_t > 0 else 0.0
-        scr_exec = (1.0 / 6.0 if ops.POOL_SCREEN_PASS == "fp16" else 0.5)
-        exec_f = tot_f + sum(a[0] for k, a in agg.items() if k == SCR) * scr_exec
-        exec_achieved = exec_f / all_t / 1e12 if all_t > 0 else 0.0
+        # the screening pass of the exact arg-max pool (its own kernel, ONE fp16 product — or three bf16 products — per operand pair)
+        scr = [r for r in recs if r[4] in (3, 4) and r[5] is not None]
+        if scr:
+            nprod = 1.0 if scr[0][4] == 3 else 3.0
+            sf, st = sum(r[1] for r in scr) * nprod, sum(r[5] for r in scr)
+            speak = PEAK_BF16_MFMA_TFLOPS                    # fp16 and bf16 dense MFMA peaks are equal
+            screen_entry = {"kernel": ("vnp_screen_f16_wide_kernel / vnp_gemm_split_kernel<..., EPI = 4>: screening pass of the exact arg-max pool "
+                                       "(VNLinear -> VNMaxPool), ONE v_mfma_f32_16x16x32_f16 product per operand pair on fp16 operand images"
+                                       if nprod == 1.0 else
+                                       "vnp_gemm_split_kernel<..., EPI = 3>: screening pass of the exact arg-max pool, three bf16 products"),
+                            "bound": "mfma", "ms": round(st / len(scr) * 1e3, 4), "launches_per_step": len(scr) // max(args.steps, 1),
+                            "achieved": round(sf / st / 1e12, 1), "peak": speak, "unit": "TFLOP/s", "frac": round(sf / st / 1e12 / speak, 4),
+                            "shape": list(scr[0][3]),
+                            "note": "executed flops = 2 M N K x products issued, kernel time from the library's HIP events; the candidate passes "
+                                    "behind it (select, sort, exact, final: gathers, 0.8 ms per step) are not matrix-pipe work and are not priced here"}
+        deg = [r for r in recs if r[4] == 2 and r[5] is not None]
+        if deg:
+            db = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in deg)
+            dt_ = sum(r[5] for r in deg)
+            degenerate_entry = {"kernel": "vnp_gemm_rank1 / matvec / wcolsum kernels (K = 1, N = 1 or M = 1 products: streaming, no MFMA)",
+                                "bound": "hbm", "ms": round(dt_ / len(deg) * 1e3, 4), "launches_per_step": len(deg) // max(args.steps, 1),
+                                "achieved": round(db / dt_ / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(db / dt_ / 1e9 / PEAK_HBM_GBS, 4),
+                                "algorithmic_bytes": db / max(len(deg), 1), "note": "bytes = every operand and the result once"}
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction);
         # bench.py cannot run the counters on itself, so this is read from profiles/ (null when absent)
         traffic, traffic_src = None, None
@@ -416,44 +450,52 @@ def main():
                 traffic, traffic_src = num / den, os.path.relpath(summ, ROOT)
         except Exception:
             pass
-        alg_bytes = sum(4.0 * (m * k + n * k + m * n) for v, _, _, (m, n, k), _, _ in prof if v != SCR) / max(nlaunch, 1)
+        alg_bytes = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in mfma) / max(nlaunch, 1)
         if gemm_mode == "split":
             kernel = ("vnp_gemm_split_kernel<*> (fp32 operands split exactly into 3 bf16 terms; 6 x v_mfma_f32_16x16x32_bf16 "
                       "per fp32 product block, fp32 accumulate)")
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         else:
             kernel, peak = "vnp_gemm_kernel<*> (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
+        # side views (no frac: they are not rates of executed work): every matrix product of the step at its algorithmic 2MNK over the
+        # time of ALL matrix-product kernels (the screened pool counts for the full product it replaces), and SURVEY 8(d)'s as-written count
+        all_t = sum(r[5] for r in recs if r[5] is not None)
+        all_f = sum(r[1] for r in recs if r[5] is not None)
         roofline = {"bound": "mfma", "kernel": kernel,
                     "achieved": round(achieved, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                    "launches_per_step": sum(a[2] for a in agg.values()) // max(args.steps, 1),
-                    "flop_per_launch": all_f / max(sum(a[2] for a in agg.values()), 1),
-                    "avg_launch_ms": all_t / max(sum(a[2] for a in agg.values()), 1) * 1e3,
-                    "gemm_ms_per_step": all_t / args.steps * 1e3,
-                    "six_product_launches": {"achieved": round(six_achieved, 2), "frac": round(six_achieved / peak, 4),
-                                             "ms_per_step": tot_t / args.steps * 1e3, "launches_per_step": nlaunch // max(args.steps, 1)},
-                    "executed_equivalent": {"achieved": round(exec_achieved, 2), "frac": round(exec_achieved / peak, 4),
-                                            "note": "the screened arg-max pool counted for the products it issues, not for the 2*M*(2C)*K it replaces"},
-                    # 212 GFLOP of matrix work per completed cloud and training step for the network AS WRITTEN
-                    # (de-duplicated broadcasts only); the step here needs fewer (sparse pool backward, re-associated pool direction,
-                    # second_conv[0] folded onto first_conv[1]'s 128 input channels, screened arg-max), so this view is a rate of
-                    # reference-equivalent work, not of executed MFMA work
-                    "survey_8d_view": ({"flop_per_step": SURVEY_FLOP_PER_CLOUD * B,
-                                        "achieved": round(SURVEY_FLOP_PER_CLOUD * B / (all_t / args.steps) / 1e12, 2),
-                                        "frac": round(SURVEY_FLOP_PER_CLOUD * B / (all_t / args.steps) / 1e12 / peak, 4),
-                                        "note": "SURVEY 8(d): 212 GF per cloud and step as written / GEMM time per step"}
-                                       if (Mc == 1024 and all_t > 0) else None),
-                    "note": ("achieved = algorithmic 2MNK fp32 flops of every matrix product of the step / its launch time (HIP events per "
-                             "launch); the VNLinear -> VNMaxPool product is found by an exact screened search that issues 1/6 of its "
-                             "products (bit-identical result), so `six_product_launches` and `executed_equivalent` give the MFMA-side "
-                             "view; encoder second_conv[0] is evaluated as (W W1) a over first_conv[1]'s 128 input channels and counted "
-                             "at the 2MNK it executes (K = 128, a quarter of the as-written product); "
-                             f"peak = bf16 dense MFMA peak ({PEAK_BF16_MFMA_TFLOPS:.0f}) / {SPLIT_PRODUCTS} products; "
-                             f"fp32-input MFMA peak is {PEAK_FP32_MFMA_TFLOPS}")
-                            if gemm_mode == "split" else "achieved = algorithmic 2MNK flops / launch time",
+                    "frac": round(achieved / peak, 4),
+                    "executed_bf16_PFLOPs": round(achieved * (SPLIT_PRODUCTS if gemm_mode == "split" else 1) / 1e3, 3),
+                    "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                    "launches_per_step": nlaunch // max(args.steps, 1),
+                    "flop_per_launch": tot_f / max(nlaunch, 1),
+                    "avg_launch_ms": tot_t / max(nlaunch, 1) * 1e3,
+                    "ms_per_step": tot_t / args.steps * 1e3,
+                    "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (vnp_gemm_profile_next): "
+                              "kernel time only — no slab reduction, no launch gap; reproduce as sum(2MNK) / sum(duration) over the "
+                              "vnp_gemm_split_kernel rows of profiles/rNN_bench_kernel_stats.csv",
+                    "note": ("achieved = EXECUTED fp32-equivalent flops (2MNK of the launches of this kernel; each is six bf16 MFMA products) / "
+                             "kernel time.  Not in it: the arg-max pool's screening pass (own kernel, one fp16 product: roofline_other), the "
+                             "streaming kernels of the degenerate shapes (roofline_other), slab reductions.  "
+                             f"peak = bf16 dense MFMA peak ({PEAK_BF16_MFMA_TFLOPS:.0f}) / {SPLIT_PRODUCTS} products; the fp32-input MFMA peak is "
+                             f"{PEAK_FP32_MFMA_TFLOPS}") if gemm_mode == "split" else "achieved = executed 2MNK flops / kernel time",
                     "by_variant": {k: {"tflops": round(a[0] / a[1] / 1e12, 2), "ms_per_step": round(a[1] / args.steps * 1e3, 3),
-                                       "launches_per_step": a[2] // max(args.steps, 1)} for k, a in agg.items() if a[1] > 0}}
+                                       "launches_per_step": a[2] // max(args.steps, 1)} for k, a in agg.items() if a[1] > 0},
+                    "views": {"all_matrix_products_algorithmic": {
+                                  "tflops": round(all_f / all_t / 1e12, 2) if all_t > 0 else None, "ms_per_step": all_t / args.steps * 1e3,
+                                  "note": "2MNK of EVERY matrix product of the step (the screened arg-max pool counted at the full product whose "
+                                          "result it reproduces bit for bit) / kernel time of all of them: a rate of useful work, not of MFMA work"},
+                              # 212 GFLOP of matrix work per completed cloud and training step for the network AS WRITTEN
+                              "survey_8d": ({"flop_per_step": SURVEY_FLOP_PER_CLOUD * B,
+                                             "tflops": round(SURVEY_FLOP_PER_CLOUD * B / (all_t / args.steps) / 1e12, 2),
+                                             "note": "SURVEY 8(d): 212 GF per cloud and step for the network as written / matrix-kernel time per "
+                                                     "step; DESIGN.md §4 removed two thirds of the as-written products, so this is "
+                                                     "reference-equivalent work, not executed work"}
+                                            if (Mc == 1024 and all_t > 0) else None)}}
+        steps_total = args.warmup + args.steps
+        pool_path = {"calls_since_start": pool_paths, "steps_since_start": steps_total,
+                     "note": "VNLinear -> VNMaxPool (maxpool2) calls by path over warm-up + timed steps: `screened` = exact screened search, "
+                             "`full_epilogue` = six-product pool epilogue (search skipped: back-off after a device-side fallback, or K < 256: "
+                             "maxpool1 in the rows form), `fallback_flags_seen` = device-side fallbacks reported back so far"}
         out = {"metric": METRIC, "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
@@ -462,7 +504,7 @@ def main():
                           "parallelism": f"dp{world}", "allreduce": allreduce["mode"]},
                "points_per_s_per_gpu": value / world, "ranks_joined": ranks_joined, "allreduce": allreduce,
                "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
-               "roofline": roofline}
+               "roofline": roofline, "pool_path": pool_path}
         if fp32_mode is not None:
             out["fp32_mfma_mode"] = fp32_mode
         if world == 1 and not args.no_extras:
@@ -473,6 +515,10 @@ def main():
                     out[key] = fn()
                 except Exception as e:                              # an extra leg must never hide the GPU number
                     out[key] = {"failed": f"{type(e).__name__}: {e}"}
+        # kernels of the timed step itself that are not the dominant kernel, priced on what they execute
+        step_extra = [e for e in (screen_entry, degenerate_entry) if e is not None]
+        if step_extra:
+            out["roofline_other"] = step_extra + (out["roofline_other"] if isinstance(out.get("roofline_other"), list) else [])
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))      # the GPU box gives 16 cores per GPU

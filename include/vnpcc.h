@@ -40,7 +40,9 @@ int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, cons
                     float* grad_xyz1, float* grad_xyz2);
 /* Same outputs as vnp_chamfer_fwd, bit for bit, by a pruned exact search for dense clouds (n, m <= 32768): both clouds are
  * Morton-sorted into 64-point chunks with bounding boxes and a wave of 256 queries skips every chunk that cannot hold a
- * nearest neighbour for any of them.  ws: vnp_chamfer_pruned_ws_bytes(B, n, m) bytes (0 = sizes not supported). */
+ * nearest neighbour for any of them.  ws: vnp_chamfer_pruned_ws_bytes(B, n, m) bytes (0 = sizes not supported).
+ * Diagnostics: after the call the 64-bit word at ws + 8 holds the (query, target) pairs the two scans evaluated (a full scan
+ * evaluates 2 B n m): bench.py prices the kernel on this executed work. */
 long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m);
 int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                            float* dist1, int* idx1, float* dist2, int* idx2, void* ws);
@@ -65,6 +67,12 @@ int vnp_emd_matchcost_bwd(hipStream_t st, int B, int n, int m, const float* grad
  * accumulation (error vs fp64 at or below mode 1's); 1 = fp32-input MFMA.  Process-wide; returns 0 or VNP_EINVAL. */
 int vnp_gemm_set_mode(int mode);
 int vnp_gemm_get_mode(void);
+/* Measurement hook (bench.py, no reference counterpart): the NEXT matrix-product launch of the calling host thread (vnp_gemm*,
+ * vnp_gemm_vn_stats*, vnp_linear_pool*_fwd) records e0 / e1 around its ONE dominant kernel on the launch stream — not the slab
+ * reduction or the pool's candidate passes — and stores in *kind (host memory, may be NULL) what that kernel was:
+ * 0 six-product bf16 split kernel, 1 fp32-input MFMA kernel, 2 streaming kernel of a degenerate shape (K = 1, N = 1, M = 1: no
+ * MFMA), 3 screening pass with one fp16 product, 4 screening pass with three bf16 products, 5 two fp16 planes / three products. */
+int vnp_gemm_profile_next(hipEvent_t e0, hipEvent_t e1, int* kind);
 int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, int ldbias, int rows_per_group,

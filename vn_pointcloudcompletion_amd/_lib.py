@@ -126,7 +126,7 @@ _SIGNATURES = {
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
 }
-_NO_STREAM = {"vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
+_NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i, _i],
               "vnp_gemm_vn_stats_ws_floats": [_ll, _i]}
 _RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,
@@ -159,6 +159,47 @@ def lib():
             raise VnpError(f"VNP_GEMM_MODE must be 'split' or 'fp32', got {mode!r}")
         L.vnp_gemm_set_mode(1 if mode == "fp32" else 0)
     return _LIB
+
+
+class KernelTimer:
+    """Raw HIP events for vnp_gemm_profile_next (bench.py): the library records them around the ONE dominant kernel of the next
+    matrix-product launch, so the time excludes slab reductions, the pool's candidate passes and launch gaps (torch.cuda.Event
+    brackets on the Python side include them).  ``kind`` is filled in by the library (see include/vnpcc.h)."""
+    _hip = None
+
+    def __init__(self):
+        if KernelTimer._hip is None:
+            KernelTimer._hip = ctypes.CDLL("libamdhip64.so")
+        h = KernelTimer._hip
+        self.e0, self.e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        for e in (self.e0, self.e1):
+            if h.hipEventCreate(ctypes.byref(e)) != 0:
+                raise VnpError("hipEventCreate failed")
+        self._kind = ctypes.c_int(-1)
+
+    def arm(self):
+        if lib().vnp_gemm_profile_next(self.e0, self.e1, ctypes.byref(self._kind)) != 0:
+            raise VnpError("vnp_gemm_profile_next failed")
+
+    @property
+    def kind(self):
+        return self._kind.value
+
+    def seconds(self):
+        """Kernel duration (call after the stream has been synchronised); None if no kernel consumed the request."""
+        if self._kind.value < 0:
+            return None
+        ms = ctypes.c_float()
+        if KernelTimer._hip.hipEventElapsedTime(ctypes.byref(ms), self.e0, self.e1) != 0:
+            return None
+        return ms.value * 1e-3
+
+    def __del__(self):
+        h = KernelTimer._hip
+        if h is not None:
+            for e in (self.e0, self.e1):
+                if e:
+                    h.hipEventDestroy(e)
 
 
 def set_gemm_mode(mode: str) -> None:

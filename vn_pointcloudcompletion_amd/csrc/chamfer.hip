@@ -339,7 +339,8 @@ __global__ void __launch_bounds__(1024) vnp_chamfer_bin_kernel(const float* __re
 template <int QPT>
 __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __restrict__ qs, int n, const float4* __restrict__ rs,
                                                                 int m, const float4* __restrict__ rbox, const int* __restrict__ flag,
-                                                                float* __restrict__ dist, int* __restrict__ idx)
+                                                                float* __restrict__ dist, int* __restrict__ idx,
+                                                                unsigned long long* __restrict__ visited)
 {
     constexpr int NG = CHP_MAXN / CHP_CHUNK / 64;             // chunk groups of 64 (one ballot word each)
     __shared__ float4 box[2 * (CHP_MAXN / CHP_CHUNK)];
@@ -405,9 +406,11 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
     const int c0 = __builtin_amdgcn_readfirstlane(cmin);
     __syncthreads();
 
+    int npairs = 0;                                               // (query, target) pairs this wave evaluates: the kernel's executed work
     auto visit = [&](int c) {
         const int r0 = c * CHP_CHUNK;
         const int cnt = min(CHP_CHUNK, m - r0);
+        npairs += cnt;
         __syncthreads();                                          // one wave per workgroup: orders the LDS reuse only
         {
             float4 v = make_float4(NAN, NAN, NAN, 0.f);           // slots past the chunk's end: NaN distances never win
@@ -469,6 +472,7 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
             idx[(size_t)b * n + qo[u]] = (int)(unsigned)(best[u] & 0xffffffffu);
         }
     }
+    if (lane == 0) atomicAdd(visited, (unsigned long long)npairs * (unsigned long long)min(64 * QPT, n - base));
 }
 
 // bytes of scratch vnp_chamfer_fwd_pruned needs (0: sizes outside the pruned path's range)
@@ -480,6 +484,8 @@ extern "C" long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m)
 }
 
 // Same contract as vnp_chamfer_fwd, by the pruned search.  n, m <= 32768; ws of vnp_chamfer_pruned_ws_bytes(B, n, m) bytes.
+// After the call the 64-bit word at ws + 8 holds the number of (query, target) pairs the two scans evaluated (a full scan: 2 B n m):
+// diagnostics, read by bench.py to price the kernel on its executed work.
 extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                                       float* dist1, int* idx1, float* dist2, int* idx2, void* ws)
 {
@@ -499,9 +505,9 @@ extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float*
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B, 2), dim3(1024), (size_t)CHP_BINS * 4, st, xyz1, n, s1, b1, xyz2, m, s2, b2, flag);
     hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
-                       (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1);
+                       (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2));
     hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
-                       (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2);
+                       (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2));
     return vnp_last_error();
 }
 

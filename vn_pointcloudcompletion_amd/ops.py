@@ -75,6 +75,7 @@ def _screen_allowed(key):
     if st["event"] is not None and st["event"].query():
         if int(st["host"][1]) != 0:
             st["skip"] = POOL_SCREEN_BACKOFF
+            POOL_PATH_COUNTS["fallback_flags_seen"] += 1
         st["event"] = None
     if st["skip"] > 0:
         st["skip"] -= 1
@@ -91,9 +92,21 @@ def _screen_report(key, ws):
         st["event"] = torch.cuda.Event()
         st["event"].record()
 
-# bench.py sets this to a list to time every GEMM launch with HIP events recorded on the launch stream:
-# entries are (variant, flops, start_event, end_event)
+# bench.py sets this to a list to time every matrix-product launch: entries are (variant, flops, nsplit, (M, N, K), timer) with
+# timer a _lib.KernelTimer — HIP events recorded by the library around the launch's ONE dominant kernel on its launch stream
 GEMM_PROFILE = None
+# calls of the VNLinear -> VNMaxPool pool by path since import (bench.py reports the timed steps' share): the exact screened search,
+# the full six-product epilogue (search skipped: short contraction, back-off after a fallback), and device-side fallbacks seen
+POOL_PATH_COUNTS = {"screened": 0, "full_epilogue": 0, "unfused": 0, "fallback_flags_seen": 0}
+
+
+def _prof_arm():
+    prof = GEMM_PROFILE
+    if prof is None:
+        return None
+    t = _lib.KernelTimer()
+    t.arm()
+    return t
 # tests set this to a dict to learn which code paths a forward pass took: path name -> launch count, and under "pool_idx" the
 # arg-max index tensors of the VNMaxPool calls in call order (tests/test_gpu_fullres_parity.py)
 TRACE = None
@@ -196,15 +209,12 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit, M, N), device=A.device, dtype=torch.float32)
-    prof = GEMM_PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     h2 = _fp16x2_shape(op_a, M, N, K, A, B, nsplit)
     if h2:
         amax_a = amax_a if amax_a is not None else amax_word(A)
         amax_b = amax_b if amax_b is not None else amax_word(B)
         h2 = amax_a is not None and amax_b is not None
+    timer = _prof_arm()
     if h2:
         _trace("gemm_fp16x2")
         call("vnp_gemm_ex", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
@@ -212,10 +222,9 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
     else:
         call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
              ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))
-    if prof is not None:
-        e1.record()
-        prof.append(("NT" if (op_a, op_b) == (0, 0) else "NN" if (op_a, op_b) == (0, 1) else "TN" if (op_a, op_b) == (1, 1) else "TT",
-                     2.0 * M * N * K, nsplit, (M, N, K), e0, e1))
+    if timer is not None:
+        GEMM_PROFILE.append(("NT" if (op_a, op_b) == (0, 0) else "NN" if (op_a, op_b) == (0, 1) else "TN" if (op_a, op_b) == (1, 1) else "TT",
+                             2.0 * M * N * K, nsplit, (M, N, K), timer))
     return out
 
 
@@ -270,13 +279,10 @@ def gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, want_stats):
     _trace("pd_gemm_stats_epilogue")
     part = torch.empty((R // 3072, C, 2), device=x.device, dtype=torch.float32)
     ws = torch.empty(_lib.lib().vnp_gemm_vn_stats_ws_floats(R, C), device=x.device, dtype=torch.float32)
-    prof = GEMM_PROFILE
-    if prof is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     am_x = am_w = None
     if _fp16x2_shape(0, R, 2 * C, K, x, Wcat, 1):
         am_x, am_w = amax_word(x), amax_word(Wcat)
+    timer = _prof_arm()
     if am_x is not None and am_w is not None:
         _trace("gemm_fp16x2")
         call("vnp_gemm_vn_stats_ex", R, 2 * C, K, ptr(x), _ld(x), ptr(Wcat), K, ptr(pd), _ld(pd), ptr(bias),
@@ -284,9 +290,8 @@ def gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, want_stats):
     else:
         call("vnp_gemm_vn_stats", R, 2 * C, K, ptr(x), _ld(x), ptr(Wcat), K, ptr(pd), _ld(pd), ptr(bias),
              _ld(bias) if bias is not None else 0, rows_per_group, C, ptr(part), ptr(ws))
-    if prof is not None:
-        e1.record()
-        prof.append(("NT", 2.0 * R * 2 * C * K, 1, (R, 2 * C, K), e0, e1))
+    if timer is not None:
+        GEMM_PROFILE.append(("NT", 2.0 * R * 2 * C * K, 1, (R, 2 * C, K), timer))
     return part
 
 
@@ -964,14 +969,10 @@ class VNLinearPoolTapFn(Function):
         idx = torch.empty((G, C), device=dev, dtype=torch.int32)
         out = torch.empty((G * 3, C), device=dev, dtype=torch.float32)
         ws = torch.empty((_lib.lib().vnp_linear_pool_ws_bytes(G, gs, C) + 7) // 8, device=dev, dtype=torch.int64)
-        prof = GEMM_PROFILE
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        timer = _prof_arm()
         call("vnp_linear_pool_store_fwd", ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(y), C, ptr(idx), ptr(out), C, ptr(ws))
-        if prof is not None:
-            e1.record()
-            prof.append(("NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
+        if timer is not None:
+            GEMM_PROFILE.append(("NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), timer))
         _trace("linear_pool_tap_fused", idx)
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
@@ -1024,26 +1025,25 @@ class VNLinearMaxPoolFn(Function):
             entry = "vnp_linear_pool_screened_fwd" if screened else "vnp_linear_pool_fwd"
             nb = _lib.lib().vnp_linear_pool_screened_ws_bytes(G, gs, C, K) if screened else _lib.lib().vnp_linear_pool_ws_bytes(G, gs, C)
             ws = torch.empty((nb + 7) // 8, device=x.device, dtype=torch.int64)
-            prof = GEMM_PROFILE
-            if prof is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            timer = _prof_arm()
+            POOL_PATH_COUNTS["screened" if screened else "full_epilogue"] += 1
             if screened:
                 if POOL_SCREEN_PASS not in ("fp16", "bf16x3"):
                     raise _lib.VnpError(f"VNP_POOL_SCREEN_PASS must be 'fp16' or 'bf16x3', got {POOL_SCREEN_PASS!r}")
                 call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws), 1 if POOL_SCREEN_PASS == "fp16" else 0)
             else:
                 call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
-            if prof is not None:
-                e1.record()
-                # algorithmic work of the pool: both products over every point; the screened search EXECUTES about half of it
-                prof.append(("NT-pool-screened" if screened else "NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), e0, e1))
+            if timer is not None:
+                # flops = 2 M (2C) K: what the full epilogue executes six-fold; the screening pass (the timed kernel when `screened`)
+                # executes ONE fp16 product of it (three bf16 products with VNP_POOL_SCREEN_PASS=bf16x3)
+                GEMM_PROFILE.append(("NT-pool-screened" if screened else "NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), timer))
             if screened:
                 if POOL_SCREEN_STATS is not None:
                     POOL_SCREEN_STATS.append(ws[:2].view(torch.int32)[:3].clone())
                 else:
                     _screen_report(skey, ws)
         else:
+            POOL_PATH_COUNTS["unfused"] += 1
             y = gemm(x, W, nsplit=1)
             if POOL_DIRECTION_REASSOCIATE:
                 # d = Wd (W x) = (Wd W) x: the product of the two weight matrices is formed once per step (8.6 GFLOP for
@@ -1272,6 +1272,9 @@ class LinOutFn(Function):
 # both clouds at least this large -> vnp_chamfer_fwd_pruned (below it the brute-force kernel's slicing fills the chip better);
 # VNP_CHAMFER_BRUTE=1 forces the brute-force kernel everywhere
 CHAMFER_PRUNED_MIN_POINTS = (1 << 30) if os.environ.get("VNP_CHAMFER_BRUTE") == "1" else 4096
+# bench.py sets this to a list to receive, per pruned call, the device word with the number of (query, target) pairs the two scans
+# evaluated (int64 [1]; a full scan evaluates 2 B n m)
+CHAMFER_STATS = None
 
 
 class ChamferFn(Function):
@@ -1294,6 +1297,8 @@ class ChamferFn(Function):
             ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
             call("vnp_chamfer_fwd_pruned", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
             _trace("chamfer_pruned")
+            if CHAMFER_STATS is not None:
+                CHAMFER_STATS.append(ws[1:2].clone())
         else:
             _trace("chamfer_brute")
             ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
