@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-input-MFMA comparison steps (clean profiles)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_other / chamfer_op (clean profiles)")
+    ap.add_argument("--deadline", type=float, default=float(os.environ.get("VNP_BENCH_DEADLINE_S", "900")),
+                    help="self-launched ranks (--gpus N without a launcher): wall-clock limit in seconds after which the launcher "
+                         "terminates every rank and exits non-zero (a rank stuck in the rendezvous would otherwise hold the others)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="launcher / rendezvous / bucketed all-reduce rehearsal on CPU ranks over gloo with a toy torch model: "
                          "no HIP kernel runs and the printed line is marked invalid (tests/test_bench_launch.py)")
@@ -59,10 +62,12 @@ def parse_args():
 
 
 # ----------------------------------------------------------------------------------------------- rank launcher
-def launch_ranks(n):
+def launch_ranks(n, deadline_s):
     """`python bench.py --gpus N` with no launcher: start N rank processes (one per GPU, LOCAL_RANK = GPU ordinal) as children
     of this process, which itself never touches the GPU.  Rank 0 inherits stdout and prints the JSON line.  Exit status is
-    non-zero if any rank fails or fewer than N join (the survivors are terminated instead of waiting in the rendezvous)."""
+    non-zero if any rank fails, fewer than N join (the survivors are terminated instead of waiting in the rendezvous), or the
+    run is not over after ``deadline_s`` seconds (a rank that is alive but stuck — it never joins, or hangs in a collective —
+    is not an exit: without the deadline the launcher would poll until the driver's own limit)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -73,11 +78,15 @@ def launch_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    failed = None
+    failed, timed_out = None, False
+    t_end = time.monotonic() + deadline_s
     while failed is None and any(p.poll() is None for p in procs):
         time.sleep(0.2)
         failed = next((r for r, p in enumerate(procs) if p.poll() not in (None, 0)), None)
-    if failed is not None:
+        if failed is None and time.monotonic() > t_end:
+            timed_out = True
+            break
+    if failed is not None or timed_out:
         for p in procs:
             if p.poll() is None:
                 p.terminate()
@@ -86,6 +95,11 @@ def launch_ranks(n):
                 p.wait(10)
             except subprocess.TimeoutExpired:
                 p.kill()
+        if timed_out:
+            alive = [r for r, p in enumerate(procs) if p.returncode not in (0,)]
+            print(f"bench.py: not finished after the {deadline_s:.0f} s deadline (ranks still running then: {alive}); all ranks terminated",
+                  file=sys.stderr)
+            return 2
         print(f"bench.py: rank {failed} exited with status {procs[failed].returncode}; {n} ranks were required", file=sys.stderr)
         return 1
     return 0
@@ -255,6 +269,8 @@ def rehearse_cpu(args):
     from vn_pointcloudcompletion_amd.optim import FlatBuffers
     if os.environ.get("VNP_BENCH_FAIL_RANK") == os.environ.get("RANK"):
         raise SystemExit(3)                                      # test hook: a rank that dies before the rendezvous
+    if os.environ.get("VNP_BENCH_STUCK_RANK") == os.environ.get("RANK"):
+        time.sleep(3600)                                         # test hook: a rank that is alive but never joins
     rank, _, world = D.init_from_env(backend="gloo")
     if world != args.gpus or world < 2:
         raise SystemExit(f"--rehearse-cpu needs --gpus N >= 2 ranks (got --gpus {args.gpus}, WORLD_SIZE={world})")
@@ -296,7 +312,7 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: become one.  Nothing above has touched the GPU (torch is not even imported yet).
-        raise SystemExit(launch_ranks(args.gpus))
+        raise SystemExit(launch_ranks(args.gpus, args.deadline))
     if args.rehearse_cpu:
         return rehearse_cpu(args)
 
@@ -340,6 +356,8 @@ def main():
     torch.cuda.synchronize()
     prof = []
     ops.GEMM_PROFILE = prof
+    waits = [] if (D.collectives_on() and overlap) else None
+    D.EXPOSED_WAIT = waits
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, loss1, loss2 = train_step(cfg, model, opt, p, c)
@@ -348,11 +366,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
+    D.EXPOSED_WAIT = None
     elapsed = D.allreduce_scalar_max(elapsed)
     ranks_joined = D.world_size()
     if D.collectives_on():
         wire = sum(r.wire_bytes() for r in opt.grad_reducers) if overlap else sum(fb.numel * 4 for fb in opt.flat_buffers)
+        exposed = D.allreduce_scalar_max(sum(a.elapsed_time(b) for a, b in waits) / max(args.steps, 1)) if waits else None
         allreduce = {"backend": torch.distributed.get_backend(), "bytes_per_step": wire,
+                     "exposed_wait_ms_per_step": exposed,          # max over ranks: compute stream parked behind collectives after backward
                      "mode": ("32 MB buckets over the live parameters, overlapped with backward" if overlap
                               else "one flat all-reduce after backward"),
                      "buckets": sum(len(r.buckets) for r in opt.grad_reducers) if overlap else len(opt.flat_buffers)}

@@ -251,12 +251,19 @@ int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* s
  * in each pass from the per-point matrices u = x W1^T, v = x (W2 - W1)^T (columns [feat | dir]).
  * mode 0: Welford partials of |p| per block of vnp_edge_block_queries() queries -> vnp_vn_bn_finalize_chunked(chunk = 64 k);
  * mode 1: out[q] = mean_j leaky(bn(p), d); mode 2: backward sums (dL/dbeta, dL/dgamma partials); mode 3: gv[q] = sum_j g(q, j),
- * gu[nbr] += g(q, j) (atomics; gu zeroed here).  count = number of edges (Pq * k). */
+ * and, when gu != NULL, gu[nbr] += g(q, j) (float atomics; gu zeroed here).  count = number of edges (Pq * k).
+ * Default for gu: vnp_edge_fused_gather — gu[s] = sum over the edges INTO s (reverse adjacency from vnp_edge_reverse: start [Pu + 1],
+ * rev [Pq * k] query ids grouped by source; ws (Pu + 1) ints), the edge gradient recomputed term for term and summed in double: no
+ * atomics, no zero fill, deterministic. */
 int vnp_edge_block_queries(void);
 int vnp_vn_bn_finalize_chunked(hipStream_t st, const float* partial, int nchunk, int chunk_points, int C, long long count,
                                float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps);
 int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
-                   long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+    
+int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long long Pu, int* start, int* rev, int* ws);
+int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
+                          long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu);               long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                    float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
                    const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv);
 /* out[(p*k+j)*3+t][c] = u[nbr[p*k+j]*3+t][c] + v[p*3+t][c]: edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278)

@@ -88,6 +88,25 @@ def _worker(rank, world, port, q):
         ok = ok and "set of parameters" in str(e)
     D.barrier()                                                     # nobody is stuck inside an all-reduce
     red.remove()
+    # BatchNorm running statistics drift apart between replicas (each rank updates them from its own shard); sync_buffers makes a
+    # sharded evaluation describe rank 0's model: after it two ranks' eval-mode outputs on the same input agree with rank 0 alone
+    bn = torch.nn.BatchNorm1d(4)
+    bn.train()
+    torch.manual_seed(300 + rank)
+    bn(torch.randn(16, 4) * (rank + 1) + rank)                     # different running_mean / running_var on every rank
+    mine = [b.clone() for b in bn.buffers()]
+    D.sync_buffers(bn)
+    got = [torch.zeros_like(b) for b in mine]
+    for g_, b_ in zip(got, mine):
+        g_.copy_(b_)
+        dist.broadcast(g_, src=0)                                   # rank 0's pre-sync values
+    ok = ok and all(torch.equal(a, b) for a, b in zip(bn.buffers(), got))
+    bn.eval()
+    xe = torch.arange(8.0).reshape(2, 4)
+    ye = bn(xe).detach()
+    y0 = ye.clone()
+    dist.broadcast(y0, src=0)
+    ok = ok and torch.equal(ye, y0)
     q.put((rank, ok, w0.sum().item(), mx))
     D.barrier()
     dist.destroy_process_group()

@@ -232,6 +232,57 @@ def test_edge_conv_fused_equals_unfused(lib_built, P, k, C, Pu, training):
         assert (a - b).abs().max().item() <= 2e-5 * scale, (name, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("Pq,k,Pu", [(130, 16, 130), (70, 8, 200), (4096, 20, 4096), (5, 3, 1), (1000, 1, 3000)])
+def test_edge_reverse_is_the_reverse_adjacency(lib_built, Pq, k, Pu):
+    """vnp_edge_reverse: start = exclusive prefix of the in-degrees, and the queries listed for a source point are exactly the queries
+    that name it (as a multiset: a query naming a source twice is listed twice); sources nobody names have empty lists."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(Pq * 7 + k)
+    nbr = torch.randint(0, Pu, (Pq, k), generator=g, dtype=torch.int32)
+    nbr[: Pq // 3] = nbr[0, 0]                                       # a hub: a third of the queries name one source k times each
+    start, rev = ops.edge_reverse(nbr.cuda(), Pu)
+    start, rev = start.cpu().numpy(), rev.cpu().numpy()
+    flat = nbr.numpy().reshape(-1)
+    deg = np.bincount(flat, minlength=Pu)
+    assert np.array_equal(start, np.concatenate([[0], np.cumsum(deg)]))
+    order = np.argsort(flat, kind="stable")
+    want_q = order // k                                              # queries grouped by source, ascending inside a group
+    for s in np.unique(np.concatenate([flat[:50], [flat.max(), flat.min()]])):
+        assert np.array_equal(np.sort(rev[start[s]:start[s + 1]]), want_q[start[s]:start[s + 1]])
+    got = np.concatenate([np.sort(rev[start[s]:start[s + 1]]) for s in range(Pu)]) if Pu <= 4096 else None
+    if got is not None:
+        assert np.array_equal(got, want_q)
+
+
+@pytest.mark.parametrize("P,k,C", [(512, 20, 64), (1000, 16, 128), (2048, 16, 32)])
+def test_edge_grad_gather_is_deterministic_and_equals_the_atomic_form(lib_built, P, k, C, monkeypatch):
+    """The neighbour-feature gradient of the fused EdgeConv as a gather over the reverse adjacency (vnp_edge_fused_gather, the default):
+    the same bits on every run although the order inside a source's list is unspecified (sums taken in double), and equal to the
+    float-atomics form (VNP_EDGE_ATOMICS=1) to summation rounding; gv and the parameter gradients are the same kernels' output."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(P + C)
+    u0, v0 = torch.randn(P * 3, 2 * C, generator=g), torch.randn(P * 3, 2 * C, generator=g)
+    nbr = torch.randint(0, P, (P, k), generator=g, dtype=torch.int32)
+    nbr[:, 0] = 7                                                    # a hub with P incoming edges
+    gam0, bet0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    gout = torch.randn(P * 3, C, generator=g).cuda()
+
+    def run(atomics):
+        monkeypatch.setattr(ops, "EDGE_GRAD_ATOMICS", atomics)
+        u, v = u0.cuda().requires_grad_(True), v0.cuda().requires_grad_(True)
+        gam, bet = gam0.cuda().requires_grad_(True), bet0.cuda().requires_grad_(True)
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        out = ops.EdgeConvFn.apply(u, v, nbr.cuda(), gam, bet, rm, rv, True, 0.2)
+        (out * gout).sum().backward()
+        return u.grad, v.grad, gam.grad, bet.grad
+    a, b, c = run(False), run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))             # bit-for-bit repeatable
+    for name, x, y in zip(("gu", "gv", "ggamma", "gbeta"), a, c):
+        scale = y.abs().max().item() + 1e-12
+        assert (x - y).abs().max().item() <= 1e-5 * scale, (name, (x - y).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("Nr,Nq,k", [(2048, 2048, 20), (512, 512, 16), (128, 128, 16), (700, 300, 8), (4096, 100, 32), (40, 40, 40), (70, 33, 64)])
 def test_knn_coords_kernel_equals_matrix_path(lib_built, Nr, Nq, k):
     """vnp_knn_coords_kernel (coordinate graphs: one wave per query, distances in registers, threshold selection) against the

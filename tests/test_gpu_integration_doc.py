@@ -27,14 +27,17 @@ def test_integration_stubs_run_and_agree(lib_built):
     ns = _doc_namespace()
     g = torch.Generator().manual_seed(0)
     a, b = (torch.rand(2, 300, 3, generator=g) - 0.5).cuda(), (torch.rand(2, 500, 3, generator=g) - 0.5).cuda()
-    # Chamfer: the pybind-shaped forward / backward pair
-    d1, d2 = torch.empty(2, 300, device="cuda"), torch.empty(2, 500, device="cuda")
-    i1, i2 = torch.empty(2, 300, device="cuda", dtype=torch.int32), torch.empty(2, 500, device="cuda", dtype=torch.int32)
+    # Chamfer: the pybind-shaped forward / backward pair.  The protocol at that boundary: the CALLER allocates the outputs,
+    # zero-filled on the host and moved to the device — distances as float32, indices as int32 — and the call fills them in place
+    d1, d2 = torch.zeros(2, 300).to("cuda"), torch.zeros(2, 500).to("cuda")
+    i1, i2 = torch.zeros(2, 300, dtype=torch.int32).to("cuda"), torch.zeros(2, 500, dtype=torch.int32).to("cuda")
+    p1, p2 = d1.data_ptr(), i2.data_ptr()
     ns["chamfer_3D"].forward(a, b, d1, d2, i1, i2)
+    assert d1.data_ptr() == p1 and i2.data_ptr() == p2 and (d1 > 0).all() and i2.max() > 0          # filled in place
     e1, e2, j1, j2 = ops.ChamferFn.apply(a, b)
     assert torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
     g1, g2 = torch.rand(2, 300, generator=g).cuda(), torch.rand(2, 500, generator=g).cuda()
-    ga, gb = torch.empty_like(a), torch.empty_like(b)
+    ga, gb = torch.zeros(a.size()).to("cuda"), torch.zeros(b.size()).to("cuda")                        # caller-zeroed gradient buffers
     ns["chamfer_3D"].backward(a, b, ga, gb, g1, g2, i1, i2)
     ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
     o1, o2, _, _ = ops.ChamferFn.apply(ar, br)
@@ -54,77 +57,3 @@ def test_integration_stubs_run_and_agree(lib_built):
     assert idx.shape == (2, 8, 500) and torch.equal(idx.transpose(1, 2).int(), ops.knn_indices(a, b, 8))
     fps = ns["furthest_point_sample"](a, 64)
     assert torch.equal(fps, ops.fps_indices(a, 64))
-
-
-def test_reference_wrappers_run_unchanged_on_the_stub_modules(lib_built):
-    """Drop-in proof at the pybind boundary: the call sequences of the reference's two autograd wrappers —
-    extensions/earth_movers_distance/emd.py:6-43 and extensions/chamfer_distance/chamfer_distance.py:29-84 — re-typed here
-    statement for statement (caller-allocated, zero-filled outputs created on the CPU and moved; the tuple-free `match`),
-    bound to INTEGRATION.md's stub modules instead of `emd_cuda` / `chamfer_3D`, against this package's own operators."""
-    from vn_pointcloudcompletion_amd import ops
-    from vn_pointcloudcompletion_amd.emd import EarthMoverDistance as OurEMD
-    ns = _doc_namespace()
-    emd_cuda, chamfer_3D = ns["emd_cuda"], ns["chamfer_3D"]
-
-    class EarthMoverDistanceFunction(torch.autograd.Function):          # emd.py:6-22
-        @staticmethod
-        def forward(ctx, xyz1, xyz2):
-            xyz1 = xyz1.contiguous()
-            xyz2 = xyz2.contiguous()
-            assert xyz1.is_cuda and xyz2.is_cuda
-            match = emd_cuda.approxmatch_forward(xyz1, xyz2)
-            cost = emd_cuda.matchcost_forward(xyz1, xyz2, match)
-            ctx.save_for_backward(xyz1, xyz2, match)
-            return cost
-
-        @staticmethod
-        def backward(ctx, grad_cost):
-            xyz1, xyz2, match = ctx.saved_tensors
-            grad_cost = grad_cost.contiguous()
-            grad_xyz1, grad_xyz2 = emd_cuda.matchcost_backward(grad_cost, xyz1, xyz2, match)
-            return grad_xyz1, grad_xyz2
-
-    class chamfer_3DFunction(torch.autograd.Function):                  # chamfer_distance.py:29-71
-        @staticmethod
-        def forward(ctx, xyz1, xyz2):
-            batchsize, n, _ = xyz1.size()
-            _, m, _ = xyz2.size()
-            device = xyz1.device
-            dist1 = torch.zeros(batchsize, n).to(device)
-            dist2 = torch.zeros(batchsize, m).to(device)
-            idx1 = torch.zeros(batchsize, n).type(torch.IntTensor).to(device)
-            idx2 = torch.zeros(batchsize, m).type(torch.IntTensor).to(device)
-            torch.cuda.set_device(device)
-            chamfer_3D.forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
-            ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
-            return dist1, dist2, idx1, idx2
-
-        @staticmethod
-        def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
-            xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-            graddist1 = graddist1.contiguous()
-            graddist2 = graddist2.contiguous()
-            device = graddist1.device
-            gradxyz1 = torch.zeros(xyz1.size()).to(device)
-            gradxyz2 = torch.zeros(xyz2.size()).to(device)
-            chamfer_3D.backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
-            return gradxyz1, gradxyz2
-
-    g = torch.Generator().manual_seed(3)
-    a, b = (torch.rand(2, 512, 3, generator=g) - 0.5).cuda(), (torch.rand(2, 384, 3, generator=g) - 0.5).cuda()
-    # EMD: cost and both gradients equal this package's operator (same kernels underneath)
-    a1, b1, a2, b2 = (v.clone().requires_grad_(True) for v in (a, b, a, b))
-    w = torch.tensor([0.7, 1.3], device="cuda")
-    c1 = EarthMoverDistanceFunction.apply(a1, b1)
-    (c1 * w).sum().backward()
-    c2 = OurEMD()(a2, b2)
-    (c2 * w).sum().backward()
-    assert torch.allclose(c1, c2, rtol=1e-5) and torch.allclose(a1.grad, a2.grad, rtol=1e-4, atol=1e-8) and torch.allclose(b1.grad, b2.grad, rtol=1e-4, atol=1e-8)
-    # Chamfer: the reference's mean-of-distances use (metrics/loss.py:42-43) through its wrapper
-    a1, b1, a2, b2 = (v.clone().requires_grad_(True) for v in (a, b, a, b))
-    d1, d2, i1, i2 = chamfer_3DFunction.apply(a1, b1)
-    (d1.mean() + d2.mean()).backward()
-    e1, e2, j1, j2 = ops.ChamferFn.apply(a2, b2)
-    (e1.mean() + e2.mean()).backward()
-    assert torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
-    assert torch.allclose(a1.grad, a2.grad, rtol=1e-5, atol=1e-9) and torch.allclose(b1.grad, b2.grad, rtol=1e-5, atol=1e-9)

@@ -43,7 +43,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 and all(os.path.getmtime(o) >= os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
-        cmd += os.environ.get("VNP_EXTRA_HIPCC_FLAGS", "").split()          # measurement builds (-DVNP_EXPERIMENT_...)
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -108,6 +107,8 @@ _SIGNATURES = {
     "vnp_vn_bn_finalize_chunked": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _f, _f],
     "vnp_edge_fused": [_i, _vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _ll, _vp, _i, _ll,
                        _vp, _i],
+    "vnp_edge_reverse": [_vp, _ll, _i, _ll, _vp, _vp, _vp],
+    "vnp_edge_fused_gather": [_vp, _i, _vp, _i, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _ll, _vp, _i],
     "vnp_edge_gather_add": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_fold_fused": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll,
                        _vp, _vp, _i],
@@ -195,11 +196,13 @@ class KernelTimer:
         return ms.value * 1e-3
 
     def __del__(self):
-        h = KernelTimer._hip
-        if h is not None:
+        try:                                    # (at interpreter shutdown the class attribute may already be gone)
+            h = KernelTimer._hip
             for e in (self.e0, self.e1):
-                if e:
+                if h is not None and e:
                     h.hipEventDestroy(e)
+        except Exception:
+            pass
 
 
 def set_gemm_mode(mode: str) -> None:

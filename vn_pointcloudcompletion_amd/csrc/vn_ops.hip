@@ -196,15 +196,9 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
 // trades a written-then-re-read map for a second read of the inputs: 6 maps instead of 7 in the rank-1 form (2R + 2R2W against
 // 2R2W + 2R1W), 8 = 8 in the matrix form but with 6 reads / 2 writes instead of 5 / 3 (reads stream faster: hbm_yardstick).
 // gradients only: v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the ~12-instruction IEEE sequences (the rank-1 form was issue-bound)
-#ifdef VNP_EXPERIMENT_IEEE_GRADS          // accuracy probe only: IEEE division / sqrt in the gradient kernels too
-#define BDIV(a, b) ((a) / (b))
-#define BSQRT(a) sqrtf(a)
-#define VNP_GRAD_HW 0
-#else
 #define BDIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
 #define BSQRT(a) __builtin_amdgcn_sqrtf(a)
 #define VNP_GRAD_HW 1
-#endif
 template <int MODE>
 __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __restrict__ go, int ldgo,
                                                                const float* __restrict__ go_row, const float* __restrict__ go_col,
@@ -1077,7 +1071,12 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
 //   MODE 0  norm statistics of p over all edges (Welford partial per block of 64 queries)
 //   MODE 1  out[q] = 1/k sum_j leaky(bn(p), d)(q, j)
 //   MODE 2  backward sums  S1 = sum g_nhat, S2 = sum g_nhat * xhat  (= dL/dbeta, dL/dgamma), upstream gradient go[q] / k per edge
-//   MODE 3  backward:  gv[q] = sum_j (dL/dp | dL/dd)(q, j)   and   gu[nbr[q][j]] += (dL/dp | dL/dd)(q, j)  (atomics)
+//   MODE 3  backward:  gv[q] = sum_j (dL/dp | dL/dd)(q, j)   and, when gu is given,  gu[nbr[q][j]] += (dL/dp | dL/dd)(q, j)  (float atomics:
+//           6 per (edge, channel), 2.8 ms of config 3's step at ~1.3 TB/s of added bytes)
+//   gather  (vnp_edge_gather_u_kernel, the default for gu)  gu[s] = sum over the edges INTO s, listed by the reverse adjacency
+//           (vnp_edge_reverse): the edge's gradient is recomputed from u[s] + v[q] and go[q] — the same arithmetic term for term — and
+//           summed per source point in double (exact for addends within 2^29 of each other, so the result does not depend on the order
+//           of a source's list), stored once: no atomics, no zero-fill, deterministic
 // The per-edge arithmetic is that of vnp_bn_leaky_fwd / bwd1 / bwd2 above, term for term.
 struct VnpEdgeArgs {
     const float* u; int ldu; const float* v; int ldv; const int* nbr;
@@ -1170,7 +1169,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             const float kk = pn > 0.f ? EDIV(gn, pn) : 0.f;
             const float f0 = s * g0 + kk * x0, f1 = s * g1 + kk * x1, f2 = s * g2 + kk * x2;   // dL/dp of this edge
             o0 += f0; o1 += f1; o2 += f2; h0 += e0; h1 += e1; h2 += e2;
-            if (live) {
+            if (live && a.gu) {                     // scatter form (gu given): float atomics; the default is vnp_edge_fused_gather below
                 float* wu = a.gu + urow * a.ldgu + c;
                 atomicAdd(wu, f0); atomicAdd(wu + a.ldgu, f1); atomicAdd(wu + 2 * a.ldgu, f2);
                 atomicAdd(wu + C, e0); atomicAdd(wu + a.ldgu + C, e1); atomicAdd(wu + 2 * a.ldgu + C, e2);
@@ -1209,8 +1208,122 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
         }
     }
 }
+
+// gu[s] = sum over the edges (q -> s) of (dL/dp | dL/dd)(q, s): MODE 3's arithmetic per edge, gathered per SOURCE point.
+// A workgroup = 64 channels x 4 edge lanes walks VNP_EDGE_SB consecutive sources; the four lanes share a source's list (edge e, e + 4, ...:
+// a hub of a feature-space graph with hundreds of incoming edges does not serialise on one thread) and meet in LDS in a fixed order.
+#define VNP_EDGE_SB 16
+__global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArgs a, const int* __restrict__ rstart, const int* __restrict__ rev,
+                                                               long long Pu)
+{
+    constexpr int MODE = 3;
+    __shared__ double red[3][6][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx, C = a.C;
+    const bool live = c < C;
+    const int cc = live ? c : 0;
+    const long long s0 = (long long)blockIdx.y * VNP_EDGE_SB;
+    const long long s1 = min(Pu, s0 + VNP_EDGE_SB);
+    const float mu = a.mean[cc], rs = a.rstd[cc], ga = a.gamma[cc], be = a.beta[cc];
+    float m1 = 0.f, m2 = 0.f;
+    if (a.sums) { m1 = a.sums[2 * cc] * a.inv_count; m2 = a.sums[2 * cc + 1] * a.inv_count; }
+    const float kf = (float)a.k;
+    for (long long sp = s0; sp < s1; ++sp) {
+        const float* ru = a.u + (size_t)sp * 3 * a.ldu + cc;
+        const float up0 = ru[0], up1 = ru[a.ldu], up2 = ru[2 * a.ldu];
+        const float ud0 = ru[C], ud1 = ru[a.ldu + C], ud2 = ru[2 * a.ldu + C];
+        double F0 = 0.0, F1 = 0.0, F2 = 0.0, E0 = 0.0, E1 = 0.0, E2 = 0.0;
+        const int e1 = rstart[sp + 1];
+        for (int e = rstart[sp] + py; e < e1; e += 4) {
+            const size_t q = (size_t)rev[e];
+            const float* rv = a.v + q * 3 * a.ldv + cc;
+            const float* rg = a.go + q * 3 * a.ldgo + cc;
+            const float x0 = up0 + rv[0], x1 = up1 + rv[a.ldv], x2 = up2 + rv[2 * a.ldv];
+            const float d0 = ud0 + rv[C], d1 = ud1 + rv[a.ldv + C], d2 = ud2 + rv[2 * a.ldv + C];
+            const float ge0 = rg[0] / kf, ge1 = rg[a.ldgo] / kf, ge2 = rg[2 * a.ldgo] / kf;
+            const float pn = ESQRT(vnp_sq3(x0, x1, x2));
+            const float n = pn + VNP_EPS;
+            const float xh = (n - mu) * rs;
+            const float nh = xh * ga + be;
+            const float s = EDIV(nh, n);
+            const float y0 = x0 * s, y1 = x1 * s, y2 = x2 * s;
+            const float dot = y0 * d0 + y1 * d1 + y2 * d2;
+            float g0 = ge0, g1 = ge1, g2 = ge2, ee0 = 0.f, ee1 = 0.f, ee2 = 0.f;
+            if (dot < 0.f) {
+                const float cf = 1.f - a.ns;
+                const float inv = EDIV(1.f, vnp_sq3(d0, d1, d2) + VNP_EPS);
+                const float al = dot * inv;
+                const float gdd = g0 * d0 + g1 * d1 + g2 * d2;
+                const float k1 = cf * gdd * inv;
+                ee0 = -cf * (al * g0 + gdd * (y0 * inv - 2.f * al * inv * d0));
+                ee1 = -cf * (al * g1 + gdd * (y1 * inv - 2.f * al * inv * d1));
+                ee2 = -cf * (al * g2 + gdd * (y2 * inv - 2.f * al * inv * d2));
+                g0 -= k1 * d0; g1 -= k1 * d1; g2 -= k1 * d2;
+            }
+            const float gs = g0 * x0 + g1 * x1 + g2 * x2;
+            const float gnh = EDIV(gs, n);
+            const float gn = ga * rs * (gnh - m1 - xh * m2) - EDIV(gs * nh, n * n);
+            const float kk = pn > 0.f ? EDIV(gn, pn) : 0.f;
+            F0 += (double)(s * g0 + kk * x0); F1 += (double)(s * g1 + kk * x1); F2 += (double)(s * g2 + kk * x2);
+            E0 += (double)ee0; E1 += (double)ee1; E2 += (double)ee2;
+        }
+        if (py > 0) {
+            red[py - 1][0][cx] = F0; red[py - 1][1][cx] = F1; red[py - 1][2][cx] = F2;
+            red[py - 1][3][cx] = E0; red[py - 1][4][cx] = E1; red[py - 1][5][cx] = E2;
+        }
+        __syncthreads();
+        if (py == 0 && live) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                F0 += red[j][0][cx]; F1 += red[j][1][cx]; F2 += red[j][2][cx];
+                E0 += red[j][3][cx]; E1 += red[j][4][cx]; E2 += red[j][5][cx];
+            }
+            float* w = a.gu + (size_t)sp * 3 * a.ldgu + c;
+            w[0] = (float)F0; w[a.ldgu] = (float)F1; w[2 * a.ldgu] = (float)F2;
+            w[C] = (float)E0; w[a.ldgu + C] = (float)E1; w[2 * a.ldgu + C] = (float)E2;
+        }
+        __syncthreads();
+    }
+}
 #undef EDIV
 #undef ESQRT
+
+// ---- reverse adjacency of a neighbour table: count -> exclusive scan -> fill (integer atomics: the ORDER inside a source's list is
+// unspecified, its CONTENT is not)
+__global__ void vnp_edge_rev_hist_kernel(const int* __restrict__ nbr, long long total, int* __restrict__ deg)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) atomicAdd(&deg[nbr[i]], 1);
+}
+
+// start[i] = sum of deg[0 .. i), i = 0 .. n; deg is zeroed (it becomes the fill pass's cursor).  One workgroup of 1024 threads.
+__global__ void __launch_bounds__(1024) vnp_edge_rev_scan_kernel(int* __restrict__ deg, long long n, int* __restrict__ start)
+{
+    __shared__ int tot[1024];
+    const int t = threadIdx.x;
+    const long long per = (n + 1023) / 1024, lo = min(n, t * per), hi = min(n, lo + per);
+    int sum = 0;
+    for (long long i = lo; i < hi; ++i) sum += deg[i];
+    tot[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = t >= o ? tot[t - o] : 0;
+        __syncthreads();
+        tot[t] += v;
+        __syncthreads();
+    }
+    int run = tot[t] - sum;
+    for (long long i = lo; i < hi; ++i) { const int v = deg[i]; start[i] = run; run += v; deg[i] = 0; }
+    if (t == 1023) start[n] = tot[1023];
+}
+
+__global__ void vnp_edge_rev_fill_kernel(const int* __restrict__ nbr, long long total, int k, const int* __restrict__ start, int* __restrict__ cursor,
+                                         int* __restrict__ rev)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int sidx = nbr[i];
+        rev[start[sidx] + atomicAdd(&cursor[sidx], 1)] = (int)(i / k);
+    }
+}
 
 // ================================================================================================ C-ABI
 static inline dim3 vnp_grid_pc(long long P, int C, int chunk) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, chunk)); }
@@ -1534,7 +1647,8 @@ extern "C" int vnp_edge_block_queries(void) { return VNP_EDGE_QB; }
 
 // Fused EdgeConv passes (see vnp_edge_fused_kernel).  u [Pu*3, ldu >= 2C], v [Pq*3, ldv >= 2C], nbr [Pq][k] ids < Pu.
 // mode 0: partial [ceil(Pq/64)][C][2].  mode 1: out [Pq*3, ldo].  mode 2: go, partial.  mode 3: go, sums ([C][2] or NULL), count =
-// number of edges, gu [Pu*3, ldgu >= 2C] (zeroed here), gv [Pq*3, ldgv >= 2C].
+// number of edges, gv [Pq*3, ldgv >= 2C], and gu [Pu*3, ldgu >= 2C] (zeroed here, filled with float atomics) or NULL (then gu comes from
+// vnp_edge_fused_gather).
 extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
                               long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
@@ -1545,7 +1659,7 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
     if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
     if (mode == 1 && !out) return VNP_EINVAL;
     if (mode >= 2 && !go) return VNP_EINVAL;
-    if (mode == 3 && (!gu || !gv || Pu <= 0)) return VNP_EINVAL;
+    if (mode == 3 && (!gv || (gu && Pu <= 0))) return VNP_EINVAL;
     const long long nblk = (Pq + VNP_EDGE_QB - 1) / VNP_EDGE_QB;
     if (nblk > 65535LL * 32768LL) return VNP_EINVAL;
     VnpEdgeArgs a;
@@ -1554,7 +1668,7 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
     a.partial = (float2*)partial; a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo;
     a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f;
     a.gu = gu; a.ldgu = ldgu; a.gv = gv; a.ldgv = ldgv;
-    if (mode == 3) {
+    if (mode == 3 && gu) {
         hipError_t e = ldgu == 2 * C ? hipMemsetAsync(gu, 0, (size_t)Pu * 3 * ldgu * 4, st)
                                      : hipMemset2DAsync(gu, (size_t)ldgu * 4, 0, (size_t)2 * C * 4, (size_t)Pu * 3, st);
         if (e != hipSuccess) return (int)e;
@@ -1576,6 +1690,45 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
         case 2: hipLaunchKernelGGL(vnp_edge_fused_kernel<2>, grid, block, 0, st, s); break;
         default: hipLaunchKernelGGL(vnp_edge_fused_kernel<3>, grid, block, 0, st, s); break;
         }
+    }
+    return vnp_last_error();
+}
+
+// Reverse adjacency of nbr [Pq][k] (ids < Pu): start [Pu + 1] = exclusive prefix of the in-degrees, rev [Pq * k] = query ids grouped by
+// source point (order inside a group unspecified).  ws: (Pu + 1) ints.  Pq * k and Pu below 2^31.
+extern "C" int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long long Pu, int* start, int* rev, int* ws)
+{
+    if (!nbr || !start || !rev || !ws || Pq <= 0 || k <= 0 || Pu <= 0 || Pq * k > 2147483647LL || Pu > 2147483646LL) return VNP_EINVAL;
+    const long long total = Pq * k;
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(Pu + 1) * 4, st);
+    if (e != hipSuccess) return (int)e;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(vnp_edge_rev_hist_kernel, dim3(blocks), dim3(256), 0, st, nbr, total, ws);
+    hipLaunchKernelGGL(vnp_edge_rev_scan_kernel, dim3(1), dim3(1024), 0, st, ws, Pu, start);
+    hipLaunchKernelGGL(vnp_edge_rev_fill_kernel, dim3(blocks), dim3(256), 0, st, nbr, total, k, (const int*)start, ws, rev);
+    return vnp_last_error();
+}
+
+// gu [Pu*3, ldgu >= 2C] of vnp_edge_fused's mode 3 as a gather over the reverse adjacency (start, rev from vnp_edge_reverse): no atomics,
+// no zero fill, the same per-edge arithmetic; k = neighbours per query (the mean-pool divisor), count = number of edges.
+extern "C" int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
+                                     long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu)
+{
+    if (!u || !v || !start || !rev || !mean || !rstd || !gamma || !beta || !go || !gu || Pu <= 0 || k <= 0 || C <= 0) return VNP_EINVAL;
+    VnpEdgeArgs a{};
+    a.u = u; a.ldu = ldu; a.v = v; a.ldv = ldv; a.k = k; a.C = C;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
+    a.go = go; a.ldgo = ldgo; a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f;
+    a.gu = gu; a.ldgu = ldgu;
+    const long long nblk = (Pu + VNP_EDGE_SB - 1) / VNP_EDGE_SB;
+    for (long long b0 = 0; b0 < nblk; b0 += 65535) {
+        const int nb = (int)((nblk - b0) < 65535 ? (nblk - b0) : 65535);
+        VnpEdgeArgs s = a;
+        const long long soff = b0 * VNP_EDGE_SB;
+        s.u = u + (size_t)soff * 3 * ldu; s.gu = gu + (size_t)soff * 3 * ldgu;
+        const long long np = (Pu - soff) < (long long)nb * VNP_EDGE_SB ? (Pu - soff) : (long long)nb * VNP_EDGE_SB;
+        hipLaunchKernelGGL(vnp_edge_gather_u_kernel, dim3(vnp_cdiv(C, 64), nb), dim3(256), 0, st, s, start + soff, rev, np);
     }
     return vnp_last_error();
 }

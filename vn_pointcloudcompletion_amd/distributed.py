@@ -35,18 +35,26 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_from_env(backend=None):
+EXPOSED_WAIT = None
+
+
+def init_from_env(backend=None, timeout_s=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
-    Returns (rank, local_rank, world_size).  A single process needs no group."""
+    Returns (rank, local_rank, world_size).  A single process needs no group.
+    The rendezvous and every collective carry an explicit timeout (``timeout_s``, else VNP_DIST_TIMEOUT_S, else 300 s): when a rank never
+    joins, or drops out of a collective, the others raise instead of waiting for torch's default (10-30 minutes)."""
     rank, local_rank, world = env_world()
     if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
+        import datetime
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("VNP_DIST_TIMEOUT_S", "300"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, local_rank, world
 
 
@@ -85,7 +93,10 @@ class ShardedBatchSampler(torch.utils.data.Sampler):
 
     A global batch of b samples is split as evenly as b allows (rank r gets [r*b//world, (r+1)*b//world): the reference's
     batch_size 12 on 8 GPUs gives shards of 1 or 2 samples); ``weight(i)`` is the factor a rank must apply to its mean loss of
-    batch i so that the all-reduce AVERAGE of the gradients equals the gradient of the global-batch mean.  When a batch has
+    batch i so that the all-reduce AVERAGE of the gradients equals the gradient of the global-batch mean — for everything in the
+    network that treats samples independently.  Train-mode VNBatchNorm does not: its statistics are taken per SHARD (there is no
+    SyncBN), so with shards of 1-2 samples (batch_size 12 on 8 GPUs) training numerics differ from the single-process run whose
+    BatchNorm saw all 12; bench.py's weak scaling (32 samples per GPU) keeps the single-GPU statistics.  When a batch has
     fewer samples than ranks (a short final batch), ``mode='train'`` replicates it on every rank (weight 1: same step on all
     ranks, the collectives stay aligned) and ``mode='eval'`` gives it to the first ranks only (no collectives inside an
     evaluation loop, sums are all-reduced once at the end).
@@ -154,6 +165,16 @@ def broadcast_model(model, src=0):
     if collectives_on():
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=src)
+
+
+def sync_buffers(model, src=0):
+    """Make every replica's BUFFERS (BatchNorm running statistics, num_batches_tracked) rank ``src``'s.  The gradient all-reduce keeps
+    the parameters identical; the running statistics are updated by each rank from its own shard and drift apart, so before a sharded
+    evaluation — and before rank 0 saves a checkpoint that the reported metric is supposed to describe — they are made equal again."""
+    if collectives_on():
+        with torch.no_grad():
+            for t in model.buffers():
                 dist.broadcast(t.data, src=src)
 
 
@@ -296,9 +317,19 @@ class OverlappedGradReducer:
             while self.launched < len(self.buckets):
                 self._launch(self.launched)
             w = world_size()
+            # EXPOSED_WAIT (bench.py, N > 1): a list that receives one (start, end) event pair per step bracketing the waits on the compute
+            # stream: the time the stream sits behind collectives that backward did not cover
+            ev = EXPOSED_WAIT is not None and torch.cuda.is_available() and dist.get_backend() == "nccl"
+            if ev:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for work, flat in self.works:
                 if work is not None:
                     work.wait()
+            if ev:
+                e1.record()
+                EXPOSED_WAIT.append((e0, e1))
+            for work, flat in self.works:
                 if flat is not None:
                     flat.mul_(1.0 / w)
             if self.late:

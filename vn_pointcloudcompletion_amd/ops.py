@@ -422,7 +422,15 @@ class SplitColsFn(Function):
         if W.dim() != 2 or sum(sizes) != W.shape[1]:
             raise _lib.VnpError(f"split_cols: sizes {sizes} do not cover {tuple(W.shape)}")
         ctx.sizes, ctx.rows = sizes, W.shape[0]
-        return tuple(torch.split(W, list(sizes), dim=1))
+        parts = torch.split(W, list(sizes), dim=1)
+        # a slice the aligned GEMM kernels cannot take as it stands (row stride or start not a multiple of 16 bytes: the 385-column
+        # weights of Attention_VN_FoldingNet's folding stages) is copied once — a few hundred KB — instead of sending every product with
+        # it (49152 x 512 x 384 per stage, forward and backward) to the bounds-checked kernel: 6.2 ms of config 4's step
+        if W.stride(0) % 4 != 0 or W.stride(1) != 1:
+            parts = tuple(p.contiguous() for p in parts)
+        else:
+            parts = tuple(p if p.data_ptr() % 16 == 0 else p.contiguous() for p in parts)
+        return parts
 
     @staticmethod
     def backward(ctx, *gs):
@@ -574,6 +582,8 @@ class VNLinearLeakyFn(Function):
         gpd, ggamma, gbeta = out[:3]
         gb = out[3] if want_gb else None
         gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None          # dX = [dP | dD] [Wf; Wd]
+        if gx is not None:
+            gx._vnp_private = True               # a fresh buffer nobody else holds (see _grad_is_private)
         gWf = gWd = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gW = _wgrad(gpd, x, fine=ctx.folded)                                    # [2C, Cin] in one split-K launch
@@ -903,6 +913,14 @@ class VNMaxPoolFn(Function):
         return gx, None, None, None, None, None
 
 
+def _grad_is_private(g):
+    """True when an incoming gradient tensor may be accumulated into IN PLACE: it carries the mark VNLinearLeakyFn.backward puts on the
+    input gradient it has just allocated.  Autograd does not promise that a node is the only user of the tensor it is handed (a
+    consumer whose backward returns one tensor for several inputs, hooks, retain_grad); a gradient that autograd itself summed from
+    several consumers, or that any other backward produced, arrives without the mark and is added out of place."""
+    return getattr(g, "_vnp_private", False) is True
+
+
 class VNMaxPoolTapFn(Function):
     """VNMaxPool of a tensor that has a SECOND consumer (encoder: first_conv[1]'s output feeds maxpool1 and, concatenated with the
     pooled feature, second_conv[0]; models/pcn.py:169-172).  Returns (x, pooled, idx): the caller hands the returned x to the other
@@ -936,11 +954,11 @@ class VNMaxPoolTapFn(Function):
         (idx,) = ctx.saved_tensors
         G, gs, C = ctx.cfg
         gout = _rows(gout)
-        if gx is None or gx.dim() != 2 or gx.stride(1) != 1 or gx.shape != (G * gs * 3, C):
+        if gx is None or gx.dim() != 2 or gx.stride(1) != 1 or gx.shape != (G * gs * 3, C) or not _grad_is_private(gx):
             dense = torch.empty((G * gs * 3, C), device=gout.device, dtype=torch.float32)
             call("vnp_vn_pool_bwd", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(dense), C)
             return (dense if gx is None else gx + dense), None, None, None, None, None
-        # gx is the other consumer's freshly computed gradient (this node is its only user): accumulate in place
+        # gx is the other consumer's freshly allocated gradient and this node its only user (_grad_is_private): accumulate in place
         call("vnp_vn_pool_bwd_acc", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(gx), _ld(gx))
         return gx, None, None, None, None, None
 
@@ -986,7 +1004,7 @@ class VNLinearPoolTapFn(Function):
         G, gs, C = ctx.cfg
         if gout is not None:
             gout = _rows(gout)
-            if gy is None or gy.dim() != 2 or gy.stride(1) != 1 or gy.shape != (G * gs * 3, C):
+            if gy is None or gy.dim() != 2 or gy.stride(1) != 1 or gy.shape != (G * gs * 3, C) or not _grad_is_private(gy):
                 dense = torch.empty((G * gs * 3, C), device=x.device, dtype=torch.float32)
                 call("vnp_vn_pool_bwd", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(dense), C)
                 gy = dense if gy is None else gy + dense
@@ -1424,6 +1442,25 @@ class EdgeGatherAddFn(Function):
         return gu, gv, None
 
 
+# VNP_EDGE_ATOMICS=1: the neighbour-feature gradient of the fused EdgeConv by float atomics (the rounds 1-2 form) instead of the gather over
+# the reverse adjacency (A/B measurement)
+EDGE_GRAD_ATOMICS = os.environ.get("VNP_EDGE_ATOMICS", "0") == "1"
+
+
+def edge_reverse(nbr, Pu):
+    """Reverse adjacency (start [Pu + 1], rev [Pq * k]) of a neighbour table, cached on the tensor: layers that share a graph share it."""
+    cached = getattr(nbr, "_vnp_rev", None)
+    if cached is not None and cached[0].shape[0] == Pu + 1:
+        return cached
+    Pq, k = nbr.shape
+    start = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
+    rev = torch.empty(Pq * k, device=nbr.device, dtype=torch.int32)
+    ws = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
+    call("vnp_edge_reverse", ptr(nbr), Pq, k, Pu, ptr(start), ptr(rev), ptr(ws))
+    nbr._vnp_rev = (start, rev)
+    return start, rev
+
+
 class EdgeConvFn(Function):
     """VNLinearLeakyReLU on the kNN edge tensor followed by mean_pool over the k neighbours, with the edge tensor never
     materialised (vnp_edge_fused): u, v = the layer's linear maps applied per point ([P*3, 2C'], columns feat | dir),
@@ -1471,8 +1508,17 @@ class EdgeConvFn(Function):
         Pu = u.shape[0] // 3
         gu = torch.empty((Pu * 3, 2 * C), device=dev, dtype=torch.float32)
         gv = torch.empty((Pq * 3, 2 * C), device=dev, dtype=torch.float32)
-        call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-             None, None, 0, ptr(go), _ld(go), ptr(S) if training else None, Pq * k, ptr(gu), 2 * C, Pu, ptr(gv), 2 * C)
+        sums = ptr(S) if training else None
+        if EDGE_GRAD_ATOMICS:
+            call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+                 None, None, 0, ptr(go), _ld(go), sums, Pq * k, ptr(gu), 2 * C, Pu, ptr(gv), 2 * C)
+        else:
+            # gv per query as before; gu per SOURCE point through the reverse adjacency (built once per graph: conv4 / conv5 share theirs)
+            start, rev = edge_reverse(nbr, Pu)
+            call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+                 None, None, 0, ptr(go), _ld(go), sums, Pq * k, None, 0, 0, ptr(gv), 2 * C)
+            call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
+                 ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), 2 * C)
         return gu, gv, None, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, None, None
 
 

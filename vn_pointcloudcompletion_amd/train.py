@@ -8,8 +8,9 @@ Differences from the reference, all on purpose:
   * scalars go to ``<exp_dir>/{train,val}/scalars.jsonl`` (tensorboardX is not required); the per-epoch PNG
     (visualization/, matplotlib) is not produced;
   * under torch.distributed every rank loads and trains on its shard of each global batch (ShardedBatchSampler: uneven
-    shards are loss-weighted so the averaged gradient is the global-batch gradient), validation is sharded the same way and
-    its sums all-reduced, rank 0 logs and checkpoints;
+    shards are loss-weighted so the averaged gradient is the global-batch gradient up to the BatchNorm statistics, which each rank
+    takes over its own shard — no SyncBN), the per-epoch training loss is the weighted sum over all ranks, validation is sharded
+    the same way behind a broadcast of rank 0's BatchNorm running statistics and its sums all-reduced, rank 0 logs and checkpoints;
   * the shuffle order of epoch e is a function of (seed, e), so a resumed run continues the uninterrupted run's data order
     instead of replaying epoch 0's (the reference's generator is unseeded);
   * on --resume the StepLR schedule continues at the absolute epoch (lr at epoch e is that of an uninterrupted run); the
@@ -159,8 +160,9 @@ def train(config, args):
             trot = make_rotation(config.rotation, p.shape[0], config.device)
             if trot is not None:
                 p, c = trot.transform_points(p), trot.transform_points(c)
-            loss, loss1, loss2 = train_step(config, model, optimizer, p, c, trot, train_sampler.weight(i))
-            sums += torch.stack([loss, loss1, loss2])
+            wgt = train_sampler.weight(i)
+            loss, loss1, loss2 = train_step(config, model, optimizer, p, c, trot, wgt)
+            sums += torch.stack([loss, loss1, loss2]) * (1.0 if wgt is None else wgt)
             if is_main and (i + 1) % step == 0:
                 l, l1, l2 = loss.item(), loss1.item(), loss2.item()
                 log.info("Training Epoch [{:03d}/{:03d}] - Iteration [{:03d}/{:03d}]: coarse loss = {:.6f}, dense loss = {:.6f}, "
@@ -171,6 +173,9 @@ def train(config, args):
                 train_writer.add_scalar("Loss/Batch/Dense", l2, ts)
                 train_writer.add_scalar("Loss/Batch/Total", l, ts)
         scheduler.step()
+        if world > 1:
+            D.allreduce_sum_(sums)          # sum over ranks of weight x shard mean = world x the global-batch mean (weights average 1)
+            sums /= world
         tot, co, de = (sums / max(n_batches, 1)).tolist()
         if is_main:
             log.info("Training Epoch [{:03d}/{:03d}]: Coarse Loss = {:.6f}, Dense Loss = {:.6f}, Total Loss = {:.6f}".format(
@@ -179,9 +184,12 @@ def train(config, args):
             train_writer.add_scalar("Loss/Epoch/Dense", de * 1e3, epoch)
             train_writer.add_scalar("Loss/Epoch/Total", tot * 1e3, epoch)
 
-        # evaluation (train.py:198-250): replicas are identical after the all-reduced step, so every rank evaluates its
-        # shard of each validation batch and the per-sample sums are all-reduced once (no rank idles in a barrier while
-        # rank 0 walks the whole validation set — that wait used to be bounded only by the NCCL watchdog)
+        # evaluation (train.py:198-250): every rank evaluates its shard of each validation batch and the per-sample sums are
+        # all-reduced once (no rank idles in a barrier while rank 0 walks the whole validation set).  The all-reduced step keeps the
+        # PARAMETERS of the replicas identical, not their BatchNorm running statistics (each rank updates them from its own shard):
+        # rank 0's buffers — the ones model_last / model_best.pth will hold — are broadcast first, so the reduced metric and the
+        # best-checkpoint choice describe the model that is saved
+        D.sync_buffers(model)
         model.eval()
         val = torch.zeros(2, device=config.device)
         with torch.no_grad():
