@@ -21,16 +21,18 @@ def edge_conv_rows(layer: VNLinearLeakyReLU, x_rows, nbr, k):
     C = x_rows.shape[1]
     Wf, Wd = layer.map_to_feat.weight, layer.map_to_dir.weight
     Cout = Wf.shape[0]
+    bn = layer.batchnorm.bn
+    layer.batchnorm._tick()
+    if ops.EDGE_FUSED:
+        # ONE GEMM for u | v (x is read once, forward and backward), edge pre-activations u[nbr] + v recomputed inside each pass: the
+        # [P*k*3, 2C'] tensor is never written
+        uv = ops.VNLinearFn.apply(x_rows, ops.EdgeWeightsFn.apply(Wf, Wd), None, 0)        # [P*3, 4C']: u (feat | dir), v (feat | dir)
+        return ops.EdgeConvPackedFn.apply(uv, nbr, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
+                                          layer.negative_slope)
     Wu = torch.cat([Wf[:, :C], Wd[:, :C]], dim=0)                           # [2C', C]  (feat | dir)
     Wv = torch.cat([Wf[:, C:] - Wf[:, :C], Wd[:, C:] - Wd[:, :C]], dim=0)
     u = ops.VNLinearFn.apply(x_rows, Wu, None, 0)
     v = ops.VNLinearFn.apply(x_rows, Wv, None, 0)
-    bn = layer.batchnorm.bn
-    layer.batchnorm._tick()
-    if ops.EDGE_FUSED:
-        # edge pre-activations u[nbr] + v recomputed inside each pass: the [P*k*3, 2C'] tensor is never written
-        return ops.EdgeConvFn.apply(u, v, nbr, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
-                                    layer.negative_slope)
     pd = ops.EdgeGatherAddFn.apply(u, v, nbr)                              # [P*k*3, 2C']
     f = ops.VNBnLeakyFn.apply(pd, True, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
                               layer.negative_slope)                         # [P*k*3, C']

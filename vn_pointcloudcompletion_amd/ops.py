@@ -668,6 +668,7 @@ class DirLinearMaxPoolFn(Function):
         idx = torch.empty((G, C), device=dev, dtype=torch.int32)
         out = torch.empty((G * 3, C), device=dev, dtype=torch.float32)
         call("vnp_dir_pool_fwd", ptr(y), 2 * C, ptr(u), G, gs, C, ptr(idx), ptr(out), C)
+        idx, out = _forced_pool(idx, out, lambda: (u.reshape(-1, 3, 1) * y[:, :C].reshape(-1, 1, C)).reshape(-1, C), G, gs)
         _trace("dir_pool", idx)
         ctx.save_for_backward(h, u, W, idx)
         ctx.cfg = (G, gs, C)
@@ -913,6 +914,30 @@ class VNMaxPoolFn(Function):
         return gx, None, None, None, None, None
 
 
+# TEST HOOK (tests/test_gpu_layers.py): a list of arg-max index tensors [G, C]; while it is set, every VNMaxPool-type forward below takes
+# its next entry instead of its own pick (the pooled vectors are re-gathered with plain tensor ops) — "teacher forcing", so that two
+# evaluation orders of the network can be compared output for output although a handful of rounding-level ties would otherwise be broken
+# differently and move everything downstream.  Never set on the product path.
+POOL_IDX_FORCE = None
+
+
+def _forced_pool(idx, out, rows_of_y, G, gs):
+    f = POOL_IDX_FORCE
+    if f is None:
+        return idx, out
+    forced = f.pop(0).to(device=idx.device, dtype=torch.int32).contiguous()
+    if forced.shape != idx.shape:
+        raise _lib.VnpError(f"POOL_IDX_FORCE: index tensor {tuple(forced.shape)} offered to a pool of shape {tuple(idx.shape)}")
+    if torch.equal(forced, idx):
+        return idx, out
+    y = rows_of_y()                                                               # [G*gs*3, C]
+    C = idx.shape[1]
+    pt = torch.arange(G, device=idx.device).view(G, 1) * gs + forced.long()        # [G, C] global point
+    rows = (pt * 3).unsqueeze(1) + torch.arange(3, device=idx.device).view(1, 3, 1)
+    cols = torch.arange(C, device=idx.device).view(1, 1, C).expand(G, 3, C)
+    return forced, y[rows, cols].reshape(G * 3, C).contiguous()
+
+
 def _grad_is_private(g):
     """True when an incoming gradient tensor may be accumulated into IN PLACE: it carries the mark VNLinearLeakyFn.backward puts on the
     input gradient it has just allocated.  Autograd does not promise that a node is the only user of the tensor it is handed (a
@@ -942,6 +967,7 @@ class VNMaxPoolTapFn(Function):
         idx = torch.empty((G, C), device=xr.device, dtype=torch.int32)
         out = torch.empty((G * 3, C), device=xr.device, dtype=torch.float32)
         call("vnp_vn_pool_fwd", ptr(xr), _ld(xr), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        idx, out = _forced_pool(idx, out, lambda: xr, G, gs)
         _trace("pool_tap", idx)
         ctx.save_for_backward(idx)
         ctx.cfg = (G, gs, C)
@@ -991,6 +1017,7 @@ class VNLinearPoolTapFn(Function):
         call("vnp_linear_pool_store_fwd", ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(y), C, ptr(idx), ptr(out), C, ptr(ws))
         if timer is not None:
             GEMM_PROFILE.append(("NT", 2.0 * (G * gs * 3) * (2 * C) * K, 1, (G * gs * 3, 2 * C, K), timer))
+        idx, out = _forced_pool(idx, out, lambda: y, G, gs)
         _trace("linear_pool_tap_fused", idx)
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
@@ -1074,6 +1101,7 @@ class VNLinearMaxPoolFn(Function):
             ws_val = torch.empty((G, nch, C), device=x.device, dtype=torch.float32)
             ws_idx = torch.empty((G, nch, C), device=x.device, dtype=torch.int32)
             call("vnp_vn_pool_fwd", ptr(y), _ld(y), ptr(d), _ld(d), G, gs, C, ptr(idx), ptr(out), C, ptr(ws_val), ptr(ws_idx))
+        idx, out = _forced_pool(idx, out, lambda: gemm(x, W, nsplit=1), G, gs)
         _trace(("linear_pool_screened" if screened else "linear_pool_fused_epilogue") if fused else "linear_pool_unfused", idx)
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
@@ -1461,6 +1489,55 @@ def edge_reverse(nbr, Pu):
     return start, rev
 
 
+def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
+    """The two forward passes of the fused EdgeConv on u [Pu*3, >= 2C], v [Pq*3, >= 2C] (row strides free): (out, mean, rstd, nblk)."""
+    Pq, k = nbr.shape
+    C = u.shape[1] // 2
+    dev = u.device
+    qb = _lib.lib().vnp_edge_block_queries()
+    nblk = (Pq + qb - 1) // qb
+    if training:
+        part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
+        call("vnp_edge_fused", 0, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
+             ptr(part), None, 0, None, 0, None, 0, None, 0, 0, None, 0)
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        rstd = torch.empty(C, device=dev, dtype=torch.float32)
+        call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
+             ptr(running_var), BN_MOMENTUM, BN_EPS)
+    else:
+        mean = running_mean
+        rstd = torch.empty(C, device=dev, dtype=torch.float32)
+        call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+    out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
+    call("vnp_edge_fused", 1, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+         float(ns), None, ptr(out), C, None, 0, None, 0, None, 0, 0, None, 0)
+    return out, mean, rstd, nblk
+
+
+def _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv):
+    """The backward passes: fills gu [Pu*3, >= 2C] and gv [Pq*3, >= 2C] (row strides free: column halves of one buffer in the packed
+    form) and returns the per-channel sums S [C, 2] (dL/dbeta, dL/dgamma)."""
+    Pq, k = nbr.shape
+    C = u.shape[1] // 2
+    Pu = u.shape[0] // 3
+    part = torch.empty((nblk, C, 2), device=go.device, dtype=torch.float32)
+    call("vnp_edge_fused", 2, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+         ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0, 0, None, 0)
+    S = reduce_rows(part, 1, nblk, 2 * C).view(C, 2)
+    sums = ptr(S) if training else None
+    if EDGE_GRAD_ATOMICS:
+        call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             None, None, 0, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu), Pu, ptr(gv), _ld(gv))
+    else:
+        # gv per query as before; gu per SOURCE point through the reverse adjacency (built once per graph: conv4 / conv5 share theirs)
+        start, rev = edge_reverse(nbr, Pu)
+        call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             None, None, 0, ptr(go), _ld(go), sums, Pq * k, None, 0, 0, ptr(gv), _ld(gv))
+        call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
+             ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
+    return S
+
+
 class EdgeConvFn(Function):
     """VNLinearLeakyReLU on the kNN edge tensor followed by mean_pool over the k neighbours, with the edge tensor never
     materialised (vnp_edge_fused): u, v = the layer's linear maps applied per point ([P*3, 2C'], columns feat | dir),
@@ -1470,56 +1547,72 @@ class EdgeConvFn(Function):
     def forward(ctx, u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
         u, v = _rows(u), _rows(v)
         nbr = nbr.contiguous()
-        Pq, k = nbr.shape
-        C = u.shape[1] // 2
-        dev = u.device
-        qb = _lib.lib().vnp_edge_block_queries()
-        nblk = (Pq + qb - 1) // qb
-        if training:
-            part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
-            call("vnp_edge_fused", 0, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
-                 ptr(part), None, 0, None, 0, None, 0, None, 0, 0, None, 0)
-            mean = torch.empty(C, device=dev, dtype=torch.float32)
-            rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
-                 ptr(running_var), BN_MOMENTUM, BN_EPS)
-        else:
-            mean = running_mean
-            rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
-        out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
-        call("vnp_edge_fused", 1, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
-             float(ns), None, ptr(out), C, None, 0, None, 0, None, 0, 0, None, 0)
+        out, mean, rstd, nblk = _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns)
         ctx.save_for_backward(u, v, nbr, gamma, beta, mean, rstd)
-        ctx.cfg = (Pq, k, C, bool(training), float(ns), nblk)
+        ctx.cfg = (bool(training), float(ns), nblk)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, go):
         u, v, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
-        Pq, k, C, training, ns, nblk = ctx.cfg
+        training, ns, nblk = ctx.cfg
         go = _rows(go)
-        dev = go.device
-        part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
-        call("vnp_edge_fused", 2, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-             ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0, 0, None, 0)
-        S = reduce_rows(part, 1, nblk, 2 * C).view(C, 2)
-        Pu = u.shape[0] // 3
-        gu = torch.empty((Pu * 3, 2 * C), device=dev, dtype=torch.float32)
-        gv = torch.empty((Pq * 3, 2 * C), device=dev, dtype=torch.float32)
-        sums = ptr(S) if training else None
-        if EDGE_GRAD_ATOMICS:
-            call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-                 None, None, 0, ptr(go), _ld(go), sums, Pq * k, ptr(gu), 2 * C, Pu, ptr(gv), 2 * C)
-        else:
-            # gv per query as before; gu per SOURCE point through the reverse adjacency (built once per graph: conv4 / conv5 share theirs)
-            start, rev = edge_reverse(nbr, Pu)
-            call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-                 None, None, 0, ptr(go), _ld(go), sums, Pq * k, None, 0, 0, ptr(gv), 2 * C)
-            call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
-                 ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), 2 * C)
+        C = u.shape[1] // 2
+        gu = torch.empty((u.shape[0], 2 * C), device=go.device, dtype=torch.float32)
+        gv = torch.empty((v.shape[0], 2 * C), device=go.device, dtype=torch.float32)
+        S = _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv)
         return gu, gv, None, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, None, None
+
+
+class EdgeConvPackedFn(Function):
+    """EdgeConvFn for a graph on ONE point set with u and v side by side in one matrix uv [P*3, 4C'] = x [Wu; Wv]^T (one GEMM instead
+    of two, forward and backward): u = uv[:, :2C'], v = uv[:, 2C':]; the gradient comes back as one [P*3, 4C'] matrix whose column halves
+    the backward kernels fill in place (no zero-padded slice gradients, no add)."""
+
+    @staticmethod
+    def forward(ctx, uv, nbr, gamma, beta, running_mean, running_var, training, ns):
+        uv = _rows(uv)
+        nbr = nbr.contiguous()
+        C2 = uv.shape[1] // 2
+        out, mean, rstd, nblk = _edge_conv_forward(uv[:, :C2], uv[:, C2:], nbr, gamma, beta, running_mean, running_var, training, ns)
+        ctx.save_for_backward(uv, nbr, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), float(ns), nblk)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        uv, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, ns, nblk = ctx.cfg
+        go = _rows(go)
+        C2 = uv.shape[1] // 2
+        guv = torch.empty_like(uv)
+        S = _edge_conv_backward(go, uv[:, :C2], uv[:, C2:], nbr, gamma, beta, mean, rstd, training, ns, nblk, guv[:, :C2], guv[:, C2:])
+        return guv, None, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, None, None
+
+
+class EdgeWeightsFn(Function):
+    """[Wu; Wv] [4C', C] of an EdgeConv layer from its VNLinearLeakyReLU weights Wf, Wd [C', 2C] (input channels: C of feature - x, then C
+    of x): W cat(f_j - x, x) = W1 f_j + (W2 - W1) x, so Wu = [Wf1; Wd1] acts on the neighbour and Wv = [Wf2 - Wf1; Wd2 - Wd1] on the centre.
+    One Function instead of eight autograd nodes of slices, subtractions and concatenations per layer and step."""
+
+    @staticmethod
+    def forward(ctx, Wf, Wd):
+        C = Wf.shape[1] // 2
+        W = torch.stack([Wf, Wd])                                # [2, C', 2C]
+        a, b = W[:, :, :C], W[:, :, C:]
+        ctx.C = C
+        return torch.cat([a.reshape(-1, C), (b - a).reshape(-1, C)], dim=0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        C = ctx.C
+        half = g.shape[0] // 2
+        gu, gv = g[:half], g[half:]
+        gW = torch.cat([(gu - gv).reshape(2, -1, C), gv.reshape(2, -1, C)], dim=2)      # [2, C', 2C]: d/dW1 = gu - gv, d/dW2 = gv
+        return gW[0], gW[1]
 
 
 # ------------------------------------------------------------------------------- transformer ops (configs 4, 5)
