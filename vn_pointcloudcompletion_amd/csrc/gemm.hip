@@ -301,7 +301,10 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     // vnp_vn_dir_layer) takes 128-row tiles on the aligned kernel instead of 192-row tiles on the bounds-checked one (120 -> 165 TFLOP/s)
     const bool rows128 = op_a == 0 && vnp_gemm_get_mode() == 0 && M % 192 != 0 && M % 128 == 0 && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a;
     // ... and the per-sample layers (M = 3 B = 96 rows: coarse head, decoder bias) 96-row tiles instead of half-empty 192-row ones
-    const bool rows96 = op_a == 0 && vnp_gemm_get_mode() == 0 && M == 96 && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a && !bias &&
+    // ... and so do activations of a few thousand rows whose 192-row tiles would leave most of the chip idle (VN-PoinTr's 12288-row
+    // blocks with N = 128: 64 tiles for 512 workgroup slots): twice the tiles
+    const bool few192 = M % 96 == 0 && (long long)vnp_cdiv(M, 192) * vnp_cdiv(N, 128) * (nsplit > 1 ? nsplit : 1) * nbatch < vnp_num_cus();
+    const bool rows96 = op_a == 0 && vnp_gemm_get_mode() == 0 && (M == 96 || few192) && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a && !bias &&
                         (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && nbatch == 1 &&
                         getenv("VNP_GEMM_NO_ROWS96") == nullptr;
     const int bm = rows96 ? 96 : (op_a == 0 && !rows128) ? 192 : 128;

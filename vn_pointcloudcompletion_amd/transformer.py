@@ -49,10 +49,10 @@ class Attention(nn.Module):
             raise NotImplementedError("dropout > 0 is not used on the PCNNet paths (rates are 0 in models/pcn.py:408-412)")
 
     def forward_rows(self, rows, B, N):
-        q = self.proj_vnq.forward_rows(rows)
-        k = self.proj_vnk.forward_rows(rows)
-        v = self.proj_vnv.forward_rows(rows)
-        x = ops.VNAttentionFn.apply(q, k, v, B, N, self.num_heads, self.scale)
+        # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result
+        Wqkv = torch.cat([self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight], dim=0)
+        qkv = ops.VNLinearFn.apply(rows, Wqkv, None, 0)
+        x = ops.VNAttentionPackedFn.apply(qkv, B, N, self.num_heads, self.scale)
         return self.proj_vn.forward_rows(x)
 
     def forward(self, vn_x):
