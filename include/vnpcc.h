@@ -23,6 +23,7 @@ extern "C" {
 
 #ifndef __HIP_PLATFORM_AMD__
 typedef struct ihipStream_t* hipStream_t;
+typedef struct ihipEvent_t* hipEvent_t;
 #endif
 
 #define VNP_OK 0
@@ -259,13 +260,13 @@ int vnp_edge_block_queries(void);
 int vnp_vn_bn_finalize_chunked(hipStream_t st, const float* partial, int nchunk, int chunk_points, int C, long long count,
                                float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps);
 int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
-    
+                   long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                   float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
+                   const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv);
 int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long long Pu, int* start, int* rev, int* ws);
 int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
                           long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                          float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu);               long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                   float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
-                   const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv);
+                          float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu);
 /* out[(p*k+j)*3+t][c] = u[nbr[p*k+j]*3+t][c] + v[p*3+t][c]: edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278)
  * with the layer's weights applied per point first (W [feat-x | x] = W1 feat + (W2-W1) x) */
 int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr,
