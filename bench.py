@@ -487,6 +487,13 @@ def main():
                     "frac": round(achieved / peak, 4),
                     "executed_bf16_PFLOPs": round(achieved * (SPLIT_PRODUCTS if gemm_mode == "split" else 1) / 1e3, 3),
                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
+                    # the same launches against the OTHER roof: the decoder's K = 256 / 512 products move 5.5-6.2 GB each for 0.41 TFLOP, 75 flop per
+                    # byte — the ridge point of (417 TF/s split-bf16, 5.5 TB/s deliverable) is 76 — so they are bound by both at once
+                    "hbm_view": ({"traffic_GBs": round(traffic / (tot_t / max(nlaunch, 1)) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                                  "frac": round(traffic / (tot_t / max(nlaunch, 1)) / 1e9 / PEAK_HBM_GBS, 4),
+                                  "flop_per_byte": round(tot_f / max(nlaunch, 1) / traffic, 1),
+                                  "ridge_flop_per_byte": round(peak * 1e12 / (PEAK_HBM_GBS * 1e9), 1),
+                                  "note": "PMC fabric bytes per launch (profiles/) / live average kernel time of this run"} if traffic else None),
                     "launches_per_step": nlaunch // max(args.steps, 1),
                     "flop_per_launch": tot_f / max(nlaunch, 1),
                     "avg_launch_ms": tot_t / max(nlaunch, 1) * 1e3,
