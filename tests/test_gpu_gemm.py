@@ -336,3 +336,49 @@ def test_split_k_weight_gradient_forms(lib_built, M, N, K, nsplit):
     out = torch.ones(M, N, device="cuda")
     ops.gemm(A, B, op_a=1, op_b=1, nsplit=nsplit, out=out, accumulate=True)
     assert relerr(out, ref + 1.0) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(192 * 300, 512, 256), (192 * 130, 768, 96), (192 * 515, 256, 512)])
+def test_wide_tile_kernel_is_the_narrow_kernel_bit_for_bit(lib_built, M, N, K):
+    """Big aligned NT products run on vnp_gemm_split_wide_kernel (192 x 256 tile, 512 threads); the same product taken 128 output columns at
+    a time runs on vnp_gemm_split_kernel<192, 128>.  Same LDS image, same six products in the same order per output element: the results
+    must be the same words — and the plain / bias / accumulate epilogues and the walk over more tiles than CUs are covered on the way."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 7, (M, 1), generator=g).float())).cuda()
+    B = torch.randn(N, K, generator=g).cuda()
+    assert (M // 192) * (N // 256) >= 256                       # the wide kernel's launch condition (gemm.hip: one tile per CU at least)
+    wide = ops.gemm(A, B)
+    narrow = torch.cat([ops.gemm(A, B[c:c + 128]) for c in range(0, N, 128)], dim=1)
+    assert torch.equal(wide, narrow)
+    assert relerr(wide, A.double() @ B.double().t()) < 2e-5
+    # per-sample VN bias (rows_per_group rows share three bias rows) and accumulation into an existing output
+    rpg = 192 * 5
+    assert M % rpg == 0
+    bias = torch.randn(3 * (M // rpg), N, generator=g).cuda()
+    wide_b = ops.gemm(A, B, bias=bias, rows_per_group=rpg)
+    narrow_b = torch.cat([ops.gemm(A, B[c:c + 128], bias=bias[:, c:c + 128].contiguous(), rows_per_group=rpg) for c in range(0, N, 128)], dim=1)
+    assert torch.equal(wide_b, narrow_b)
+    out = torch.ones(M, N, device="cuda")
+    ops.gemm(A, B, out=out, accumulate=True)
+    r = torch.arange(M, device="cuda")
+    assert relerr(out, A.double() @ B.double().t() + 1.0) < 2e-5
+    assert relerr(wide_b, A.double() @ B.double().t() + bias.double()[(r // rpg) * 3 + r % 3]) < 2e-5
+
+
+@pytest.mark.gpu
+def test_dgrad_nt_form_equals_the_nn_form(lib_built, _mode):
+    """ops._dgrad transposes the weight for big activations so that dX = gy W runs on the aligned NT kernels: same words as the NN form."""
+    from vn_pointcloudcompletion_amd import ops
+    if _mode != "split":
+        pytest.skip("the bit-for-bit statement is about the split kernels' common LDS image")
+    g = torch.Generator().manual_seed(77)
+    gy = torch.randn(192 * 300, 512, generator=g).cuda()
+    W = torch.randn(512, 256, generator=g).cuda()
+    assert gy.shape[0] >= ops.DGRAD_NT_ROWS
+    got = ops._dgrad(gy, W)
+    assert torch.equal(got, ops.gemm(gy, W, op_b=1))
+    assert relerr(got, gy.double() @ W.double()) < 2e-5
+    small = ops._dgrad(gy[:960], W)                            # below the threshold: the NN kernel itself (K split over slices there)
+    assert torch.equal(small, ops.gemm(gy[:960], W, op_b=1)) and relerr(small, got[:960]) < 2e-6

@@ -18,6 +18,7 @@
 // K order inside an MFMA pair is permuted identically for A and B (lane half h takes k = 8q+4h+s), so a lane's
 // four consecutive K values come from ONE 16-byte LDS read.
 #include "gemm_split_kernel.h"
+#include "gemm_split_wide_kernel.h"
 #include "screen_wide_kernel.h"
 
 // 0 = bf16x3 split (fp32-grade), 1 = fp32 MFMA.  The library's only process-wide setting: an atomic switch that every vnp_gemm*
@@ -76,6 +77,13 @@ static int vnp_num_cus()
 static bool vnp_no_xcd_split()
 {
     static const bool v = getenv("VNP_GEMM_NO_XCD_SPLIT") != nullptr;
+    return v;
+}
+
+// VNP_GEMM_NO_WIDE=1: big aligned NT products on the 256-thread 192 x 128 kernel as before (A/B measurement of vnp_gemm_split_wide_kernel)
+static bool vnp_no_wide()
+{
+    static const bool v = getenv("VNP_GEMM_NO_WIDE") != nullptr;
     return v;
 }
 
@@ -331,8 +339,14 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p);   \
         }                                                                                                               \
     } while (0)
+    // big aligned NT products (both operands K-contiguous, N % 256 == 0, at least one 192 x 256 tile per CU): the 512-thread kernel with the
+    // wide tile — the same arithmetic bit for bit, 0.7x the staging work per MFMA; measured +4-8 % (scripts/experiments/gemm_wide_bench.hip)
+    const long long items_w = (long long)(M / 192) * (N / 256) * nsplit * nbatch;
+    const bool wide = split && !h2 && fast && bm == 192 && op_a == 0 && op_b == 0 && N % 256 == 0 && items_w >= vnp_num_cus() && !vnp_no_wide();
     vnp_prof_begin(stream);
-    if (rows96) {
+    if (wide)
+        hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
+    else if (rows96) {
         if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, true, true>), grid, block, 0, stream, p);
         else           hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, false, true>), grid, block, 0, stream, p);
     }
@@ -909,8 +923,11 @@ extern "C" int vnp_gemm_vn_stats_ex(hipStream_t st, int M, int N, int K, const f
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
     if ((amax_a == nullptr) != (amax_b == nullptr)) return VNP_EINVAL;
     p.amax_a = amax_a; p.amax_b = amax_b;
+    const long long items_w = (long long)(M / 192) * (N / 256);
     vnp_prof_begin(st);
     if (amax_a && K >= 64) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2, 1>), grid, block, 0, st, p);
+    else if (N % 256 == 0 && items_w >= vnp_num_cus() && !vnp_no_wide())          // the wide tile, as in vnp_gemm_impl
+        hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<2>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
     vnp_prof_end(st, (amax_a && K >= 64) ? 5 : 0);
     hipLaunchKernelGGL(vnp_stats_merge32_kernel, dim3(vnp_cdiv(stats_cols, 64), M / 3072), dim3(256), 0, st,

@@ -411,6 +411,19 @@ def _wgrad(gy, x, fine=False):
     return gemm(gy, x, op_a=1, op_b=1, nsplit=nsplit)
 
 
+DGRAD_NT_ROWS = 49152           # activations of at least this many rows: see _dgrad
+
+
+def _dgrad(gy, W):
+    """dX [R, Cin] = gy [R, Cout] W [Cout, Cin].  For the big activations W is transposed first (a few hundred KB) so that both operands
+    are K-contiguous: the product then runs on the aligned NT kernels (the 192 x 256 tile of vnp_gemm_split_wide_kernel where Cin % 256
+    == 0) instead of the kernel that transposes W's tile in registers at every K-step — the same LDS image, the same products in the
+    same order, the same bits (tests/test_gpu_gemm.py), 3-10 % less time."""
+    if gy.shape[0] >= DGRAD_NT_ROWS and W.shape[1] % 128 == 0 and W.shape[0] % 32 == 0:
+        return gemm(gy, W.t().contiguous())
+    return gemm(gy, W, op_b=1)
+
+
 # ------------------------------------------------------------------------------- autograd Functions
 class SplitColsFn(Function):
     """W[:, 0:n0], W[:, n0:n0+n1], ... as views, with ONE concatenation as the backward: autograd's own slicing gives every slice a
@@ -539,7 +552,7 @@ class VNLinearFn(Function):
     def backward(ctx, gy):
         x, W = ctx.saved_tensors
         gy = _rows(gy)
-        gx = gemm(gy, W, op_b=1) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, W) if ctx.needs_input_grad[0] else None
         gW = _wgrad(gy, x) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -581,7 +594,7 @@ class VNLinearLeakyFn(Function):
                                  colsum_rows_per_group=rpg if want_gb else 0)
         gpd, ggamma, gbeta = out[:3]
         gb = out[3] if want_gb else None
-        gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None          # dX = [dP | dD] [Wf; Wd]
+        gx = _dgrad(gpd, Wcat) if ctx.needs_input_grad[0] else None          # dX = [dP | dD] [Wf; Wd]
         if gx is not None:
             gx._vnp_private = True               # a fresh buffer nobody else holds (see _grad_is_private)
         gWf = gWd = None
@@ -775,7 +788,7 @@ class VNDirLinearLeakyFn(Function):
         if want_gb:
             nb, cps = P // ppg, ppg // chunk
             gb = reduce_rows(cs_part.view(nb, cps, 6 * C), nb, cps, 6 * C).view(nb * 3, 2 * C)
-        gh = gemm(gv, Wcat, op_b=1) if ctx.needs_input_grad[0] else None
+        gh = _dgrad(gv, Wcat) if ctx.needs_input_grad[0] else None
         gWf = gWd = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             gW = _wgrad(gv, h, fine=folded)
@@ -824,7 +837,7 @@ class VNLinearLeakyOutFn(Function):
         g = g.contiguous()
         gpd, ggamma, gbeta, gw = _bn_leaky_backward(None, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, ns,
                                                     go_row=g, go_col=w, want_gw=True)
-        gx = gemm(gpd, Wcat, op_b=1) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gpd, Wcat) if ctx.needs_input_grad[0] else None
         gW = _wgrad(gpd, x)
         gcoarse = torch.empty(cshape, device=g.device, dtype=torch.float32)
         call("vnp_group_sum3", ptr(g), g.numel() // 3 // S, S, ptr(gcoarse), 0)
@@ -1038,7 +1051,7 @@ class VNLinearPoolTapFn(Function):
             else:
                 call("vnp_vn_pool_bwd_acc", ptr(gout), _ld(gout), ptr(idx), G, gs, C, ptr(gy), _ld(gy))
         gy = _rows(gy)
-        gx = gemm(gy, W, op_b=1) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, W) if ctx.needs_input_grad[0] else None
         gW = _wgrad(gy, x) if ctx.needs_input_grad[1] else None
         return gx, gW, None, None, None
 
