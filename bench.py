@@ -7,7 +7,7 @@ of vn_pointnet + vn_foldingnet on synthetic (B,2048,3) -> (B,16384,3) clouds, fp
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (the dominant kernel, vnp_gemm_split_kernel: EXECUTED
 work over KERNEL time — HIP events recorded by the library around each launch of that kernel on its launch stream, so the figure is
-Σflops / Σduration over the vnp_gemm_split_kernel rows of a rocprofv3 kernel trace of the same command, profiles/rNN_bench_kernel_stats.csv),
+Σflops / Σduration over the vnp_gemm_split_kernel / vnp_gemm_split_wide_kernel rows of a rocprofv3 kernel trace of the same command, profiles/rNN_bench_kernel_stats.csv),
 `roofline_other` (the arg-max pool's screening pass on the fp16 pipe it uses; Chamfer — the pruned search priced on the pairs it
 actually evaluates, counted by the kernel — and kNN on the fp32 VALU bound; the BatchNorm / leaky passes and the streaming kernels of
 the degenerate matrix shapes on the HBM bound), `chamfer_op` (the one shape the reference tree publishes a number for) and
@@ -464,17 +464,18 @@ def main():
             import glob
             summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")))[-1]
             tr = json.load(open(summ)).get("traffic", {})
-            kname = "vnp_gemm_split_kernel" if gemm_mode == "split" else "vnp_gemm_kernel"
-            num = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in tr.items() if kname in k)
-            den = sum(v["launches"] for k, v in tr.items() if kname in k)
+            knames = ("vnp_gemm_split_kernel", "vnp_gemm_split_wide_kernel") if gemm_mode == "split" else ("vnp_gemm_kernel",)
+            fam = [v for k, v in tr.items() if any(n in k for n in knames)]
+            num = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam)
+            den = sum(v["launches"] for v in fam)
             if den:
                 traffic, traffic_src = num / den, os.path.relpath(summ, ROOT)
         except Exception:
             pass
         alg_bytes = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in mfma) / max(nlaunch, 1)
         if gemm_mode == "split":
-            kernel = ("vnp_gemm_split_kernel<*> (fp32 operands split exactly into 3 bf16 terms; 6 x v_mfma_f32_16x16x32_bf16 "
-                      "per fp32 product block, fp32 accumulate)")
+            kernel = ("vnp_gemm_split_kernel<*> + vnp_gemm_split_wide_kernel<*> (one arithmetic, two tile shapes: fp32 operands split exactly "
+                      "into 3 bf16 terms; 6 x v_mfma_f32_16x16x32_bf16 per fp32 product block, fp32 accumulate)")
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         else:
             kernel, peak = "vnp_gemm_kernel<*> (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
@@ -500,7 +501,7 @@ def main():
                     "ms_per_step": tot_t / args.steps * 1e3,
                     "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (vnp_gemm_profile_next): "
                               "kernel time only — no slab reduction, no launch gap; reproduce as sum(2MNK) / sum(duration) over the "
-                              "vnp_gemm_split_kernel rows of profiles/rNN_bench_kernel_stats.csv",
+                              "vnp_gemm_split_kernel and vnp_gemm_split_wide_kernel rows of profiles/rNN_bench_kernel_stats.csv",
                     "note": ("achieved = EXECUTED fp32-equivalent flops (2MNK of the launches of this kernel; each is six bf16 MFMA products) / "
                              "kernel time.  Not in it: the arg-max pool's screening pass (own kernel, one fp16 product: roofline_other), the "
                              "streaming kernels of the degenerate shapes (roofline_other), slab reductions.  "

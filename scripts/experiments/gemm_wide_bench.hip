@@ -44,6 +44,12 @@ void run_case(const char* name, int M, int N, int K, int nsplit, int cg, const f
         printf("  r%d 192x128 / 256 threads   %8.3f ms %7.1f TF-equiv\n", round, t, fl / t * 1e-9);
         t = time_it([&] { hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<EPI>), g2, dim3(512), 0, 0, p2); }, 10);
         printf("  r%d 192x256 / 512 threads   %8.3f ms %7.1f TF-equiv\n", round, t, fl / t * 1e-9);
+        if (round == 1) {
+            t = time_it([&] { hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<EPI, 16>), g2, dim3(512), 0, 0, p2); }, 10);
+            printf("     192x256 without the output stores %8.3f ms\n", t);
+            t = time_it([&] { hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 16, EPI>), g1, dim3(256), 0, 0, p1); }, 10);
+            printf("     192x128 without the output stores %8.3f ms\n", t);
+        }
     }
     std::vector<float> h1(outn), h2(outn);
     CK(hipMemcpy(h1.data(), C1, outn * 4, hipMemcpyDeviceToHost));

@@ -8,6 +8,7 @@ set -e
 tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/$tag
+rm -rf $out          # gpurun merges into gpurun_out/: an earlier pass of the same tag would be summarised along with this one
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="$root/bench.py --no-cpu-baseline --no-fp32-mode --no-extras"
