@@ -47,6 +47,13 @@ int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, cons
 long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m);
 int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                            float* dist1, int* idx1, float* dist2, int* idx2, void* ws);
+/* One side of the density-aware Chamfer distance, calc_dcd (/root/reference/metrics/loss.py:77-118; the reference loops over the batch
+ * with torch.bincount): hits [B, T] = histogram of the arg-min indices idx [B, N] (scratch, zeroed by the call; integer atomics, so the
+ * result does not depend on their order), loss [B] = mean_i (1 - exp(-alpha dist_i) * frac / (hits[idx_i]^lambda + 1e-6)) in the
+ * reference's fp32 operation order (the sum over i in double, fixed order), gfac [B, N] = d loss / d dist_i with the weight held
+ * constant (the reference detaches it), or NULL. */
+int vnp_dcd_side(hipStream_t st, int B, int N, int T, const float* dist, const int* idx, float alpha, float lambda, float frac,
+                 int* hits, float* loss, float* gfac);
 
 /* ---- Earth Mover's Distance ---------------------------------------------------------------------------------------
  * replaces emd_cuda.approxmatch_forward / matchcost_forward / matchcost_backward

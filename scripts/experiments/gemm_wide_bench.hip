@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 
+static bool g_pmc = false;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -36,6 +37,15 @@ void run_case(const char* name, int M, int N, int K, int nsplit, int cg, const f
     dim3 g1(items1 < 512 ? items1 : 512), g2(items2 < 256 ? items2 : 256);
     const double fl = 2.0 * M * N * K;
     VnpGemmArgs p1 = p, p2 = p; p1.C = C1; p2.C = C2;
+    if (EPI == 2) { p1.stats_part = (float2*)S1; p2.stats_part = (float2*)S2; p1.stats_cols = p2.stats_cols = N / 2; }
+    if (g_pmc) {          // counter runs (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE): each kernel twice, nothing else
+        for (int i = 0; i < 2; ++i) {
+            hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, EPI>), g1, dim3(256), 0, 0, p1);
+            hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<EPI>), g2, dim3(512), 0, 0, p2);
+        }
+        CK(hipDeviceSynchronize());
+        return;
+    }
     const size_t outn = (size_t)M * N * nsplit;
     CK(hipMemset(C1, 0xff, outn * 4)); CK(hipMemset(C2, 0x7f, outn * 4));
     printf("%-16s NT M=%d N=%d K=%d split=%d EPI=%d\n", name, M, N, K, nsplit, EPI);
@@ -59,13 +69,14 @@ void run_case(const char* name, int M, int N, int K, int nsplit, int cg, const f
     printf("  outputs: %zu of %zu words differ%s\n", diff, outn, diff ? "   <-- MISMATCH" : " (bit-identical)");
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    g_pmc = argc > 1 && !strcmp(argv[1], "pmc");
     const size_t maxA = (size_t)1572864 * 512, maxC = (size_t)1572864 * 512;
     float *A, *B, *C1, *C2, *S1, *S2;
     CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&B, maxA * 4)); CK(hipMalloc(&C1, maxC * 4)); CK(hipMalloc(&C2, maxC * 4));
-    CK(hipMalloc(&S1, 1 << 24)); CK(hipMalloc(&S2, 1 << 24));
-    CK(hipMemset(S1, 0, 1 << 24)); CK(hipMemset(S2, 0, 1 << 24));
+    CK(hipMalloc(&S1, 1 << 26)); CK(hipMalloc(&S2, 1 << 26));          // EPI = 2: [M / 96][stats_cols] float2 partials
+    CK(hipMemset(S1, 0, 1 << 26)); CK(hipMemset(S2, 0, 1 << 26));
     std::vector<float> hA(maxA);
     srand(1);
     auto rnd = [] { float u = (float)(rand() & 0xffffff) / 8388608.f - 1.f; int e = rand() % 13 - 6; return ldexpf(u, e); };
@@ -74,6 +85,8 @@ int main()
     for (auto& v : hA) v = rnd();
     CK(hipMemcpy(B, hA.data(), maxA * 4, hipMemcpyHostToDevice));
     run_case<0>("dec 256->512", 1572864, 512, 256, 1, 8, A, B, C1, C2, S1, S2);
+    run_case<2>("dec 256->512 + BatchNorm statistics", 1572864, 512, 256, 1, 8, A, B, C1, C2, S1, S2);
+    if (g_pmc) return 0;
     run_case<0>("dec dgrad as NT", 1572864, 256, 512, 1, 8, A, B, C1, C2, S1, S2);
     run_case<0>("enc 1024->2048", 196608, 2048, 1024, 1, 8, A, B, C1, C2, S1, S2);
     run_case<0>("enc 1024->2048 cg4", 196608, 2048, 1024, 1, 4, A, B, C1, C2, S1, S2);

@@ -151,6 +151,33 @@ def test_dcd_and_fscore_match_reference_golden(lib_built, tag):
     assert np.abs(f1.cpu().numpy() - G[f"f1_{tag}"]).max() <= 1.0 / 128 + 1e-7     # threshold 1e-4 sits on distance noise: one point may flip
 
 
+@pytest.mark.parametrize("B,N,T,lam", [(3, 1000, 37, 0.5), (2, 16384, 16384, 1.0), (1, 5, 3, 0.5), (4, 2049, 700, 2.0)])
+def test_dcd_side_histogram_and_mean(lib_built, B, N, T, lam):
+    """vnp_dcd_side through the C ABI: the histogram of the arg-min indices equals torch.bincount per sample (exact: integer atomics),
+    loss and d loss / d dist equal the reference's formula (metrics/loss.py:99-113) evaluated in torch fp32 / fp64; ragged sizes, heavy
+    collisions (T << N) and targets nobody hits."""
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(B * 1000 + N + T)
+    dist = (torch.rand(B, N, generator=g) * 0.02).cuda()
+    idx = torch.randint(0, max(1, T - 1), (B, N), generator=g, dtype=torch.int32).cuda()          # target T - 1 is never hit
+    hits = torch.full((B, T), -7, device="cuda", dtype=torch.int32)                               # scratch need not be zeroed
+    loss = torch.empty(B, device="cuda")
+    gfac = torch.empty(B, N, device="cuda")
+    alpha, frac = 200.0, T / N
+    call("vnp_dcd_side", B, N, T, ptr(dist), ptr(idx), alpha, lam, frac, ptr(hits), ptr(loss), ptr(gfac))
+    ref_hits = torch.stack([torch.bincount(idx[b].long(), minlength=T) for b in range(B)])
+    assert torch.equal(hits.long(), ref_hits)
+    d64 = dist.double().requires_grad_(True)
+    w = (ref_hits.gather(1, idx.long()).float() ** lam + 1e-6) ** (-1) * frac
+    ref = (1.0 - torch.exp(-alpha * d64) * w.double()).mean(dim=1)
+    assert (loss.double() - ref).abs().max().item() < 2e-6
+    ref.sum().backward()
+    assert (gfac.double() - d64.grad).abs().max().item() < 2e-6 * max(1.0, d64.grad.abs().max().item())
+    loss2 = torch.empty(B, device="cuda")
+    call("vnp_dcd_side", B, N, T, ptr(dist), ptr(idx), alpha, lam, frac, ptr(hits), ptr(loss2), None)   # no gradient wanted
+    assert torch.equal(loss, loss2)                                                                # and deterministic
+
+
 # ------------------------------------------------------------------------------------------- pruned search (dense clouds)
 def _both_paths(a, b):
     """(brute-force kernel outputs, pruned kernel outputs) through the C ABI, same inputs."""

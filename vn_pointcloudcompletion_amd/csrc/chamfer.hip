@@ -548,3 +548,58 @@ extern "C" int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, 
     hipLaunchKernelGGL(vnp_chamfer_grad_kernel<false>, dim3(vnp_cdiv(m, 256), B), dim3(256), 0, st, m, xyz2, n, xyz1, grad_dist2, idx2, grad_xyz2, grad_xyz1);
     return vnp_last_error();
 }
+
+// ---- density-aware Chamfer term (the reference's calc_dcd, metrics/loss.py:77-118: per sample a bincount of the arg-min indices,
+// then mean over the queries of 1 - exp(-alpha d) * frac / (count[idx]^lambda + 1e-6)) -------------------------------------------------
+// hits[b][t] = number of queries of sample b whose nearest target is t.  Integer atomics: the result does not depend on their order.
+__global__ void __launch_bounds__(256) vnp_dcd_hist_kernel(const int* __restrict__ idx, int N, int T, int* __restrict__ hits)
+{
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int t = idx[(size_t)b * N + i];
+    if (t >= 0 && t < T) atomicAdd(&hits[(size_t)b * T + t], 1);
+}
+
+// One workgroup per sample: loss[b] = mean_i (1 - exp(-alpha d_i) w_i), w_i = frac / (hits[idx_i]^lambda + 1e-6) (fp32, the reference's
+// operation order); gfac[b][i] = d loss[b] / d d_i = alpha exp(-alpha d_i) w_i / N (the weight is a constant of the graph: .detach()).
+// The per-sample sum is taken in double, per thread in index order and across the workgroup in a fixed tree: deterministic.
+__global__ void __launch_bounds__(1024) vnp_dcd_side_kernel(const float* __restrict__ dist, const int* __restrict__ idx, const int* __restrict__ hits,
+                                                            int N, int T, float alpha, float lambda, float frac,
+                                                            float* __restrict__ loss, float* __restrict__ gfac)
+{
+    __shared__ double red[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* d = dist + (size_t)b * N;
+    const int* ix = idx + (size_t)b * N;
+    const int* h = hits + (size_t)b * T;
+    const float inv_n = 1.f / (float)N;
+    double acc = 0.0;
+    for (int i = tid; i < N; i += 1024) {
+        const int t = ix[i];
+        const float cnt = (t >= 0 && t < T) ? (float)h[t] : 0.f;
+        const float w = 1.f / (powf(cnt, lambda) + 1e-6f) * frac;
+        const float e = expf(-alpha * d[i]);
+        acc += (double)(1.f - e * w);
+        if (gfac) gfac[(size_t)b * N + i] = alpha * e * w * inv_n;
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) loss[b] = (float)(red[0] / (double)N);
+}
+
+// One side of calc_dcd.  dist / idx [B, N]: one-sided squared distances and arg-min indices (into T targets) from vnp_chamfer_fwd;
+// hits [B, T] ints: scratch, zeroed here; loss [B]; gfac [B, N] or NULL (no gradient wanted).
+extern "C" int vnp_dcd_side(hipStream_t st, int B, int N, int T, const float* dist, const int* idx, float alpha, float lambda, float frac,
+                            int* hits, float* loss, float* gfac)
+{
+    if (B <= 0 || N <= 0 || T <= 0 || !dist || !idx || !hits || !loss || B > 65535) return VNP_EINVAL;
+    hipError_t e = hipMemsetAsync(hits, 0, (size_t)B * T * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vnp_dcd_hist_kernel, dim3(vnp_cdiv(N, 256), B), dim3(256), 0, st, idx, N, T, hits);
+    hipLaunchKernelGGL(vnp_dcd_side_kernel, dim3(B), dim3(1024), 0, st, dist, idx, (const int*)hits, N, T, alpha, lambda, frac, loss, gfac);
+    return vnp_last_error();
+}

@@ -398,19 +398,26 @@ __device__ __forceinline__ void vnp_split_epilogue(const VnpGemmArgs& p, vnp_f4 
                 }
                 float* d0 = Cz + (size_t)(m0 + lr) * p.ldc;
                 ++wn_cnt;
+                float xs[3][TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = n0 + wn * (TN * 16) + j * 16 + l16;
                     float x0 = acc[3 * i3][j][e], x1 = acc[3 * i3 + 1][j][e], x2 = acc[3 * i3 + 2][j][e];
                     if (has_bias) { x0 += b0[col]; x1 += b1[col]; x2 += b2[col]; }
-                    __builtin_nontemporal_store(x0, d0 + col);
-                    __builtin_nontemporal_store(x1, d0 + p.ldc + col);
-                    __builtin_nontemporal_store(x2, d0 + 2 * p.ldc + col);
+                    xs[0][j] = x0; xs[1][j] = x1; xs[2][j] = x2;
                     const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2) + VNP_EPS;
                     const float delta = nrm - wmean[j];
                     wmean[j] += delta / (float)wn_cnt;
                     wm2[j] += delta * (nrm - wmean[j]);
                 }
+                // stores row by row, the TN segments of a row back to back (as the plain epilogue does): with the three rows of a point
+                // interleaved per segment the two halves of a 128-byte line arrived three stores apart, and the launch wrote 1.23x its
+                // output through the fabric (profiles/r03_bench_summary.json: 3.97 GB for 3.22)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        __builtin_nontemporal_store(xs[t][j], d0 + t * p.ldc + n0 + wn * (TN * 16) + j * 16 + l16);
             }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {

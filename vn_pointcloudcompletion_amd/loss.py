@@ -45,14 +45,34 @@ def calc_cd(output, gt, calc_f1=False, return_raw=False, normalize=False, separa
     return res
 
 
+class _DensitySideFn(torch.autograd.Function):
+    """One direction of the density-aware term on the device (vnp_dcd_side): histogram of the arg-min indices, the weighted
+    exponential and its per-sample mean in one call; the gradient reaches ``dist`` only (the weight is detached in the reference)."""
+
+    @staticmethod
+    def forward(ctx, dist, idx, n_targets, alpha, n_lambda, frac):
+        from .ops import call, ptr
+        dist = dist.contiguous()
+        idx = idx.to(torch.int32).contiguous()
+        B, N = dist.shape
+        hits = torch.empty((B, n_targets), device=dist.device, dtype=torch.int32)
+        loss = torch.empty((B,), device=dist.device, dtype=torch.float32)
+        gfac = torch.empty_like(dist) if ctx.needs_input_grad[0] else None
+        call("vnp_dcd_side", B, N, n_targets, ptr(dist), ptr(idx), float(alpha), float(n_lambda), float(frac), ptr(hits), ptr(loss), ptr(gfac))
+        if gfac is not None:
+            ctx.save_for_backward(gfac)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (gfac,) = ctx.saved_tensors
+        return gloss.unsqueeze(1) * gfac, None, None, None, None, None
+
+
 def _density_side(dist, idx, n_targets, alpha, n_lambda, frac):
     """One direction of the density-aware term: every query is weighted by 1 / (number of queries that share its nearest
     neighbour)^lambda (a batched histogram of the arg-min indices; the reference loops over the batch with bincount)."""
-    idx = idx.long()
-    hits = torch.zeros((dist.shape[0], n_targets), device=dist.device, dtype=torch.float32)
-    hits.scatter_add_(1, idx, torch.ones_like(dist, dtype=torch.float32))
-    weight = (hits.gather(1, idx).detach() ** n_lambda + 1e-6) ** (-1) * frac
-    return (1.0 - torch.exp(-alpha * dist) * weight).mean(dim=1)
+    return _DensitySideFn.apply(dist.float(), idx, n_targets, alpha, n_lambda, frac)
 
 
 def calc_dcd(x, gt, alpha=1000, n_lambda=1, return_raw=False, non_reg=False):
