@@ -211,3 +211,21 @@ def test_softmax_rows_forward_backward(lib_built, L):
     dS = dP.clone()
     call("vnp_softmax_bwd", ptr(P), ptr(dS), R, L, scale)
     assert (dS.double() - Sd.grad).abs().max().item() < 5e-7 * max(1.0, Sd.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 37, 384, 8), (1, 5, 12, 4), (3, 64, 96, 2), (1, 3, 2304, 8)])
+def test_head_permutes_are_the_index_permutation(lib_built, B, N, C, H):
+    """vnp_rows_to_heads / vnp_heads_to_rows (LDS-staged transposes): heads[(b, h)][n][cl * 3 + t] == rows[(b, n, t)][h * ch + cl] exactly,
+    for token counts that do not fill the last workgroup, one to eight tokens per workgroup, and row strides wider than C on either side."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(B + N + C + H)
+    wide = torch.randn(B * N * 3, C + 8, generator=g).cuda()
+    rows = wide[:, 4:4 + C]                                      # a column slice: row stride C + 8
+    ch = C // H
+    want = rows.view(B, N, 3, H, ch).permute(0, 3, 1, 4, 2).reshape(B * H, N, ch * 3)
+    heads = ops._to_heads(rows, B, N, H)
+    assert torch.equal(heads, want)
+    back = torch.full((B * N * 3, C + 8), 7.0, device="cuda")
+    ops._from_heads(heads, B, N, C, H, out=back[:, 2:2 + C])
+    assert torch.equal(back[:, 2:2 + C], rows)
+    assert (back[:, :2] == 7.0).all() and (back[:, 2 + C:] == 7.0).all()          # nothing written outside the view

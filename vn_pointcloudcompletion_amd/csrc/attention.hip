@@ -88,31 +88,51 @@ __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict
 }
 
 // heads[((b*H + h)*N + n)*Dh + cl*3 + t] = rows[((b*N + n)*3 + t)*ld + h*(C/H) + cl],  Dh = (C/H)*3
-__global__ void vnp_rows_to_heads_kernel(const float* __restrict__ rows, int ld, int B, int N, int C, int H, float* __restrict__ heads)
+// rows [(b, n, t)][C] <-> heads [(b, h)][n][cl * 3 + t] (C = H ch): for one token (b, n) the three rows hold [t][h][cl] and the H head
+// slices hold [h][cl][t] — a transpose of the two inner index pairs inside 3 C contiguous floats per side.  A workgroup stages PN tokens
+// in LDS: every global read is a contiguous run of C floats (a row) and every global write a contiguous run of 3 ch floats (a head
+// slice), or the converse; the permuted LDS accesses have a stride of 3 or ch words.  (Rounds 1-2 did the permutation in the global
+// address of one side: every 128-byte line of that side was touched by three waves at three times, and the counters showed 3x its bytes
+// through the fabric — profiles/r03_cfg5_summary.json: 57 MB written for 19 MB read.)
+template <bool TO_HEADS>
+__global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H, int PN)
 {
-    const int ch = C / H, Dh = ch * 3;
-    const long long total = (long long)B * N * 3 * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C); long long k = i / C;
-        const int t = (int)(k % 3); k /= 3;
-        const int n = (int)(k % N); const int b = (int)(k / N);
-        const int h = c / ch, cl = c % ch;
-        heads[(((size_t)b * H + h) * N + n) * Dh + cl * 3 + t] = rows[(((size_t)b * N + n) * 3 + t) * ld + c];
-    }
+    extern __shared__ float tile[];                  // [PN][3][C] in the rows' order
+    const int ch = C / H, Dh = ch * 3, per = 3 * C;
+    const long long tok0 = (long long)blockIdx.x * PN, ntok = (long long)B * N;
+    const int cnt = (int)(ntok - tok0 < PN ? ntok - tok0 : PN);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // a wave walks whole rows / whole head slices, its lanes the contiguous floats inside: the only divisions by run-time values are
+    // per slice, not per element (with one flat index per element the kernel was bound by integer division, not by memory)
+    auto rows_side = [&](bool load) {
+        for (int pt = wave; pt < cnt * 3; pt += 4) {                  // row pt = 3 p + t of the workgroup's tokens: C contiguous floats
+            const size_t g = ((size_t)tok0 * 3 + pt) * ld;
+            for (int c = lane; c < C; c += 64) {
+                if (load) tile[pt * C + c] = src[g + c];
+                else dst[g + c] = tile[pt * C + c];
+            }
+        }
+    };
+    auto heads_side = [&](bool load) {
+        for (int ph = wave; ph < cnt * H; ph += 4) {                  // head slice (p, h): 3 ch contiguous floats, [cl][t]
+            const int p = ph / H, h = ph - p * H;
+            const long long tok = tok0 + p;
+            const int b = (int)(tok / N), n = (int)(tok - (long long)b * N);
+            const size_t g = (((size_t)b * H + h) * N + n) * Dh;
+            const int base = p * per + h * ch;
+            for (int r = lane; r < Dh; r += 64) {
+                const int cl = r / 3, t = r - cl * 3;
+                if (load) tile[base + t * C + cl] = src[g + r];
+                else dst[g + r] = tile[base + t * C + cl];
+            }
+        }
+    };
+    if (TO_HEADS) { rows_side(true); __syncthreads(); heads_side(false); }
+    else          { heads_side(true); __syncthreads(); rows_side(false); }
 }
 
-__global__ void vnp_heads_to_rows_kernel(const float* __restrict__ heads, int B, int N, int C, int H, float* __restrict__ rows, int ld)
-{
-    const int ch = C / H, Dh = ch * 3;
-    const long long total = (long long)B * N * 3 * C;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C); long long k = i / C;
-        const int t = (int)(k % 3); k /= 3;
-        const int n = (int)(k % N); const int b = (int)(k / N);
-        const int h = c / ch, cl = c % ch;
-        rows[(((size_t)b * N + n) * 3 + t) * ld + c] = heads[(((size_t)b * H + h) * N + n) * Dh + cl * 3 + t];
-    }
-}
+// tokens per workgroup: ~24 KB of LDS, at least one token, at most eight
+static inline int vnp_head_permute_pn(int C) { const int pn = 6144 / (3 * C); return pn < 1 ? 1 : pn > 8 ? 8 : pn; }
 
 // rows of up to 2048 elements (L % 64 == 0) stay in registers between the passes: one read and one write of the matrix instead of three
 // reads and two writes; same element-to-lane assignment and summation order as the streaming form below
@@ -205,19 +225,23 @@ extern "C" int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, c
 
 extern "C" int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads)
 {
-    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H) return VNP_EINVAL;
-    const long long total = (long long)B * N * 3 * C;
-    hipLaunchKernelGGL(vnp_rows_to_heads_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
-                       rows, ld, B, N, C, H, heads);
+    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H || ld < C || C > 5000) return VNP_EINVAL;          // one token (3 C floats) must fit 64 KB of LDS
+    const int pn = vnp_head_permute_pn(C);
+    const long long blocks = ((long long)B * N + pn - 1) / pn;
+    if (blocks > 2147483647LL) return VNP_EINVAL;
+    hipLaunchKernelGGL((vnp_head_permute_kernel<true>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * C * sizeof(float), st,
+                       rows, heads, ld, B, N, C, H, pn);
     return vnp_last_error();
 }
 
 extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int N, int C, int H, float* rows, int ld)
 {
-    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H) return VNP_EINVAL;
-    const long long total = (long long)B * N * 3 * C;
-    hipLaunchKernelGGL(vnp_heads_to_rows_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
-                       heads, B, N, C, H, rows, ld);
+    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H || ld < C || C > 5000) return VNP_EINVAL;          // one token (3 C floats) must fit 64 KB of LDS
+    const int pn = vnp_head_permute_pn(C);
+    const long long blocks = ((long long)B * N + pn - 1) / pn;
+    if (blocks > 2147483647LL) return VNP_EINVAL;
+    hipLaunchKernelGGL((vnp_head_permute_kernel<false>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * C * sizeof(float), st,
+                       heads, rows, ld, B, N, C, H, pn);
     return vnp_last_error();
 }
 
