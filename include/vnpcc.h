@@ -177,6 +177,9 @@ int vnp_vn_bn_bwd2(hipStream_t st, float* g, int ldg, const float* p, int ldp, l
 /* out[b][j] = sum_{i<n} in[b*batch_stride + i*stride + j], j < W (double accumulation) */
 int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long long batch_stride, int n, long long stride, int W,
                     float* out, long long out_stride);
+/* Sum over n partials of interleaved pairs: in [n][C][2] -> S [C][2] (read by the BatchNorm backward kernels) and planar [2][C]
+ * (the two per-channel parameter gradients dL/dbeta, dL/dgamma as contiguous rows). */
+int vnp_reduce_pairs(hipStream_t st, const float* in, int n, int C, float* S, float* planar);
 
 /* ---- pooling ----------------------------------------------------------------------------------------------
  * VNMaxPool (models/vn_layers.py:153-167) over groups of gs consecutive points; idx [G][C] = local arg-max (first max).
@@ -351,6 +354,10 @@ int vnp_ref_to_rows(hipStream_t st, const float* ref, int B, int C, int N, float
 /* ---- optimizer: fused Adam over flat buffers (train.py:70, torch.optim.Adam semantics) ----------------------- */
 int vnp_adam_step(hipStream_t st, float* p, const float* g, float* m, float* v, long long n,
                   float lr, float beta1, float beta2, float eps, int step, float weight_decay);
+/* Gather of per-parameter gradient tensors into the flat gradient buffer (optim.FlatBuffers.gather): dst[dst_off[i] .. + numel[i]) =
+ * src[i][0 .. numel[i]) for i < count, zeros where src[i] == NULL.  src / dst_off / numel are HOST arrays (the table travels in kernel
+ * arguments, 48 entries per launch); sources and slices need no particular alignment (16-byte aligned pairs move as float4). */
+int vnp_pack_tensors(hipStream_t st, int count, const void* const* src, const long long* dst_off, const long long* numel, float* dst);
 
 #ifdef __cplusplus
 }

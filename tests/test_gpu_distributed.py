@@ -132,6 +132,7 @@ def test_two_ranks_overlapped_allreduce_matches_manual_average(lib_built):
         coarse, fine = model(p[2 * r:2 * r + 2].cuda())
         loss, _, _ = compute_losses(cfg, coarse, fine, c[2 * r:2 * r + 2].cuda())
         loss.backward()
+        fb.check_views()                                                 # gathered gradients: bring them to the flat buffer first
         acc += fb.flat_grad / world
     ref = acc.cpu()
     scale = ref.abs().max().item()

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "vnp_vn_bn_leaky_rowdot_fwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp],
     "vnp_vn_bn_bwd2": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _vp, _ll],
     "vnp_reduce_rows": [_vp, _i, _ll, _i, _ll, _i, _vp, _ll],
+    "vnp_reduce_pairs": [_vp, _i, _i, _vp, _vp],
     "vnp_linear_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _i, _vp],
     "vnp_linear_pool_store_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp],
     "vnp_linear_pool_screened_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _i, _vp, _i],
@@ -127,6 +128,7 @@ _SIGNATURES = {
     "vnp_rows_to_ref": [_vp, _i, _i, _i, _i, _vp],
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
+    "vnp_pack_tensors": [_i, _vp, _vp, _vp, _vp],
 }
 _NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i, _i],

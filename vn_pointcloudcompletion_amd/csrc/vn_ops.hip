@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
 // dependent loads is n / 32 long
 #define VNP_RR_LANES 16
 __global__ void __launch_bounds__(64 * VNP_RR_LANES) vnp_reduce_rows_kernel(const float* __restrict__ in, long long batch_stride, int n, long long stride, int W,
-                                                             float* __restrict__ out, long long out_stride)
+                                                             float* __restrict__ out, long long out_stride, float* __restrict__ planar = nullptr)
 {
     __shared__ double red[VNP_RR_LANES][64];
     const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
@@ -422,6 +422,7 @@ __global__ void __launch_bounds__(64 * VNP_RR_LANES) vnp_reduce_rows_kernel(cons
 #pragma unroll
         for (int q = 0; q < VNP_RR_LANES; ++q) t += red[q][cx];
         out[(size_t)blockIdx.y * out_stride + j] = (float)t;
+        if (planar) planar[(size_t)(j & 1) * (W >> 1) + (j >> 1)] = (float)t;        // vnp_reduce_pairs: the same sums as [2][W / 2]
     }
 }
 
@@ -1458,6 +1459,17 @@ extern "C" int vnp_reduce_rows(hipStream_t st, const float* in, int nb, long lon
 {
     if (!in || !out || nb <= 0 || n <= 0 || W <= 0) return VNP_EINVAL;
     hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(W, 64), nb), dim3(64 * VNP_RR_LANES), 0, st, in, batch_stride, n, stride, W, out, out_stride);
+    return vnp_last_error();
+}
+
+// Sum of n partials of interleaved pairs, in [n][C][2] -> S [C][2] (what the BatchNorm backward kernels read) AND planar [2][C]
+// (planar[0] = the first member of every pair, planar[1] = the second: the two parameter gradients as contiguous rows, so that no
+// strided copy follows the reduction).
+extern "C" int vnp_reduce_pairs(hipStream_t st, const float* in, int n, int C, float* S, float* planar)
+{
+    if (!in || !S || !planar || n <= 0 || C <= 0) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_reduce_rows_kernel, dim3(vnp_cdiv(2 * C, 64), 1), dim3(64 * VNP_RR_LANES), 0, st, in, 0LL, n, (long long)2 * C, 2 * C,
+                       S, 0LL, planar);
     return vnp_last_error();
 }
 

@@ -272,7 +272,9 @@ class OverlappedGradReducer:
             self._launch(self.launched)
 
     def _launch(self, b):
-        _, _, lo, hi = self.buckets[b]
+        lo_i, hi_i, lo, hi = self.buckets[b]
+        if getattr(self.fb, "gathered", False):
+            self.fb.gather(range(lo_i, hi_i))            # the bucket's gradient tensors -> their slices: one launch, then the collective
         flat = self.fb.flat_grad[lo:hi]
         if self.transport is not None:
             self.works.append((self.transport(flat), None))
@@ -294,9 +296,10 @@ class OverlappedGradReducer:
                 self.late = True                             # a second accumulation after the bucket went on the wire
             return
         self.fired.add(id(p))
-        if p.grad is not None and p.grad.data_ptr() != self.fb.flat_grad.data_ptr() + self.fb.offsets[self._index(p)] * 4:
+        if (not getattr(self.fb, "gathered", False) and p.grad is not None
+                and p.grad.data_ptr() != self.fb.flat_grad.data_ptr() + self.fb.offsets[self._index(p)] * 4):
             self.fb.view(self.fb.flat_grad, self._index(p)).copy_(p.grad)        # autograd replaced the view: re-home it
-            p.grad = self.fb.view(self.fb.flat_grad, self._index(p))
+            p.grad = self.fb.view(self.fb.flat_grad, self._index(p))             # (gathered buffers: _launch brings the whole bucket home)
         if b < self.launched:
             self.late = True                                 # its bucket is already on the wire
             return

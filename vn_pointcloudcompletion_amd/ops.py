@@ -228,6 +228,23 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
     return out
 
 
+def reduce_pairs(part, n, C):
+    """part: contiguous [n][C][2] partial (sum1, sum2) pairs -> (S [C, 2], planar [2, C]): the same sums in the interleaved layout the
+    BatchNorm backward kernels read and as two contiguous rows (the per-channel parameter gradients), one launch (vnp_reduce_pairs)."""
+    dev = part.device
+    if n > 1024:
+        m = next((d for d in range(512, 15, -1) if n % d == 0), 0)
+        if m:
+            n1 = n // m
+            tmp = torch.empty((n1, 2 * C), device=dev, dtype=torch.float32)
+            call("vnp_reduce_rows", ptr(part), n1, m * 2 * C, m, 2 * C, 2 * C, ptr(tmp), 2 * C)
+            part, n = tmp, n1
+    S = torch.empty((C, 2), device=dev, dtype=torch.float32)
+    planar = torch.empty((2, C), device=dev, dtype=torch.float32)
+    call("vnp_reduce_pairs", ptr(part), n, C, ptr(S), ptr(planar))
+    return S, planar
+
+
 def reduce_rows(part, nb, n, W):
     """part: contiguous [nb][n][W] partials -> [nb][W] (sum over n; two passes when n is large so that no thread
     walks more than a few hundred partials)."""
@@ -365,21 +382,19 @@ def _bn_leaky_backward(go, p, d, C, gamma, beta, mean, rstd, training, ns, use_b
         args = (ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col), ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0,
                 ptr(gq), ldg, ptr(gd), ldg, P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
         call("vnp_vn_bn_leaky_bwd_pass", 1, *args, ptr(part), ptr(gw_part), chunk, None, P, None)
-        S = torch.empty((C, 2), device=dev, dtype=torch.float32)
-        call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
+        S, planar = reduce_pairs(part, nch, C)
         call("vnp_vn_bn_leaky_bwd_pass", 2, *args, None, None, chunk, ptr(S) if training else None, P, ptr(cs_part))
-        gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
+        gbeta, ggamma = planar[0], planar[1]
     else:
         call("vnp_vn_bn_leaky_bwd1", ptr(go), _ld(go) if go is not None else 0, ptr(go_row), ptr(go_col),
              ptr(p), _ld(p), ptr(d), _ld(d) if has_d else 0, ptr(gq), ldg, ptr(gd), ldg, P, C,
              ptr(mean) if use_bn else None, ptr(rstd), ptr(gamma) if use_bn else None, ptr(beta) if use_bn else None,
              ns, ptr(part), ptr(gw_part), chunk)
         if use_bn:
-            S = torch.empty((C, 2), device=dev, dtype=torch.float32)
-            call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
+            S, planar = reduce_pairs(part, nch, C)
             call("vnp_vn_bn_bwd2", ptr(gq), ldg, ptr(p), _ld(p), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
                  ptr(S) if training else None, P)
-            gbeta, ggamma = S[:, 0].contiguous(), S[:, 1].contiguous()
+            gbeta, ggamma = planar[0], planar[1]
     res = [gpd, ggamma, gbeta]
     if want_gw:
         res.append(reduce_rows(gw_part, 1, nch_pad, C))
@@ -777,8 +792,7 @@ class VNDirLinearLeakyFn(Function):
         stats = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
         part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
         call("vnp_vn_dir_layer_ex", 2, *common, *stats, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, 0, None, sio)
-        S = torch.empty((C, 2), device=dev, dtype=torch.float32)
-        call("vnp_reduce_rows", ptr(part), 1, 0, nch, 2 * C, 2 * C, ptr(S), 2 * C)
+        S, planar = reduce_pairs(part, nch, C)
         want_gb = bias is not None and ctx.needs_input_grad[8]
         gv = torch.empty((P, 2 * C), device=dev, dtype=torch.float32)
         cs_part = torch.empty((nch, 3, 2 * C), device=dev, dtype=torch.float32) if want_gb else None
@@ -793,7 +807,7 @@ class VNDirLinearLeakyFn(Function):
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             gW = _wgrad(gv, h, fine=folded)
             gWf, gWd = gW[:C], gW[C:]
-        return gh, None, gWf, gWd, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, gb, None, None, None, None, None
+        return gh, None, gWf, gWd, planar[1], planar[0], None, None, gb, None, None, None, None, None
 
 
 class VNLinearLeakyOutFn(Function):
@@ -1275,7 +1289,7 @@ class FoldBnLeakyFn(Function):
         bn = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
         part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
         call("vnp_fold_fused", 2, *args, *bn, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, None, cpc)
-        Ssum = reduce_rows(part.view(1, nch, 2 * C), 1, nch, 2 * C).view(C, 2)
+        Ssum, planar = reduce_pairs(part, nch, C)
         part5 = torch.empty((nch, 5, 2 * C), device=dev, dtype=torch.float32)
         gcoarse = torch.empty((B, Mc, 3), device=dev, dtype=torch.float32)
         call("vnp_fold_fused", 3, *args, *bn, None, 0, ptr(go), _ld(go), None, ptr(Ssum) if training else None, P,
@@ -1285,8 +1299,7 @@ class FoldBnLeakyFn(Function):
         gbias = per_sample[:, :3 * W].reshape(B * 3, W)
         tot = reduce_rows(per_sample, 1, B, 5 * W)
         gws, gwc = tot[0, 3 * W:4 * W], tot[0, 4 * W:]
-        return (gbias, gws, gwc, None, gcoarse if ctx.needs_input_grad[4] else None, Ssum[:, 1].contiguous(),
-                Ssum[:, 0].contiguous(), None, None, None, None)
+        return (gbias, gws, gwc, None, gcoarse if ctx.needs_input_grad[4] else None, planar[1], planar[0], None, None, None, None)
 
 
 class LinOutFn(Function):
@@ -1529,14 +1542,14 @@ def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, traini
 
 def _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv):
     """The backward passes: fills gu [Pu*3, >= 2C] and gv [Pq*3, >= 2C] (row strides free: column halves of one buffer in the packed
-    form) and returns the per-channel sums S [C, 2] (dL/dbeta, dL/dgamma)."""
+    form) and returns the per-channel sums as planar [2, C] rows (dL/dbeta, dL/dgamma)."""
     Pq, k = nbr.shape
     C = u.shape[1] // 2
     Pu = u.shape[0] // 3
     part = torch.empty((nblk, C, 2), device=go.device, dtype=torch.float32)
     call("vnp_edge_fused", 2, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
          ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0, 0, None, 0)
-    S = reduce_rows(part, 1, nblk, 2 * C).view(C, 2)
+    S, planar = reduce_pairs(part, nblk, C)
     sums = ptr(S) if training else None
     if EDGE_GRAD_ATOMICS:
         call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
@@ -1548,7 +1561,7 @@ def _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nb
              None, None, 0, ptr(go), _ld(go), sums, Pq * k, None, 0, 0, ptr(gv), _ld(gv))
         call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
              ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
-    return S
+    return planar
 
 
 class EdgeConvFn(Function):
@@ -1575,7 +1588,7 @@ class EdgeConvFn(Function):
         gu = torch.empty((u.shape[0], 2 * C), device=go.device, dtype=torch.float32)
         gv = torch.empty((v.shape[0], 2 * C), device=go.device, dtype=torch.float32)
         S = _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv)
-        return gu, gv, None, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, None, None
+        return gu, gv, None, S[1], S[0], None, None, None, None
 
 
 class EdgeConvPackedFn(Function):
@@ -1602,7 +1615,7 @@ class EdgeConvPackedFn(Function):
         C2 = uv.shape[1] // 2
         guv = torch.empty_like(uv)
         S = _edge_conv_backward(go, uv[:, :C2], uv[:, C2:], nbr, gamma, beta, mean, rstd, training, ns, nblk, guv[:, :C2], guv[:, C2:])
-        return guv, None, S[:, 1].contiguous(), S[:, 0].contiguous(), None, None, None, None
+        return guv, None, S[1], S[0], None, None, None, None
 
 
 class EdgeWeightsFn(Function):

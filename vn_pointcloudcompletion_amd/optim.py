@@ -12,6 +12,9 @@ therefore never moved, exactly as torch's Adam skips ``grad is None`` parameters
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 
 from . import _lib
@@ -20,9 +23,17 @@ _ALIGN = 4  # elements: keeps every slice 16-byte aligned for the float4 kernels
 
 
 class FlatBuffers:
-    """Re-homes ``params`` (and their ``.grad``) into one flat parameter buffer and one flat gradient buffer."""
+    """Re-homes ``params`` (and their ``.grad``) into one flat parameter buffer and one flat gradient buffer.
 
-    def __init__(self, params):
+    Two ways for the gradients to reach the flat buffer:
+      * in place (CPU tensors; ``VNP_GRAD_INPLACE=1``): every ``p.grad`` IS its slice of ``flat_grad``, the buffer is zeroed per step and
+        autograd adds each incoming gradient into the slice — one small add launch per parameter per step (config 5: 190 of them);
+      * gathered (device tensors, the default): ``zero_grad`` empties ``p.grad``, autograd keeps each incoming gradient tensor as it is
+        (no add, no zero-fill), and ``gather`` copies them to their slices with one launch per 48 tensors (``vnp_pack_tensors``), after
+        which ``p.grad`` is the slice again.  A parameter that received nothing gets zeros (once: a slice known to be zero is left alone).
+    """
+
+    def __init__(self, params, gathered=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -37,6 +48,10 @@ class FlatBuffers:
         self.numel = off
         self.flat_param = torch.zeros(off, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.gathered = (dev.type == "cuda" and os.environ.get("VNP_GRAD_INPLACE", "0") != "1") if gathered is None else bool(gathered)
+        if self.gathered and dev.type != "cuda":
+            raise ValueError("gathered gradients need the device library (vnp_pack_tensors)")
+        self._zero = [True] * len(self.params)            # slice i of flat_grad is known to hold zeros
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 self.flat_param[o:o + p.numel()].copy_(p.detach().reshape(-1))
@@ -47,20 +62,58 @@ class FlatBuffers:
         p, o = self.params[i], self.offsets[i]
         return flat[o:o + p.numel()].view(p.shape)
 
+    def _home(self, i):
+        return self.flat_grad.data_ptr() + self.offsets[i] * 4
+
     def zero_grad(self):
+        if self.gathered:
+            for p in self.params:                     # autograd will keep the incoming gradient tensors; gather() brings them home
+                p.grad = None
+            return
         self.flat_grad.zero_()
         for i, p in enumerate(self.params):          # re-attach views a caller may have dropped (set_to_none=True)
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + self.offsets[i] * 4:
+            if p.grad is None or p.grad.data_ptr() != self._home(i):
                 p.grad = self.view(self.flat_grad, i)
 
+    def gather(self, indices=None):
+        """Bring the gradients of ``indices`` (default: all parameters) home: afterwards ``p.grad`` is the parameter's slice of
+        ``flat_grad`` and holds what autograd produced (zeros if nothing).  No-op for parameters that are at home already."""
+        idx = range(len(self.params)) if indices is None else indices
+        src, off, num, keep = [], [], [], []
+        for i in idx:
+            p = self.params[i]
+            g = p.grad
+            if g is not None and g.data_ptr() == self._home(i):
+                if self.gathered:
+                    self._zero[i] = False             # autograd may have accumulated into the view in place
+                continue
+            if g is None:
+                if not self._zero[i]:
+                    src.append(None); off.append(self.offsets[i]); num.append(p.numel())
+                    self._zero[i] = True
+            elif self.gathered and g.is_contiguous() and g.dtype == torch.float32 and g.numel() == p.numel() and g.device == self.flat_grad.device:
+                src.append(g.data_ptr()); off.append(self.offsets[i]); num.append(p.numel()); keep.append(g)
+                self._zero[i] = False
+            else:
+                self.view(self.flat_grad, i).copy_(g)
+                self._zero[i] = False
+            p.grad = self.view(self.flat_grad, i)
+        if src:
+            if not self.gathered:                     # in-place mode only ever sees a dropped view: zero-fill
+                for o, n in zip(off, num):
+                    self.flat_grad[o:o + n].zero_()
+            else:
+                n = len(src)
+                a_src = (ctypes.c_void_p * n)(*src)
+                a_off = (ctypes.c_longlong * n)(*off)
+                a_num = (ctypes.c_longlong * n)(*num)
+                _lib.call("vnp_pack_tensors", n, ctypes.addressof(a_src), ctypes.addressof(a_off), ctypes.addressof(a_num),
+                          self.flat_grad.data_ptr())
+        del keep                                      # the sources stayed alive until the launch was queued on their stream
+
     def check_views(self):
-        """Gradients produced by autograd must have been accumulated IN PLACE into the flat buffer."""
-        for i, p in enumerate(self.params):
-            if p.grad is None:
-                p.grad = self.view(self.flat_grad, i)
-            elif p.grad.data_ptr() != self.flat_grad.data_ptr() + self.offsets[i] * 4:
-                self.view(self.flat_grad, i).copy_(p.grad)
-                p.grad = self.view(self.flat_grad, i)
+        """Every gradient produced by autograd must be in the flat buffer before it is reduced or applied."""
+        self.gather()
 
 
 class FusedAdam(torch.optim.Optimizer):
