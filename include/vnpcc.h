@@ -75,6 +75,10 @@ int vnp_emd_matchcost_bwd(hipStream_t st, int B, int n, int m, const float* grad
  * accumulation (error vs fp64 at or below mode 1's); 1 = fp32-input MFMA.  Process-wide; returns 0 or VNP_EINVAL. */
 int vnp_gemm_set_mode(int mode);
 int vnp_gemm_get_mode(void);
+/* The tile vnp_gemm runs for an aligned split-mode product with A [M, K] (op_a = 0; N % 128 == 0, K % 32 == 0): 192 / 128 / 96 = the
+ * row-tile height of the 256-thread kernel, 256 = the 512-thread 192 x 256 kernel.  Chosen per launch from the number of workgroup
+ * rounds each height needs (measured costs per round, gemm.hip: vnp_choose_tile); the results are the same bits whichever runs. */
+int vnp_gemm_tile_rows(int op_b, int M, int N, int nsplit, int nbatch, int has_bias);
 /* Measurement hook (bench.py, no reference counterpart): the NEXT matrix-product launch of the calling host thread (vnp_gemm*,
  * vnp_gemm_vn_stats*, vnp_linear_pool*_fwd) records e0 / e1 around its ONE dominant kernel on the launch stream — not the slab
  * reduction or the pool's candidate passes — and stores in *kind (host memory, may be NULL) what that kernel was:

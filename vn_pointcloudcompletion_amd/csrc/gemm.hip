@@ -80,6 +80,13 @@ static bool vnp_no_xcd_split()
     return v;
 }
 
+// VNP_GEMM_NO_ROWS96=1: no 96-row tiles (A/B measurement of the tile choice in vnp_gemm_impl)
+static bool vnp_no_rows96()
+{
+    static const bool v = getenv("VNP_GEMM_NO_ROWS96") != nullptr;
+    return v;
+}
+
 // VNP_GEMM_NO_WIDE=1: big aligned NT products on the 256-thread 192 x 128 kernel as before (A/B measurement of vnp_gemm_split_wide_kernel)
 static bool vnp_no_wide()
 {
@@ -224,6 +231,49 @@ __global__ void __launch_bounds__(256) vnp_gemm_wcolsum_kernel(const float* __re
     if (py == 0 && c < Ccols) slab[(size_t)blockIdx.y * Ccols + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
+// ---- tile choice for activations on M (A [M, K], aligned shapes).  A launch is a number of ROUNDS of workgroups (two resident per
+// CU), and for the mid-sized products of the transformer configs (12288 .. 49152 rows) the fill of the last round decides the time.
+// Measured on M x N x K grids of such shapes (scripts/experiments/gemm_tile_choice_bench.hip, profiles/r03_gemm_tile_choice.txt), in units
+// of one lone 192-row workgroup per CU:  a round that fills at most ONE slot per CU costs 1.0 / 0.77 / 0.68 with 192- / 128- / 96-row
+// tiles, a round that uses both slots 1.45 / 1.08 / 0.95; the 512-thread wide kernel (192 x 256, one per CU) 1.38 per round of 256.
+// The cheapest height that divides M wins (192 unless another is clearly cheaper): 96 rows up to one 192-row tile per CU (-10..-35 %),
+// 128 rows where 192 would spill a nearly empty second round (N = 1152: -14 %), the wide tile for big N % 256 == 0 products (-2..-5 %).
+// Returns the row-tile height (192 also when no aligned height divides M: the bounds-checked kernel); wide = the 192 x 256 kernel.
+static int vnp_choose_tile(int op_b, int M, int N, int nsplit, int nbatch, bool has_bias, bool& wide)
+{
+    wide = false;
+    int bm = 192;
+    const long long sb = (long long)nsplit * nbatch, slots = 2LL * vnp_num_cus();
+    auto cost = [&](int h, double c1, double c2) -> double {
+        if (M % h) return 1e30;
+        const long long it = (long long)(M / h) * (N / 128) * sb, full = it / slots, r = it % slots;
+        return (double)full * c2 + (r == 0 ? 0.0 : 2 * r <= slots ? c1 : c2);
+    };
+    double best = cost(192, 1.0, 1.45);
+    const double c128 = cost(128, 0.77, 1.08);
+    if (c128 < 0.97 * best) { best = c128; bm = 128; }
+    if (!has_bias && nbatch == 1 && !vnp_no_rows96()) {           // (the 96-row instantiations carry no bias epilogue and no batch walk)
+        const double c96 = cost(96, 0.68, 0.95);
+        if (c96 < 0.97 * best) { best = c96; bm = 96; }
+    }
+    if (op_b == 0 && M % 192 == 0 && N % 256 == 0 && !vnp_no_wide()) {
+        const long long items_w = (long long)(M / 192) * (N / 256) * sb;
+        const double cw = (double)((items_w + vnp_num_cus() - 1) / vnp_num_cus()) * 1.38;
+        if (cw < 0.99 * best) { best = cw; bm = 192; wide = true; }
+    }
+    return best >= 1e30 ? 192 : bm;
+}
+
+// What vnp_gemm would run for an aligned split-mode product with A [M, K] (op_a = 0): the row-tile height 192 / 128 / 96, or 256 for the
+// 512-thread 192 x 256 kernel (tests and DESIGN.md quote it; N % 128 == 0 and K % 32 == 0 assumed).
+extern "C" int vnp_gemm_tile_rows(int op_b, int M, int N, int nsplit, int nbatch, int has_bias)
+{
+    if (M <= 0 || N <= 0 || N % 128) return VNP_EINVAL;
+    bool wide = false;
+    const int bm = vnp_choose_tile(op_b, M, N, nsplit < 1 ? 1 : nsplit, nbatch < 1 ? 1 : nbatch, has_bias != 0, wide);
+    return wide ? 256 : bm;
+}
+
 // ---------------------------------------------------------------------------------------------- C-ABI
 // op_a: 0 = A is [M, K] row-major (K contiguous), 1 = A is [K, M] row-major (M contiguous)
 // op_b: 0 = B is [N, K] row-major (K contiguous), 1 = B is [K, N] row-major (N contiguous)
@@ -305,27 +355,19 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     p.xcd_split = (nsplit > 1 && nsplit % 8 == 0 && nbatch == 1 && vnp_gemm_get_mode() == 0 && !vnp_no_xcd_split()) ? 1 : 0;
     p.col_group = 8;                     // measured: +3 % at N = 2048 (B panels of 8 column tiles stay in the XCD's L2)
     p.pool_val = nullptr; p.pool_idx = nullptr; p.pool_x = nullptr; p.pool_gs = 0;
-    // activations on M: 192-row tiles; a row count that 128 divides but 192 does not (65536 points: the per-point GEMMs of
-    // vnp_vn_dir_layer) takes 128-row tiles on the aligned kernel instead of 192-row tiles on the bounds-checked one (120 -> 165 TFLOP/s)
-    const bool rows128 = op_a == 0 && vnp_gemm_get_mode() == 0 && M % 192 != 0 && M % 128 == 0 && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a;
-    // ... and the per-sample layers (M = 3 B = 96 rows: coarse head, decoder bias) 96-row tiles instead of half-empty 192-row ones
-    // ... and so do activations of a few thousand rows whose 192-row tiles would leave most of the chip idle (VN-PoinTr's 12288-row
-    // blocks with N = 128: 64 tiles for 512 workgroup slots): twice the tiles
-    const bool few192 = M % 96 == 0 && (long long)vnp_cdiv(M, 192) * vnp_cdiv(N, 128) * (nsplit > 1 ? nsplit : 1) * nbatch < vnp_num_cus();
-    const bool rows96 = op_a == 0 && vnp_gemm_get_mode() == 0 && (M == 96 || few192) && N % 128 == 0 && K % 32 == 0 && K > 0 && !amax_a && !bias &&
-                        (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && nbatch == 1 &&
-                        getenv("VNP_GEMM_NO_ROWS96") == nullptr;
-    const int bm = rows96 ? 96 : (op_a == 0 && !rows128) ? 192 : 128;
-    const long long items = (long long)vnp_cdiv(M, bm) * vnp_cdiv(N, 128) * nsplit * nbatch;
-    if (items > 2147483647LL) return VNP_EINVAL;
+    const bool split = vnp_gemm_get_mode() == 0;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) &&
                          (bsa % 4 == 0) && (bsb % 4 == 0);
+    bool wide = false;
+    const bool tileable = op_a == 0 && split && aligned && N % 128 == 0 && K % BK == 0 && K > 0 && !amax_a;
+    const int bm = tileable ? vnp_choose_tile(op_b, M, N, nsplit, nbatch, bias != nullptr, wide) : (op_a == 0 ? 192 : 128);
+    const long long items = (long long)vnp_cdiv(M, bm) * vnp_cdiv(N, 128) * nsplit * nbatch;
+    if (items > 2147483647LL) return VNP_EINVAL;
     const bool fast = aligned && (M % bm == 0) && (N % 128 == 0) && (K % BK == 0) && K > 0;
-    // resident workgroups per CU: 2 for the 192-row tiles (~240 VGPRs), 3 for the aligned 128-row weight-gradient kernel (151)
-    const bool split = vnp_gemm_get_mode() == 0;
     // two fp16 planes / three products when the caller supplies max |A| and max |B| (vnp_gemm_ex); aligned shapes with K >= 64 only
     const bool h2 = split && fast && amax_a && amax_b && K >= 64;
     p.amax_a = amax_a; p.amax_b = amax_b;
+    // resident workgroups per CU: 2 for the 192-row tiles (~240 VGPRs), 3 for the aligned 128-row weight-gradient kernel (151)
     const long long cap = (long long)vnp_num_cus() * ((!split && bm == 128 && fast && op_b == 1) ? 3 : 2);
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
 #define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                                    \
@@ -339,23 +381,19 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p);   \
         }                                                                                                               \
     } while (0)
-    // big aligned NT products (both operands K-contiguous, N % 256 == 0, at least one 192 x 256 tile per CU): the 512-thread kernel with the
-    // wide tile — the same arithmetic bit for bit, 0.7x the staging work per MFMA; measured +4-8 % (scripts/experiments/gemm_wide_bench.hip)
-    const long long items_w = (long long)(M / 192) * (N / 256) * nsplit * nbatch;
-    const bool wide = split && !h2 && fast && bm == 192 && op_a == 0 && op_b == 0 && N % 256 == 0 && items_w >= vnp_num_cus() && !vnp_no_wide();
     vnp_prof_begin(stream);
-    if (wide)
+    if (wide) {
+        // both operands K-contiguous, N % 256 == 0: the 512-thread kernel with the 192 x 256 tile — the same arithmetic bit for bit,
+        // 0.7x the staging work per MFMA (scripts/experiments/gemm_wide_bench.hip)
+        const long long items_w = (long long)(M / 192) * (N / 256) * nsplit * nbatch;
         hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
-    else if (rows96) {
+    } else if (tileable && fast && bm == 96) {
         if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, true, true>), grid, block, 0, stream, p);
         else           hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, false, true>), grid, block, 0, stream, p);
-    }
-    else if (rows128 && fast) {
+    } else if (tileable && fast && bm == 128) {
         if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<128, 128, true, true, true>), grid, block, 0, stream, p);
         else           hipLaunchKernelGGL((vnp_gemm_split_kernel<128, 128, true, false, true>), grid, block, 0, stream, p);
     }
-    else if (rows128 && op_b == 0)   VNP_LAUNCH(128, true, true);        // (unaligned pointers / strides: the generic instantiation)
-    else if (rows128)                VNP_LAUNCH(128, true, false);
     else if (op_a == 0 && op_b == 0) VNP_LAUNCH(192, true, true);
     else if (op_a == 0 && op_b == 1) VNP_LAUNCH(192, true, false);
     else if (op_a == 1 && op_b == 1) VNP_LAUNCH(128, false, false);
@@ -926,7 +964,9 @@ extern "C" int vnp_gemm_vn_stats_ex(hipStream_t st, int M, int N, int K, const f
     const long long items_w = (long long)(M / 192) * (N / 256);
     vnp_prof_begin(st);
     if (amax_a && K >= 64) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2, 1>), grid, block, 0, st, p);
-    else if (N % 256 == 0 && items_w >= vnp_num_cus() && !vnp_no_wide())          // the wide tile, as in vnp_gemm_impl
+    else if (N % 256 == 0 && !vnp_no_wide() &&                                     // the wide tile where its rounds are cheaper (vnp_gemm_impl)
+             (double)((items_w + vnp_num_cus() - 1) / vnp_num_cus()) * 1.38 <
+             0.99 * ((double)(items / cap) * 1.45 + (items % cap == 0 ? 0.0 : 2 * (items % cap) <= cap ? 1.0 : 1.45)))
         hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<2>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
     vnp_prof_end(st, (amax_a && K >= 64) ? 5 : 0);
