@@ -129,6 +129,14 @@ int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, const float*
 /* rows [B*N*3][ld] <-> heads [B][H][N][(C/H)*3] (transformer.py:91-93: reshape(B,H,C/H,3,N).permute(0,1,4,2,3)) */
 int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads);
 int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int N, int C, int H, float* rows, int ld);
+/* The same permutation into layouts the aligned GEMM kernels can take when the head dimension Dh = 3 C / H (144 in
+ * Attention_VN_FoldingNet) is neither a multiple of 32 nor of 128:
+ *   _pad: token-major heads [(b, h)][n][ldh], ldh >= Dh, columns [Dh, ldh) zero   (K of q k^T and dout v^T, padded to a multiple of 32)
+ *   _fm:  feature-major heads [(b, h)][fr][N], fr >= Dh, rows [Dh, fr) zero        (the head dimension on M of out^T = v^T P^T,
+ *         dv^T = dout^T P, dq^T = k^T dS^T, dk^T = q^T dS, padded to whole row tiles) and back to rows. */
+int vnp_rows_to_heads_pad(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads, int ldh);
+int vnp_rows_to_heads_fm(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads, int fr);
+int vnp_heads_fm_to_rows(hipStream_t st, const float* heads, int fr, int B, int N, int C, int H, float* rows, int ld);
 /* S[R][L] <- softmax(S*scale) in place; backward: dP <- P*(dP - sum(dP*P))*scale */
 int vnp_softmax_fwd(hipStream_t st, float* S, long long R, int L, float scale);
 int vnp_softmax_bwd(hipStream_t st, const float* P, float* dP, long long R, int L, float scale);

@@ -229,3 +229,61 @@ def test_head_permutes_are_the_index_permutation(lib_built, B, N, C, H):
     ops._from_heads(heads, B, N, C, H, out=back[:, 2:2 + C])
     assert torch.equal(back[:, 2:2 + C], rows)
     assert (back[:, :2] == 7.0).all() and (back[:, 2 + C:] == 7.0).all()          # nothing written outside the view
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 37, 384, 8), (1, 130, 12, 4), (3, 64, 96, 2), (1, 128, 384, 6), (2, 70, 384, 4)])
+def test_padded_and_feature_major_head_layouts(lib_built, B, N, C, H):
+    """vnp_rows_to_heads_pad / vnp_rows_to_heads_fm / vnp_heads_fm_to_rows: the permutation of vnp_rows_to_heads into token-major slices of
+    ldh >= Dh floats and into feature-major [fr >= Dh][N] panels, padding written as zeros, ragged token tiles, strided row views."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(B + N + C + H)
+    wide = torch.randn(B * N * 3, 3 * C, generator=g).cuda()
+    rows = wide[:, C:2 * C]                                      # the k third of a packed q | k | v matrix
+    ch = C // H
+    Dh, ldh, fr = ops._attn_dims(C, H)
+    assert ldh % 32 == 0 and fr % 96 == 0 and ldh >= Dh and fr >= Dh
+    want = rows.view(B, N, 3, H, ch).permute(0, 3, 1, 4, 2).reshape(B * H, N, Dh)
+    tm = ops._heads_tm(rows, B, N, H, ldh)
+    assert torch.equal(tm[:, :, :Dh], want) and (tm[:, :, Dh:] == 0).all()
+    fm = ops._heads_fm(rows, B, N, H, fr)
+    assert torch.equal(fm[:, :Dh, :], want.transpose(1, 2)) and (fm[:, Dh:, :] == 0).all()
+    back = torch.full((B * N * 3, 3 * C), 7.0, device="cuda")
+    ops._rows_from_fm(fm, B, N, C, H, out=back[:, 2 * C:])
+    assert torch.equal(back[:, 2 * C:], rows) and (back[:, :2 * C] == 7.0).all()
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 128, 384, 8), (2, 256, 384, 6), (1, 37, 24, 4), (2, 128, 384, 4)])
+def test_attention_layouts_agree(lib_built, B, N, C, H):
+    """The attention core on padded token-major / feature-major head tensors (every product on the aligned kernels) against the
+    rounds 1-2 form (head dimension on N / K, bounds-checked kernels) and against float64 torch: same values within fp32 rounding
+    (the products of out, dq, dk, dv swap their operand roles, so the six-product sums meet in another order), packed and unpacked."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(N + C)
+    qkv = torch.randn(B * N * 3, 3 * C, generator=g).cuda()
+    go = torch.randn(B * N * 3, C, generator=g).cuda()
+    scale = 0.3
+    res = {}
+    floor = ops.ATTN_FM_MIN_FLOP
+    for tm in (False, True):
+        ops.ATTN_TOKEN_MAJOR, ops.ATTN_FM_MIN_FLOP = tm, 0.0              # no size floor: these small cases take the padded layouts too
+        try:
+            x = qkv.clone().requires_grad_(True)
+            out = ops.VNAttentionPackedFn.apply(x, B, N, H, scale)
+            out.backward(go)
+            q, k, v = (qkv[:, i * C:(i + 1) * C].contiguous().requires_grad_(True) for i in range(3))
+            out2 = ops.VNAttentionFn.apply(q, k, v, B, N, H, scale)
+            out2.backward(go)
+            res[tm] = (out.detach(), x.grad, out2.detach(), torch.cat([q.grad, k.grad, v.grad], dim=1))
+        finally:
+            ops.ATTN_TOKEN_MAJOR, ops.ATTN_FM_MIN_FLOP = False, floor
+    assert not ops._attn_token_major(16, 1024, 384, 8) and ops._attn_token_major(32, 128, 384, 4)       # configs 4 and 5
+    assert torch.equal(res[False][0], res[False][2]) and torch.equal(res[False][1], res[False][3])        # packed == unpacked
+    assert relerr(res[False][0], res[True][0]) < 2e-6 and relerr(res[False][1], res[True][1]) < 5e-6
+
+    def heads(r):
+        return r.double().reshape(B, N, 3, H, C // H).permute(0, 3, 1, 4, 2).reshape(B, H, N, -1)
+    xd = qkv.double().clone().requires_grad_(True)
+    o = ((heads(xd[:, :C]) @ heads(xd[:, C:2 * C]).transpose(-1, -2)) * scale).softmax(-1) @ heads(xd[:, 2 * C:])
+    o = o.reshape(B, H, N, C // H, 3).permute(0, 2, 4, 1, 3).reshape(B * N * 3, C)
+    o.backward(go.double())
+    assert relerr(res[False][0], o) < 2e-5 and relerr(res[False][1], xd.grad) < 5e-5

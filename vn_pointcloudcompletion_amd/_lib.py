@@ -76,6 +76,9 @@ _SIGNATURES = {
     "vnp_vn_layernorm_bwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "vnp_rows_to_heads": [_vp, _i, _i, _i, _i, _i, _vp],
     "vnp_heads_to_rows": [_vp, _i, _i, _i, _i, _vp, _i],
+    "vnp_rows_to_heads_pad": [_vp, _i, _i, _i, _i, _i, _vp, _i],
+    "vnp_rows_to_heads_fm": [_vp, _i, _i, _i, _i, _i, _vp, _i],
+    "vnp_heads_fm_to_rows": [_vp, _i, _i, _i, _i, _i, _vp, _i],
     "vnp_softmax_fwd": [_vp, _ll, _i, _f],
     "vnp_softmax_bwd": [_vp, _vp, _ll, _i, _f],
     "vnp_vn_norm_stats": [_vp, _i, _ll, _i, _vp, _i],

@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict
 // address of one side: every 128-byte line of that side was touched by three waves at three times, and the counters showed 3x its bytes
 // through the fabric — profiles/r03_cfg5_summary.json: 57 MB written for 19 MB read.)
 template <bool TO_HEADS>
-__global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H, int PN)
+__global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H, int PN,
+                                                              int ldh)
 {
     extern __shared__ float tile[];                  // [PN][3][C] in the rows' order
     const int ch = C / H, Dh = ch * 3, per = 3 * C;
@@ -118,17 +119,79 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
             const int p = ph / H, h = ph - p * H;
             const long long tok = tok0 + p;
             const int b = (int)(tok / N), n = (int)(tok - (long long)b * N);
-            const size_t g = (((size_t)b * H + h) * N + n) * Dh;
+            const size_t g = (((size_t)b * H + h) * N + n) * ldh;             // slices of ldh >= Dh floats: [Dh, ldh) is zero padding
             const int base = p * per + h * ch;
             for (int r = lane; r < Dh; r += 64) {
                 const int cl = r / 3, t = r - cl * 3;
                 if (load) tile[base + t * C + cl] = src[g + r];
                 else dst[g + r] = tile[base + t * C + cl];
             }
+            if (!load) for (int r = Dh + lane; r < ldh; r += 64) dst[g + r] = 0.f;
         }
     };
     if (TO_HEADS) { rows_side(true); __syncthreads(); heads_side(false); }
     else          { heads_side(true); __syncthreads(); rows_side(false); }
+}
+
+// FEATURE-major head tensors: hf[(b, h)][r][n], r = cl * 3 + t < Dh, with rows [Dh, FR) zero.  They put the head dimension (48 * 3 = 144
+// in Attention_VN_FoldingNet: neither a multiple of 128 nor of 32) on M of the attention's products, padded to whole row tiles, instead of
+// on N / K where the bounds-checked kernels had to take it: out^T = v^T P^T, dv^T = dout^T P, dq^T = k^T dS^T, dk^T = q^T dS.
+// A workgroup = one (b, h) and 64 tokens, staged in LDS as [token][Dh + 1]: the rows side moves runs of ch contiguous floats, the
+// feature-major side runs of 64 consecutive tokens.
+template <bool TO_HEADS>
+__global__ void __launch_bounds__(256) vnp_head_permute_fm_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H,
+                                                                 int FR, int TT, int vec)
+{
+    extern __shared__ float tile[];                  // [TT][3 ch + 1] in the rows' order [t][cl], TT <= 64 tokens
+    const int ch = C / H, Dh = ch * 3, TS = Dh + 1;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int n0 = blockIdx.x * TT, cnt = N - n0 < TT ? N - n0 : TT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // rows side: a (token, component) segment is ch contiguous floats of one row.  vec: ch % 4 == 0 and 16-byte aligned rows — a wave
+    // moves 64 / (ch / 4) segments per instruction as float4 (five 192-byte segments at ch = 48) instead of one with ch of its lanes;
+    // the loops are unrolled so that several loads are in flight per wave (one segment per trip was a chain of dependent round trips).
+    auto rows_side = [&](bool load) {
+        const int nseg = cnt * 3;
+        if (vec) {
+            const int q4 = ch >> 2, per = 64 / q4, sl = lane / q4, quad = lane - sl * q4;
+            const bool on = sl < per;
+#pragma unroll 4
+            for (int s0 = wave * per; s0 < nseg; s0 += 4 * per) {
+                const int seg = s0 + sl;
+                if (on && seg < nseg) {
+                    const int n = seg / 3, t = seg - n * 3;
+                    const size_t g = (((size_t)b * N + n0 + n) * 3 + t) * ld + h * ch + quad * 4;
+                    float* tp = tile + n * TS + t * ch + quad * 4;
+                    if (load) { const vnp_f4 v = *(const vnp_f4*)(src + g); tp[0] = v[0]; tp[1] = v[1]; tp[2] = v[2]; tp[3] = v[3]; }
+                    else *(vnp_f4*)(dst + g) = vnp_f4{tp[0], tp[1], tp[2], tp[3]};
+                }
+            }
+        } else {
+            for (int seg = wave; seg < nseg; seg += 4) {
+                const int n = seg / 3, t = seg - n * 3;
+                const size_t g = (((size_t)b * N + n0 + n) * 3 + t) * ld + h * ch;
+                for (int cl = lane; cl < ch; cl += 64) {
+                    if (load) tile[n * TS + t * ch + cl] = src[g + cl];
+                    else dst[g + cl] = tile[n * TS + t * ch + cl];
+                }
+            }
+        }
+    };
+    // feature-major side: feature row r = cl * 3 + t, TT consecutive tokens (lane = token: LDS stride 3 ch + 1 words, conflict-free)
+    auto fm_side = [&](bool load) {
+        const int nr = load ? Dh : FR;
+#pragma unroll 4
+        for (int r = wave; r < nr; r += 4) {
+            const size_t g = ((size_t)bh * FR + r) * N + n0;
+            const int cl = r / 3, t = r - cl * 3;
+            if (lane < cnt) {
+                if (load) tile[lane * TS + t * ch + cl] = src[g + lane];
+                else dst[g + lane] = r < Dh ? tile[lane * TS + t * ch + cl] : 0.f;
+            }
+        }
+    };
+    if (TO_HEADS) { rows_side(true); __syncthreads(); fm_side(false); }
+    else          { fm_side(true); __syncthreads(); rows_side(false); }
 }
 
 // tokens per workgroup: ~24 KB of LDS, at least one token, at most eight
@@ -223,15 +286,22 @@ extern "C" int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, c
     return vnp_last_error();
 }
 
-extern "C" int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads)
+// heads [(b, h)][n][ldh] token-major with ldh >= 3 C / H; the columns [3 C / H, ldh) are written as zeros (K padding of q k^T / dout v^T)
+extern "C" int vnp_rows_to_heads_pad(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads, int ldh)
 {
-    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H || ld < C || C > 5000) return VNP_EINVAL;          // one token (3 C floats) must fit 64 KB of LDS
+    if (!rows || !heads || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H || ld < C || C > 5000 || ldh < 3 * (C / H)) return VNP_EINVAL;   // one token (3 C floats) must fit 64 KB of LDS
     const int pn = vnp_head_permute_pn(C);
     const long long blocks = ((long long)B * N + pn - 1) / pn;
     if (blocks > 2147483647LL) return VNP_EINVAL;
     hipLaunchKernelGGL((vnp_head_permute_kernel<true>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * C * sizeof(float), st,
-                       rows, heads, ld, B, N, C, H, pn);
+                       rows, heads, ld, B, N, C, H, pn, ldh);
     return vnp_last_error();
+}
+
+extern "C" int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads)
+{
+    if (H <= 0 || C <= 0 || C % H) return VNP_EINVAL;
+    return vnp_rows_to_heads_pad(st, rows, ld, B, N, C, H, heads, 3 * (C / H));
 }
 
 extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int N, int C, int H, float* rows, int ld)
@@ -241,8 +311,36 @@ extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int 
     const long long blocks = ((long long)B * N + pn - 1) / pn;
     if (blocks > 2147483647LL) return VNP_EINVAL;
     hipLaunchKernelGGL((vnp_head_permute_kernel<false>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * C * sizeof(float), st,
-                       heads, rows, ld, B, N, C, H, pn);
+                       heads, rows, ld, B, N, C, H, pn, 3 * (C / H));
     return vnp_last_error();
+}
+
+// feature-major heads hf [(b, h)][fr][N], fr >= 3 C / H (rows beyond the head dimension are written as zeros) <-> rows [(b, n, t)][C]
+static int vnp_heads_fm(hipStream_t st, bool to_heads, const float* src, float* dst, int ld, int B, int N, int C, int H, int fr)
+{
+    if (!src || !dst || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H || ld < C || fr < 3 * (C / H) || (long long)B * H > 65535) return VNP_EINVAL;
+    const int Dh = 3 * (C / H);
+    int tt = 64;                                                     // tokens per workgroup: as many (64, 32, 16) as fit 64 KB of LDS
+    while (tt > 16 && (size_t)tt * (Dh + 1) * sizeof(float) > 65536) tt >>= 1;
+    const size_t lds = (size_t)tt * (Dh + 1) * sizeof(float);
+    if (lds > 65536) return VNP_EINVAL;
+    dim3 grid((unsigned)((N + tt - 1) / tt), (unsigned)(B * H));
+    const float* rows = to_heads ? src : dst;
+    const int ch = C / H;
+    const int vec = (ch % 4 == 0 && ch / 4 <= 64 && ld % 4 == 0 && ((uintptr_t)rows & 15) == 0) ? 1 : 0;
+    if (to_heads) hipLaunchKernelGGL((vnp_head_permute_fm_kernel<true>), grid, dim3(256), lds, st, src, dst, ld, B, N, C, H, fr, tt, vec);
+    else          hipLaunchKernelGGL((vnp_head_permute_fm_kernel<false>), grid, dim3(256), lds, st, src, dst, ld, B, N, C, H, fr, tt, vec);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_rows_to_heads_fm(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads, int fr)
+{
+    return vnp_heads_fm(st, true, rows, heads, ld, B, N, C, H, fr);
+}
+
+extern "C" int vnp_heads_fm_to_rows(hipStream_t st, const float* heads, int fr, int B, int N, int C, int H, float* rows, int ld)
+{
+    return vnp_heads_fm(st, false, heads, rows, ld, B, N, C, H, fr);
 }
 
 extern "C" int vnp_softmax_fwd(hipStream_t st, float* S, long long R, int L, float scale)

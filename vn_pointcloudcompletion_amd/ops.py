@@ -1670,35 +1670,116 @@ def _from_heads(heads, B, N, C, H, out=None):
     return rows
 
 
+ATTN_TOKEN_MAJOR = os.environ.get("VNP_ATTN_TOKEN_MAJOR", "0") == "1"      # A/B: the rounds 1-2 layout (head dimension on N / K of the products)
+
+
+ATTN_FM_MIN_FLOP = 8e9          # per attention product (2 B H N^2 Dh): below this the products are launch-bound and the extra permutes cost more
+
+
+def _attn_token_major(B, N, C, H):
+    """The rounds 1-2 layout (head dimension on N / K, bounds-checked kernels where it is not a multiple of 128 / 32) for small attention
+    problems — VN-PoinTr's 128 tokens: 1.2 GFLOP per product, measured 29.1 (this layout) vs 30.2 ms per step — and the padded
+    token-major / feature-major layout for big ones (Attention_VN_FoldingNet's 1024 tokens: 39 GFLOP per product, 32.8 -> 31.8 ms)."""
+    return ATTN_TOKEN_MAJOR or 2.0 * B * H * N * N * (C // H) * 3 < ATTN_FM_MIN_FLOP
+
+
+def _attn_dims(C, H):
+    """(Dh, ldh, fr): the head dimension 3 C / H, its K padding (multiple of 32) and its M padding (whole 96-row tiles)."""
+    Dh = (C // H) * 3
+    return Dh, (Dh + 31) // 32 * 32, (Dh + 95) // 96 * 96
+
+
+def _heads_tm(rows, B, N, H, ldh):
+    """rows [B*N*3, C] (any row stride) -> token-major heads [B*H, N, ldh], columns beyond 3 C / H zero."""
+    C = rows.shape[1]
+    heads = torch.empty((B * H, N, ldh), device=rows.device, dtype=torch.float32)
+    call("vnp_rows_to_heads_pad", ptr(rows), _ld(rows), B, N, C, H, ptr(heads), ldh)
+    return heads
+
+
+def _heads_fm(rows, B, N, H, fr):
+    """rows [B*N*3, C] (any row stride) -> feature-major heads [B*H, fr, N], rows beyond 3 C / H zero."""
+    C = rows.shape[1]
+    heads = torch.empty((B * H, fr, N), device=rows.device, dtype=torch.float32)
+    call("vnp_rows_to_heads_fm", ptr(rows), _ld(rows), B, N, C, H, ptr(heads), fr)
+    return heads
+
+
+def _rows_from_fm(hf, B, N, C, H, out=None):
+    rows = torch.empty((B * N * 3, C), device=hf.device, dtype=torch.float32) if out is None else out
+    call("vnp_heads_fm_to_rows", ptr(hf), hf.shape[1], B, N, C, H, ptr(rows), _ld(rows))
+    return rows
+
+
+def _attention_forward(q, k, v, B, N, H, scale):
+    """softmax(q k^T scale) v per (sample, head); q, k, v rows [B*N*3, C] (column slices allowed).  Returns (out rows, P [B*H, N, N]).
+    The head dimension Dh = 3 C / H (144 in Attention_VN_FoldingNet, 192 in VN-PoinTr) is zero-padded to a multiple of 32 where it is
+    the K of a product (q k^T) and laid out feature-major, padded to whole row tiles, where it would have been the N (out^T = v^T P^T):
+    every product then runs on the aligned kernels (round 3; before: the bounds-checked ones, 5.4 ms of config 4's step at 70-100 TF/s)."""
+    C = q.shape[1]
+    _, ldh, fr = _attn_dims(C, H)
+    P = gemm_batched(_heads_tm(q, B, N, H, ldh), _heads_tm(k, B, N, H, ldh))      # [B*H, N(q), N(k)] scores
+    call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
+    o_fm = gemm_batched(_heads_fm(v, B, N, H, fr), P)                               # [B*H, fr, N(q)] = v^T P^T
+    return _rows_from_fm(o_fm, B, N, C, H), P
+
+
+def _attention_backward(go, q, k, v, P, B, N, H, scale, outs):
+    """Fills outs = (dq, dk, dv) rows views [B*N*3, C] (any row stride).  P is consumed (it stays P; dP becomes dS in place)."""
+    C = q.shape[1]
+    _, ldh, fr = _attn_dims(C, H)
+    dP = gemm_batched(_heads_tm(go, B, N, H, ldh), _heads_tm(v, B, N, H, ldh))    # dout v^T: [B*H, N(q), N(k)]
+    dv_fm = gemm_batched(_heads_fm(go, B, N, H, fr), P, op_b=1)                     # dout^T P: [B*H, fr, N(k)]
+    _rows_from_fm(dv_fm, B, N, C, H, out=outs[2])
+    del dv_fm
+    call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)                  # dP <- dS
+    dq_fm = gemm_batched(_heads_fm(k, B, N, H, fr), dP)                             # k^T dS^T: [B*H, fr, N(q)]
+    _rows_from_fm(dq_fm, B, N, C, H, out=outs[0])
+    del dq_fm
+    dk_fm = gemm_batched(_heads_fm(q, B, N, H, fr), dP, op_b=1)                     # q^T dS: [B*H, fr, N(k)]
+    _rows_from_fm(dk_fm, B, N, C, H, out=outs[1])
+
+
 class VNAttentionFn(Function):
     """softmax(q k^T * scale) v over tokens whose features are the flattened (C/H, 3) vectors of each head
-    (models/transformer.py:91-104).  q, k, v: rows [B*N*3, C].  The two matrix products are batched vnp_gemm GEMMs (fp32 results; split-bf16 or fp32-input MFMA, see gemm.hip)."""
+    (models/transformer.py:91-104).  q, k, v: rows [B*N*3, C].  The matrix products are batched vnp_gemm GEMMs (fp32 results; split-bf16 or
+    fp32-input MFMA, see gemm.hip) on padded token-major / feature-major head tensors (_attention_forward)."""
 
     @staticmethod
     def forward(ctx, q, k, v, B, N, H, scale):
         q, k, v = _rows(q), _rows(k), _rows(v)
         C = q.shape[1]
-        qh, kh, vh = _to_heads(q, B, N, H), _to_heads(k, B, N, H), _to_heads(v, B, N, H)
-        P = gemm_batched(qh, kh)                                      # [B*H, N, N] scores
-        call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
-        oh = gemm_batched(P, vh, op_b=1)                               # [B*H, N, Dh]
-        ctx.save_for_backward(qh, kh, vh, P)
         ctx.cfg = (B, N, C, H, float(scale))
-        return _from_heads(oh, B, N, C, H)
+        ctx.token_major = _attn_token_major(B, N, C, H)
+        if ctx.token_major:
+            qh, kh, vh = _to_heads(q, B, N, H), _to_heads(k, B, N, H), _to_heads(v, B, N, H)
+            P = gemm_batched(qh, kh)                                      # [B*H, N, N] scores
+            call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
+            oh = gemm_batched(P, vh, op_b=1)                               # [B*H, N, Dh]
+            ctx.save_for_backward(qh, kh, vh, P)
+            return _from_heads(oh, B, N, C, H)
+        out, P = _attention_forward(q, k, v, B, N, H, scale)
+        ctx.save_for_backward(q, k, v, P)
+        return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, go):
-        qh, kh, vh, P = ctx.saved_tensors
         B, N, C, H, scale = ctx.cfg
-        goh = _to_heads(_rows(go), B, N, H)
-        dP = gemm_batched(goh, vh)                                     # [B*H, N, N]
-        dvh = gemm_batched(P, goh, op_a=1, op_b=1)                     # P^T goh
-        call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
-        dqh = gemm_batched(dP, kh, op_b=1)
-        dkh = gemm_batched(dP, qh, op_a=1, op_b=1)
-        return (_from_heads(dqh, B, N, C, H), _from_heads(dkh, B, N, C, H), _from_heads(dvh, B, N, C, H),
-                None, None, None, None)
+        if ctx.token_major:
+            qh, kh, vh, P = ctx.saved_tensors
+            goh = _to_heads(_rows(go), B, N, H)
+            dP = gemm_batched(goh, vh)                                     # [B*H, N, N]
+            dvh = gemm_batched(P, goh, op_a=1, op_b=1)                     # P^T goh
+            call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
+            dqh = gemm_batched(dP, kh, op_b=1)
+            dkh = gemm_batched(dP, qh, op_a=1, op_b=1)
+            return (_from_heads(dqh, B, N, C, H), _from_heads(dkh, B, N, C, H), _from_heads(dvh, B, N, C, H),
+                    None, None, None, None)
+        q, k, v, P = ctx.saved_tensors
+        outs = tuple(torch.empty((B * N * 3, C), device=go.device, dtype=torch.float32) for _ in range(3))
+        _attention_backward(_rows(go), q, k, v, P, B, N, H, scale, outs)
+        return outs + (None, None, None, None)
 
 
 class VNAttentionPackedFn(Function):
@@ -1710,28 +1791,38 @@ class VNAttentionPackedFn(Function):
     def forward(ctx, qkv, B, N, H, scale):
         qkv = _rows(qkv)
         C = qkv.shape[1] // 3
-        qh, kh, vh = (_to_heads(qkv[:, i * C:(i + 1) * C], B, N, H) for i in range(3))
-        P = gemm_batched(qh, kh)                                      # [B*H, N, N] scores
-        call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
-        oh = gemm_batched(P, vh, op_b=1)                               # [B*H, N, Dh]
-        ctx.save_for_backward(qh, kh, vh, P)
         ctx.cfg = (B, N, C, H, float(scale))
-        return _from_heads(oh, B, N, C, H)
+        ctx.token_major = _attn_token_major(B, N, C, H)
+        if ctx.token_major:
+            qh, kh, vh = (_to_heads(qkv[:, i * C:(i + 1) * C], B, N, H) for i in range(3))
+            P = gemm_batched(qh, kh)                                      # [B*H, N, N] scores
+            call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
+            oh = gemm_batched(P, vh, op_b=1)                               # [B*H, N, Dh]
+            ctx.save_for_backward(qh, kh, vh, P)
+            return _from_heads(oh, B, N, C, H)
+        out, P = _attention_forward(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, N, H, scale)
+        ctx.save_for_backward(qkv, P)
+        return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, go):
-        qh, kh, vh, P = ctx.saved_tensors
         B, N, C, H, scale = ctx.cfg
-        goh = _to_heads(_rows(go), B, N, H)
-        dP = gemm_batched(goh, vh)                                     # [B*H, N, N]
-        dvh = gemm_batched(P, goh, op_a=1, op_b=1)                     # P^T goh
-        call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
-        dqh = gemm_batched(dP, kh, op_b=1)
-        dkh = gemm_batched(dP, qh, op_a=1, op_b=1)
         g = torch.empty((B * N * 3, 3 * C), device=go.device, dtype=torch.float32)
-        for i, h in enumerate((dqh, dkh, dvh)):
-            _from_heads(h, B, N, C, H, out=g[:, i * C:(i + 1) * C])
+        if ctx.token_major:
+            qh, kh, vh, P = ctx.saved_tensors
+            goh = _to_heads(_rows(go), B, N, H)
+            dP = gemm_batched(goh, vh)                                     # [B*H, N, N]
+            dvh = gemm_batched(P, goh, op_a=1, op_b=1)                     # P^T goh
+            call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
+            dqh = gemm_batched(dP, kh, op_b=1)
+            dkh = gemm_batched(dP, qh, op_a=1, op_b=1)
+            for i, h in enumerate((dqh, dkh, dvh)):
+                _from_heads(h, B, N, C, H, out=g[:, i * C:(i + 1) * C])
+            return g, None, None, None, None
+        qkv, P = ctx.saved_tensors
+        _attention_backward(_rows(go), qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], P, B, N, H, scale,
+                            (g[:, :C], g[:, C:2 * C], g[:, 2 * C:]))
         return g, None, None, None, None
 
 
