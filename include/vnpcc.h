@@ -308,6 +308,18 @@ int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const f
                    const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
                    float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
                    float* part5, float* gcoarse, int coarse_per_chunk);
+/* The four passes of vnp_fold_fused for a layer whose per-point input is ONE VN channel x [G][S][3] beside per-GROUP features
+ * (Attention_VN_FoldingNet's folding stages, /root/reference/models/pcn.py:486-488: cat([point, centre features]) ->
+ * VNLinearLeakyReLU(385, 256)):  p | d [(g, s)][t][j] = bias[g*3 + t][j | C + j] + w[j | C + j] * x[g][s][t],  bias [G*3][2C] = the
+ * group features times their weight columns, w [2C] = the weight column of the point channel.  The [G*S*3, 2C] pre-activations are
+ * never written.  mode 0: Welford partials [G/cpc][C][2]; 1: out [G*S*3][C]; 2: backward sums partial [G/cpc][C][2]; 3: gbias
+ * [G*3][2C] (per group), part5 [G/cpc][5][2C] (row 3 = dL/dw partials; rows 0-2, 4 unused) and, if gx_part != NULL, dL/dx as one
+ * partial per 64-column block, gx_part [ceil(C/64)][G][S*3] (S <= 16; the caller sums the blocks).  S even for modes 2 and 3;
+ * coarse_per_chunk groups per chunk (divides G; 0 = vnp_chunk_points() / S). */
+int vnp_group_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* w, const float* x, long long G, int S, int C,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                         float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
+                         float* part5, float* gbias, float* gx_part, int coarse_per_chunk);
 
 /* VNLinearLeakyReLU on a map whose VN vectors are all parallel to ONE unit direction u per point (the layer behind VN_PointNet's
  * single-channel first layer, models/pcn.py:165-173 + models/vn_layers.py:46-74), on per-POINT operands:

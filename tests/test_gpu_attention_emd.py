@@ -287,3 +287,48 @@ def test_attention_layouts_agree(lib_built, B, N, C, H):
     o = o.reshape(B, H, N, C // H, 3).permute(0, 2, 4, 1, 3).reshape(B * N * 3, C)
     o.backward(go.double())
     assert relerr(res[False][0], o) < 2e-5 and relerr(res[False][1], xd.grad) < 5e-5
+
+
+@pytest.mark.parametrize("G,S,C,needs_x", [(128, 16, 256, True), (96, 16, 64, False), (64, 4, 128, True)])
+def test_group_fold_fused_equals_the_unfused_layer(lib_built, G, S, C, needs_x):
+    """GroupFoldBnLeakyFn (vnp_group_fold_fused: the folding stages' first layer without its [P*3, 2C] pre-activation tensor) against the
+    same VNLinearLeakyReLU evaluated by VNLinearLeakyFn (outer product + BatchNorm / leaky passes): outputs, running statistics and
+    every gradient — the per-point input's (one partial per 64-column block, summed), the point channel's weight columns, the group
+    features' (through the per-group bias), the group weights', gamma / beta — in training mode, and the outputs in eval mode."""
+    from vn_pointcloudcompletion_amd import ops
+    from vn_pointcloudcompletion_amd.vn_layers import VNLinearLeakyReLU
+    g = torch.Generator().manual_seed(G + S + C)
+    cg = 24
+    x0 = torch.randn(G * S * 3, 1, generator=g).cuda()
+    f0 = torch.randn(G * 3, cg, generator=g).cuda()
+    go = torch.randn(G * S * 3, C, generator=g).cuda()
+    res = {}
+    for fused in (True, False):
+        ops.GROUP_FOLD = fused
+        try:
+            torch.manual_seed(3)
+            layer = VNLinearLeakyReLU(cg + 1, C, dim=4).cuda().train()
+            with torch.no_grad():
+                layer.batchnorm.bn.weight.uniform_(0.5, 1.5); layer.batchnorm.bn.bias.uniform_(-0.3, 0.3)
+            x = x0.clone().requires_grad_(needs_x)
+            f = f0.clone().requires_grad_(True)
+            tr = {}
+            ops.TRACE = tr
+            y = layer.forward_rows(x, global_rows=f, rows_per_group=S * 3, global_first=False)
+            ops.TRACE = None
+            assert ("group_fold_fused" in tr) == fused
+            y.backward(go)
+            grads = [f.grad] + ([x.grad] if needs_x else []) + [p.grad for p in layer.parameters()]
+            stats = [layer.batchnorm.bn.running_mean.clone(), layer.batchnorm.bn.running_var.clone()]
+            layer.eval()
+            with torch.no_grad():
+                ye = layer.forward_rows(x0, global_rows=f0, rows_per_group=S * 3, global_first=False)
+            res[fused] = (y.detach(), grads, stats, ye)
+        finally:
+            ops.GROUP_FOLD, ops.TRACE = True, None
+    assert relerr(res[True][0], res[False][0]) < 2e-6 and relerr(res[True][3], res[False][3]) < 2e-6
+    for a, b in zip(res[True][2], res[False][2]):
+        assert relerr(a, b) < 1e-6
+    assert len(res[True][1]) == len(res[False][1])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert a.shape == b.shape and relerr(a, b) < 3e-5, (a.shape, relerr(a, b))

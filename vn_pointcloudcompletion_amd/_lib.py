@@ -117,6 +117,7 @@ _SIGNATURES = {
     "vnp_edge_gather_add": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_fold_fused": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll,
                        _vp, _vp, _i],
+    "vnp_group_fold_fused": [_i, _vp, _i, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _vp, _vp, _i],
     "vnp_vn_dir_layer": [_i, _vp, _i, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _i, _vp],
     "vnp_vn_dir_layer_ex": [_i, _vp, _i, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _i, _vp, _i],
     "vnp_unit_dirs": [_vp, _ll, _vp],

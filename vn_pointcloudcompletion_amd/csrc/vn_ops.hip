@@ -811,6 +811,10 @@ struct VnpFoldArgs {
     const float* sums; float inv_count;   // MODE 3: reduced sums [C][2] (nullptr in eval mode)
     float* part5;                         // MODE 3: [nchunk][5][2C]
     float* gcoarse;                       // MODE 3: [B*Mc][3], zero-filled, atomically accumulated
+    // GRP (vnp_group_fold_fused): bias rows per COARSE point (group) instead of per sample, seed_batched = 2: seed points per coarse
+    // point; coarse == nullptr: no coarse term
+    float* gbias_cp;                      // MODE 3, GRP: dL/dbias per coarse point [B*Mc*3][2C]
+    float* gx_part;                       // MODE 3, GRP: dL/dseed per point, one partial per column block [C/64][B*Mc][S*3] (or nullptr)
 };
 
 // two-lane helpers of the packed backward body (PK): one thread evaluates two seed points per step on v_pk_*_f32
@@ -820,10 +824,16 @@ __device__ __forceinline__ vnp_f2 vnp_sqrt2(vnp_f2 v) { return VNP_GRAD_HW ? vnp
 
 // PK (backward modes, even S): the loop over a coarse point's S seed points takes two per step with packed fp32 arithmetic — the same
 // formulas lane by lane; only the order in which the per-thread sums collect their terms changes (even and odd seed points separately)
-template <int MODE, bool PK = false>
+#define VNP_GRP_MAXS 16          // GRP, MODE 3 with gx_part: seed points per coarse point (LDS transpose of S * 3 values x 64 columns per wave)
+template <int MODE, bool PK = false, bool GRP = false>
 __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a)
 {
     static_assert(!PK || MODE >= 2, "the packed body exists for the backward modes");
+    static_assert(!GRP || MODE < 2 || PK, "the per-group form of the backward modes exists in the packed body only (even S)");
+    // GRP, MODE 3: dL/dseed[point][t] = sum over ALL columns of (dL/dp w_f + dL/dd w_d): every lane parks its column's S * 3 terms in LDS
+    // (wave-private rows), then lane i < S * 3 sums row i over the 64 columns: a transpose-reduce for ~130 instructions per coarse
+    // point instead of 6 shuffle steps per value (~600)
+    __shared__ float xpose[(GRP && MODE == 3) ? 4 : 1][(GRP && MODE == 3) ? VNP_GRP_MAXS * 3 : 1][(GRP && MODE == 3) ? 65 : 1];
     // the backward modes (gradients) use v_rcp_f32 / v_sqrt_f32 (1 ulp each) where the forward modes keep IEEE division and sqrtf so that statistics and
     // outputs stay bit-identical to the unfused path
 #define FDIV(a, b) ((MODE >= 2 && VNP_GRAD_HW) ? (a) * __builtin_amdgcn_rcpf(b) : (a) / (b))
@@ -843,7 +853,8 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     const long long cp1 = min(a.ncoarse, cp0 + cpc);
     float wsf = 0, wcf = 0, wsd = 0, wcd = 0, mu = 0, rs = 0, ga = 0, be = 0;
     if (live) {
-        wsf = a.wseed[j]; wcf = a.wcoarse[j]; wsd = a.wseed[C + j]; wcd = a.wcoarse[C + j];
+        wsf = a.wseed[j]; wsd = a.wseed[C + j];
+        if (!GRP || a.wcoarse) { wcf = a.wcoarse[j]; wcd = a.wcoarse[C + j]; }
         if (a.mean) { mu = a.mean[j]; rs = a.rstd[j]; ga = a.gamma[j]; be = a.beta[j]; }
     }
     const float m1 = (MODE == 3 && a.sums) ? a.sums[2 * (live ? j : 0)] * a.inv_count : 0.f;
@@ -853,14 +864,15 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     double acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};         // MODE 3: [feat|dir][bias t0..2, seed, coarse]
     for (long long cp = cp0 + py; cp < cp1; cp += 4) {
         const int b = (int)(cp / a.Mc);
-        const float c0 = a.coarse[cp * 3], c1 = a.coarse[cp * 3 + 1], c2 = a.coarse[cp * 3 + 2];
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (!GRP || a.coarse) { c0 = a.coarse[cp * 3]; c1 = a.coarse[cp * 3 + 1]; c2 = a.coarse[cp * 3 + 2]; }
         float pf[3] = {0, 0, 0}, pdv[3] = {0, 0, 0};
         if (live) {
-            const float* bb = a.bias + (size_t)b * 3 * a.ldb;
+            const float* bb = a.bias + (size_t)(GRP ? cp : (long long)b) * 3 * a.ldb;
             pf[0] = bb[j] + wcf * c0; pf[1] = bb[a.ldb + j] + wcf * c1; pf[2] = bb[2 * a.ldb + j] + wcf * c2;
             pdv[0] = bb[C + j] + wcd * c0; pdv[1] = bb[a.ldb + C + j] + wcd * c1; pdv[2] = bb[2 * a.ldb + C + j] + wcd * c2;
         }
-        const float* sd = a.seed + (a.seed_batched ? (size_t)b * S * 3 : 0);
+        const float* sd = a.seed + (a.seed_batched == 2 ? (size_t)cp * S * 3 : a.seed_batched ? (size_t)b * S * 3 : 0);
         float gc0 = 0.f, gc1 = 0.f, gc2 = 0.f;                     // MODE 3: dcoarse contributions of this column
         // (measured: `#pragma unroll 4` here — more gradient loads in flight — costs registers instead: mode 3 0.99 -> 1.16 ms,
         // mode 2 0.52 -> 0.69 ms)
@@ -917,6 +929,11 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
                 vacc[1][3] += h0 * e0 + h1 * e1 + h2 * e2;
                 vacc[1][4] += h0 * c0 + h1 * c1 + h2 * c2;
                 vgc0 += r0 * wcf + h0 * wcd; vgc1 += r1 * wcf + h1 * wcd; vgc2 += r2 * wcf + h2 * wcd;
+                if (GRP && MODE == 3 && a.gx_part) {
+                    const vnp_f2 y0 = r0 * wsf + h0 * wsd, y1 = r1 * wsf + h1 * wsd, y2 = r2 * wsf + h2 * wsd;
+                    xpose[py][s * 3 + 0][cx] = y0[0]; xpose[py][s * 3 + 1][cx] = y1[0]; xpose[py][s * 3 + 2][cx] = y2[0];
+                    xpose[py][s * 3 + 3][cx] = y0[1]; xpose[py][s * 3 + 4][cx] = y1[1]; xpose[py][s * 3 + 5][cx] = y2[1];
+                }
             }
             s1 += (double)vs1[0] + (double)vs1[1]; s2 += (double)vs2[0] + (double)vs2[1];
 #pragma unroll
@@ -924,6 +941,25 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
 #pragma unroll
                 for (int r = 0; r < 5; ++r) acc[h][r] += (double)vacc[h][r][0] + (double)vacc[h][r][1];
             gc0 = vgc0[0] + vgc0[1]; gc1 = vgc1[0] + vgc1[1]; gc2 = vgc2[0] + vgc2[1];
+            if (GRP && MODE == 3) {
+                if (live) {                                        // dL/dbias of THIS coarse point (the bias is per group here)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            a.gbias_cp[((size_t)cp * 3 + t) * 2 * C + h * C + j] = vacc[h][t][0] + vacc[h][t][1];
+                }
+                if (a.gx_part) {
+                    __builtin_amdgcn_wave_barrier();               // wave-private LDS rows: the wave's own writes above, in program order
+                    if (cx < S * 3) {
+                        float v = 0.f;
+#pragma unroll 8
+                        for (int q = 0; q < 64; ++q) v += xpose[py][cx][q];
+                        a.gx_part[((size_t)blockIdx.x * a.ncoarse + cp) * (S * 3) + cx] = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         } else
         for (int s = 0; s < S; ++s) {
             const float e0 = sd[s * 3], e1 = sd[s * 3 + 1], e2 = sd[s * 3 + 2];
@@ -976,7 +1012,7 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
             acc[1][4] += h0 * c0 + h1 * c1 + h2 * c2;
             gc0 += r0 * wcf + h0 * wcd; gc1 += r1 * wcf + h1 * wcd; gc2 += r2 * wcf + h2 * wcd;
         }
-        if (MODE == 3) {
+        if (MODE == 3 && !GRP) {
             // dcoarse[cp][t] = sum over columns (this wave's 64, then the other column tiles through atomics)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { gc0 += __shfl_xor(gc0, o); gc1 += __shfl_xor(gc1, o); gc2 += __shfl_xor(gc2, o); }
@@ -1045,6 +1081,7 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
     a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
     a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo; a.partial = (float2*)partial;
     a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f; a.part5 = part5; a.gcoarse = gcoarse;
+    a.gbias_cp = nullptr; a.gx_part = nullptr;
     a.cpc = cpc;
     const int nchunk = vnp_cdiv((long long)B * Mc, cpc);
     if (nchunk > 65535) return VNP_EINVAL;
@@ -1060,6 +1097,47 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
         if (S % 2 == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<3, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((vnp_fold_fused_kernel<3>), grid, block, 0, st, a);
     }
+    return vnp_last_error();
+}
+
+// The same four passes for a layer whose per-point input is ONE VN channel x [G][S][3] beside per-GROUP features (Attention_VN_FoldingNet's
+// folding stages, models/pcn.py:486-488: cat([point, per-centre features]) -> VNLinearLeakyReLU(385, 256)):
+//   p | d [point (g, s)][t][j] = bias[g*3 + t][j | C + j] + w[j | C + j] * x[g][s][t]
+// with bias [G*3][2C] = the group features times their weight columns (a 49152-row GEMM) and w [2C] the weight column of the point
+// channel.  Nothing of the [G*S*3, 2C] pre-activation tensor is written or read (it was an outer-product launch, a statistics pass, the
+// BatchNorm / leaky forward and two backward passes over 1.6 GB each, a column-sum pass for the bias gradient and a matrix-vector
+// pass for the input gradient).  mode 3 writes dL/dbias per group (gbias [G*3][2C]), the per-chunk partials of dL/dw (part5 row 3)
+// and, when gx_part is given, dL/dx as one partial per 64-column block (gx_part [ceil(C/64)][G][S*3]; S <= 16): deterministic.
+// S even; chunk = coarse_per_chunk groups (must divide G; 0 = vnp_chunk_points() / S).
+extern "C" int vnp_group_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* w, const float* x, long long G, int S, int C,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
+                                    float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
+                                    float* part5, float* gbias, float* gx_part, int coarse_per_chunk)
+{
+    if (!bias || !w || !x || G <= 0 || S <= 0 || C <= 0 || G > 2147483647LL) return VNP_EINVAL;
+    const int cpc = coarse_per_chunk > 0 ? coarse_per_chunk : (VNP_CHUNK % S == 0 ? VNP_CHUNK / S : 0);
+    if (cpc <= 0 || G % cpc || (long long)cpc * S > VNP_CHUNK) return VNP_EINVAL;
+    if (mode < 0 || mode > 3) return VNP_EINVAL;
+    if (mode > 0 && (!mean || !rstd || !gamma || !beta)) return VNP_EINVAL;
+    if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
+    if (mode == 1 && !out) return VNP_EINVAL;
+    if (mode >= 2 && (!go || S % 2)) return VNP_EINVAL;
+    if (mode == 3 && (!part5 || !gbias || (gx_part && S > VNP_GRP_MAXS))) return VNP_EINVAL;
+    VnpFoldArgs a;
+    a.bias = bias; a.ldb = ldb; a.wseed = w; a.wcoarse = nullptr; a.seed = x; a.seed_batched = 2;
+    a.coarse = nullptr; a.Mc = (int)G; a.S = S; a.C = C; a.ncoarse = G;
+    a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
+    a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo; a.partial = (float2*)partial;
+    a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f; a.part5 = part5; a.gcoarse = nullptr;
+    a.gbias_cp = gbias; a.gx_part = gx_part;
+    a.cpc = cpc;
+    const long long nchunk = G / cpc;
+    if (nchunk > 65535) return VNP_EINVAL;
+    dim3 grid(vnp_cdiv(C, 64), (unsigned)nchunk), block(256);
+    if (mode == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<0, false, true>), grid, block, 0, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((vnp_fold_fused_kernel<1, false, true>), grid, block, 0, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((vnp_fold_fused_kernel<2, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((vnp_fold_fused_kernel<3, true, true>), grid, block, 0, st, a);
     return vnp_last_error();
 }
 

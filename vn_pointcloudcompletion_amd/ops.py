@@ -1302,6 +1302,80 @@ class FoldBnLeakyFn(Function):
         return (gbias, gws, gwc, None, gcoarse if ctx.needs_input_grad[4] else None, planar[1], planar[0], None, None, None, None)
 
 
+GROUP_FOLD = os.environ.get("VNP_NO_GROUP_FOLD", "0") != "1"      # A/B: the unfused form (outer product + BatchNorm / leaky passes over p | d)
+
+
+def group_fold_ok(x_cols, S, C):
+    """Can GroupFoldBnLeakyFn take a VNLinearLeakyReLU whose per-point input has ``x_cols`` channels, S points per group and C outputs?"""
+    return GROUP_FOLD and x_cols == 1 and S % 2 == 0 and 2 <= S <= 16 and S <= _lib.chunk_points()
+
+
+class GroupFoldBnLeakyFn(Function):
+    """VNLinearLeakyReLU on cat([x, group features]) where x is ONE VN channel per point and the features are shared by the S points
+    of a group (Attention_VN_FoldingNet's folding stages, models/pcn.py:486-488; vn_layers.py:46-74), end to end without the
+    [P*3, 2C] pre-activation tensor: p | d = bias[group] + w x[point] is rebuilt inside each of the four passes (vnp_group_fold_fused).
+    x [P*3, 1] rows, w [2C] = [Wf[:, x] | Wd[:, x]], bias [G*3, 2C] = group features times their weight columns (VNLinearFn).
+    Replaces, per stage and step: an outer-product launch writing 1.6 GB, a statistics pass, the BatchNorm / leaky forward, two
+    backward passes, a column-sum pass (bias gradient) and a matrix-vector pass (input gradient) over that tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, S, gamma, beta, running_mean, running_var, training, ns):
+        bias = _rows(bias)
+        x = x.reshape(-1).contiguous()
+        w = w.contiguous()
+        C = bias.shape[1] // 2
+        G = bias.shape[0] // 3
+        P = G * S
+        if x.numel() != P * 3 or w.numel() != 2 * C:
+            raise _lib.VnpError(f"group fold: x {tuple(x.shape)}, w {tuple(w.shape)}, bias {tuple(bias.shape)}, S = {S} do not fit")
+        dev = bias.device
+        cpc = FoldBnLeakyFn.coarse_per_chunk(G, S)
+        nch = G // cpc
+        args = (ptr(bias), _ld(bias), ptr(w), ptr(x), G, S, C)
+        if training:
+            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_group_fold_fused", 0, *args, None, None, None, None, ns, None, 0, None, 0, ptr(part), None, 0, None, None, None, cpc)
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize_chunked", ptr(part), nch, cpc * S, C, P, ptr(mean), ptr(rstd), ptr(running_mean),
+                 ptr(running_var), BN_MOMENTUM, BN_EPS)
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+        out = torch.empty((P * 3, C), device=dev, dtype=torch.float32)
+        _trace("group_fold_fused")
+        call("vnp_group_fold_fused", 1, *args, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns, ptr(out), C, None, 0, None, None, 0,
+             None, None, None, cpc)
+        ctx.save_for_backward(x, w, bias, gamma, beta, mean, rstd)
+        ctx.cfg = (G, S, C, training, ns, cpc)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, w, bias, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, S, C, training, ns, cpc = ctx.cfg
+        go = _rows(go)
+        dev = go.device
+        P = G * S
+        nch = G // cpc
+        args = (ptr(bias), _ld(bias), ptr(w), ptr(x), G, S, C)
+        bn = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns)
+        part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+        call("vnp_group_fold_fused", 2, *args, *bn, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, None, None, cpc)
+        Ssum, planar = reduce_pairs(part, nch, C)
+        part5 = torch.empty((nch, 5, 2 * C), device=dev, dtype=torch.float32)
+        gbias = torch.empty((G * 3, 2 * C), device=dev, dtype=torch.float32)
+        ncb = (C + 63) // 64
+        gx_part = torch.empty((ncb, P * 3), device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        call("vnp_group_fold_fused", 3, *args, *bn, None, 0, ptr(go), _ld(go), None, ptr(Ssum) if training else None, P,
+             ptr(part5), ptr(gbias), ptr(gx_part), cpc)
+        gw = reduce_rows(part5[:, 3, :].contiguous(), 1, nch, 2 * C)[0]
+        gx = reduce_rows(gx_part, 1, ncb, P * 3).view(P * 3, 1) if gx_part is not None else None
+        return gx, gw, gbias, None, planar[1], planar[0], None, None, None, None
+
+
 class LinOutFn(Function):
     """Final VNLinear(C -> 1) plus the residual point_feat (models/pcn.py:346,387):
     fine[(b*Md+m)*3+t] = sum_c x[.., c] w[c] + coarse[b, m // S, t]."""

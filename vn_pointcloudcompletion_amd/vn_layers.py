@@ -149,6 +149,12 @@ class VNLinearLeakyReLU(nn.Module):
         if pre_linear is not None:
             ops._trace("linear_folded_onto_producer")
             Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
+        if (bias is not None and pre_linear is None and rows_per_group % 3 == 0 and rows.dim() == 2
+                and ops.group_fold_ok(rows.shape[1], rows_per_group // 3, Wf.shape[0])):
+            # ONE per-point VN channel beside per-group features (the attention decoder's folding stages): all passes rebuild
+            # p | d = bias[group] + w x[point] in registers instead of streaming a [P*3, 2C] tensor six times
+            return ops.GroupFoldBnLeakyFn.apply(rows, torch.cat([Wf[:, 0], Wd[:, 0]]), bias, rows_per_group // 3, bn.weight, bn.bias,
+                                                bn.running_mean, bn.running_var, self.training, self.negative_slope)
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                          rows_per_group, self.training, self.negative_slope, pre_linear is not None)
 
