@@ -332,3 +332,34 @@ def test_group_fold_fused_equals_the_unfused_layer(lib_built, G, S, C, needs_x):
     assert len(res[True][1]) == len(res[False][1])
     for a, b in zip(res[True][1], res[False][1]):
         assert a.shape == b.shape and relerr(a, b) < 3e-5, (a.shape, relerr(a, b))
+
+
+def test_attention_decoder_fused_stage_tails_equal_layer_by_layer(lib_built):
+    """Attention_VN_FoldingNet with each folding stage's VNLinearLeakyReLU(256, 128) + VNLinear(128, 1) as one function
+    (ops.VNLinearLeakyOutFn without a residual) against the layer-by-layer evaluation: outputs and every parameter gradient."""
+    from vn_pointcloudcompletion_amd import ops
+    from vn_pointcloudcompletion_amd.attention_decoder import Attention_VN_FoldingNet
+    g = torch.Generator().manual_seed(11)
+    coarse = (torch.rand(2, 128, 3, generator=g) - 0.5).cuda()
+    feat = torch.randn(2, 2048, 3, generator=g).cuda()
+    go = torch.randn(2, 128 * 16, 3, generator=g).cuda()
+    res = {}
+    for fused in (True, False):
+        Attention_VN_FoldingNet.FUSED_TAIL = fused
+        try:
+            torch.manual_seed(4)
+            dec = Attention_VN_FoldingNet(SimpleNamespace(num_coarse=128, latent_dim=2048)).cuda().train()
+            c = coarse.clone().requires_grad_(True)
+            tr = {}
+            ops.TRACE = tr
+            out = dec(c, feat)
+            ops.TRACE = None
+            assert tr.get("decoder_tail_fused", 0) == (2 if fused else 0) and tr.get("group_fold_fused", 0) == 2
+            out.backward(go)
+            res[fused] = (out.detach(), c.grad, [(n, p.grad) for n, p in dec.named_parameters() if p.grad is not None])
+        finally:
+            Attention_VN_FoldingNet.FUSED_TAIL, ops.TRACE = True, None
+    assert relerr(res[True][0], res[False][0]) < 5e-6 and relerr(res[True][1], res[False][1]) < 5e-5
+    assert [n for n, _ in res[True][2]] == [n for n, _ in res[False][2]]
+    for (n, a), (_, b) in zip(res[True][2], res[False][2]):
+        assert relerr(a, b) < 1e-4, (n, relerr(a, b))

@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import ops
 from .pcn import global_to_rows
 from .transformer import VN_Block, tokens_to_rows
 from .vn_layers import VNLinear, VNLinearLeakyReLU
@@ -38,11 +39,21 @@ class Attention_VN_FoldingNet(nn.Module):
         self.vn_folding2 = nn.Sequential(VNLinearLeakyReLU(in_channel + 1, hidden_dim, dim=4),
                                          VNLinearLeakyReLU(hidden_dim, hidden_dim // 2, dim=4), VNLinear(hidden_dim // 2, 1))
 
-    @staticmethod
-    def _fold(stage, point_rows, feat_rows, S):
+    FUSED_TAIL = True        # stage[1] + stage[2] as one function (ops.VNLinearLeakyOutFn); False: layer by layer (tests)
+
+    @classmethod
+    def _fold(cls, stage, point_rows, feat_rows, S):
         h = stage[0].forward_rows(point_rows, global_rows=feat_rows, rows_per_group=S * 3, global_first=False)
-        h = stage[1].forward_rows(h)
-        return stage[2].forward_rows(h)                                                              # [P*3, 1]
+        l1, l2 = stage[1], stage[2]
+        if not cls.FUSED_TAIL:
+            return l2.forward_rows(l1.forward_rows(h))                                               # [P*3, 1]
+        # VNLinearLeakyReLU(256, 128) + VNLinear(128, 1) fused as in VN_FoldingNet's tail: the 128-channel activation between them and
+        # its gradient are never stored (the upstream gradient of that activation is rank one: g_fold[r] * w_out[c])
+        bn1 = l1.batchnorm.bn
+        l1.batchnorm._tick()
+        fd = ops.VNLinearLeakyOutFn.apply(h, l1.map_to_feat.weight, l1.map_to_dir.weight, bn1.weight, bn1.bias, bn1.running_mean,
+                                          bn1.running_var, l2.map_to_feat.weight, None, S, l1.training, l1.negative_slope)
+        return fd.view(-1, 1)                                                                        # [P*3, 1]
 
     def forward(self, coarse, feature_global, rot=None):
         bs, N, _ = coarse.shape

@@ -834,13 +834,13 @@ class VNLinearLeakyOutFn(Function):
             rstd = torch.empty(C, device=dev, dtype=torch.float32)
             call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
         w = w_out.reshape(-1).contiguous()
-        coarse = coarse.contiguous()
+        coarse = coarse.contiguous() if coarse is not None else None          # None: no residual (the attention decoder's folding stages)
         fine = torch.empty(R, device=dev, dtype=torch.float32)
         _trace("decoder_tail_fused")
         call("vnp_vn_bn_leaky_rowdot_fwd", ptr(p), _ld(p), ptr(d), _ld(d), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-             ptr(w), ptr(coarse), S, ptr(fine))
+             ptr(w), ptr(coarse), S if coarse is not None else 0, ptr(fine))
         ctx.save_for_backward(x, Wcat, gamma, beta, pd, mean, rstd, w)
-        ctx.cfg = (C, S, tuple(coarse.shape), training, ns)
+        ctx.cfg = (C, S, tuple(coarse.shape) if coarse is not None else None, training, ns)
         return fine
 
     @staticmethod
@@ -853,8 +853,10 @@ class VNLinearLeakyOutFn(Function):
                                                     go_row=g, go_col=w, want_gw=True)
         gx = _dgrad(gpd, Wcat) if ctx.needs_input_grad[0] else None
         gW = _wgrad(gpd, x)
-        gcoarse = torch.empty(cshape, device=g.device, dtype=torch.float32)
-        call("vnp_group_sum3", ptr(g), g.numel() // 3 // S, S, ptr(gcoarse), 0)
+        gcoarse = None
+        if cshape is not None and ctx.needs_input_grad[8]:
+            gcoarse = torch.empty(cshape, device=g.device, dtype=torch.float32)
+            call("vnp_group_sum3", ptr(g), g.numel() // 3 // S, S, ptr(gcoarse), 0)
         return gx, gW[:C], gW[C:], ggamma, gbeta, None, None, gw.reshape(1, C), gcoarse, None, None, None
 
 
