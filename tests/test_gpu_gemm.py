@@ -411,3 +411,19 @@ def test_tile_choice_changes_time_not_bits(lib_built, M, N, K, op_b):
             ref[r:r + 3072, c:c + 128] = ops.gemm(A[r:r + 3072], Bc, op_b=op_b, nsplit=1, bias=zero, rows_per_group=3072)
     assert torch.equal(got, ref), rows
     assert relerr(got, A.double() @ (B.double().t() if op_b == 0 else B.double())) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,nsplit", [(512, 256, 32 * 4096, 64), (256, 256, 32 * 2048, 128), (768, 384, 32 * 900, 14), (1536, 128, 32 * 600, 64)])
+def test_wide_weight_gradient_kernel_is_the_narrow_kernel_bit_for_bit(lib_built, M, N, K, nsplit):
+    """Weight gradients (A [K, M], B [K, N]) whose 256 x 128 tiles fill whole rounds run on vnp_gemm_split_wide_tn_kernel (512 threads);
+    the same product taken 128 output rows at a time (M = 128: no 256-row tile) runs on vnp_gemm_split_kernel<128, 128, false, false>.
+    Same LDS image per 128-row block, same products in the same order, same K-slices: the same words after the (double) slab reduction."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(K, M, generator=g) * torch.exp2(torch.randint(-4, 5, (K, 1), generator=g).float())).cuda()
+    B = torch.randn(K, N, generator=g).cuda()
+    wide = ops.gemm(A, B, op_a=1, op_b=1, nsplit=nsplit)
+    narrow = torch.cat([ops.gemm(A[:, r:r + 128].contiguous(), B, op_a=1, op_b=1, nsplit=nsplit) for r in range(0, M, 128)], dim=0)
+    assert torch.equal(wide, narrow)
+    assert relerr(wide, A.double().t() @ B.double()) < 2e-5

@@ -396,6 +396,15 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     }
     else if (op_a == 0 && op_b == 0) VNP_LAUNCH(192, true, true);
     else if (op_a == 0 && op_b == 1) VNP_LAUNCH(192, true, false);
+    else if (op_a == 1 && op_b == 1 && split && fast && !h2 && M % 256 == 0 && !vnp_no_wide() &&
+             (long long)(M / 256) * (N / 128) * nsplit * nbatch >= vnp_num_cus() &&
+             ((long long)(M / 256) * (N / 128) * nsplit * nbatch % vnp_num_cus() == 0 ||
+              (long long)(M / 256) * (N / 128) * nsplit * nbatch >= 4LL * vnp_num_cus())) {
+        // weight gradients whose 256 x 128 tiles fill whole rounds of one 512-thread workgroup per CU: 0.75x the staging work per MFMA,
+        // evenly divided (vnp_gemm_split_wide_tn_kernel); measured +2.5 .. 4 % on the step's shapes, same bits
+        const long long items_w = (long long)(M / 256) * (N / 128) * nsplit * nbatch;
+        hipLaunchKernelGGL((vnp_gemm_split_wide_tn_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
+    }
     else if (op_a == 1 && op_b == 1) VNP_LAUNCH(128, false, false);
     else                             VNP_LAUNCH(128, false, true);
 #undef VNP_LAUNCH
