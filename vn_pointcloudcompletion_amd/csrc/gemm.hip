@@ -874,6 +874,9 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
             // 192 x 256 tiles on eight waves, one workgroup per CU: 0.70x the operand bytes per MFMA (screen_wide_kernel.h); same slots
             const long long iw = (M / 192) * (2LL * C / 256);
             const long long cw = vnp_num_cus();
+            // tile walk of an XCD: two column tiles (2 x 512 KB of W images) stay in its L2 while the A panels stream through; with
+            // eight (4 MB = the whole L2) the panels evicted them: 1.99 -> 1.89 ms (measured 1 / 2 / 4 / 8 / 16: 1.90 1.89 1.95 1.99 2.00)
+            p.col_group = 2;
             constexpr int wide_lds = 2 * (2 * (192 * 64 + 128) + 2 * (256 * 64 + 128));          // two stages of a 192 x 256 x 64 fp16 tile
             static std::atomic<unsigned long long> wide_ok{0};
             hipError_t ew = vnp_allow_dynamic_lds(wide_ok, (const void*)vnp_screen_f16_wide_kernel, wide_lds);
