@@ -378,6 +378,7 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
         }
     // chunk boxes -> LDS; the group-box bound of chunk lane + 64 g classifies it: overlapping (0) / apart (> 0)
     unsigned long long near_mask[NG], far_mask[NG];
+    float vfar[NG];                                               // this lane's chunk of group g: squared distance between the two boxes
     float lmin = INFINITY;
     int cmin = 0;
 #pragma unroll
@@ -395,6 +396,7 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
         }
         near_mask[g] = __ballot(c < nchunk && v == 0.f);
         far_mask[g] = __ballot(c < nchunk && v > 0.f);
+        vfar[g] = v * (1.0f - 1e-6f);
         if (v < lmin) { lmin = v; cmin = c; }
     }
 #pragma unroll
@@ -449,12 +451,26 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
         return __any(need);
     };
 
+    // the largest best distance among the wave's queries: a chunk whose BOX-TO-BOX distance from the wave's queries exceeds it cannot hold
+    // a nearer point for any of them (a query lies inside the wave's box, so its own distance to the chunk's box is at least that; the
+    // per-query test below is the same formula term by term, and fp subtraction, multiplication and addition are monotone) — one
+    // compare + ballot settles 64 far chunks at once, and the ~25-instruction per-query test runs only for the few that survive
+    auto wave_max_best = [&]() -> float {
+        float mb = __uint_as_float((unsigned)(best[0] >> 32));
+#pragma unroll
+        for (int u = 1; u < QPT; ++u) mb = fmaxf(mb, __uint_as_float((unsigned)(best[u] >> 32)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mb = fmaxf(mb, __shfl_xor(mb, o));
+        return mb;                                                // (+inf while any query has seen nothing; NaN distances never enter best)
+    };
     visit(c0);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+        float maxbest = (pass == 1 && prune) ? wave_max_best() : INFINITY;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             unsigned long long mask = pass == 0 ? near_mask[g] : far_mask[g];
+            if (pass == 1 && prune) mask &= __ballot(!(vfar[g] > maxbest));
             while (mask) {
                 const int bit = __builtin_ctzll(mask);
                 mask &= mask - 1;
@@ -462,6 +478,10 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
                 if (c == c0) continue;
                 if (prune && !needed(c)) continue;
                 visit(c);
+                if (pass == 1 && prune) {
+                    maxbest = wave_max_best();
+                    mask &= __ballot(!(vfar[g] > maxbest));
+                }
             }
         }
     }
