@@ -1187,7 +1187,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
     float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, m1 = 0.f, m2 = 0.f;
     if (MODE >= 1) { mu = a.mean[cc]; rs = a.rstd[cc]; ga = a.gamma[cc]; be = a.beta[cc]; }
     if (MODE == 3 && a.sums) { m1 = a.sums[2 * cc] * a.inv_count; m2 = a.sums[2 * cc + 1] * a.inv_count; }
-    const float kf = (float)k;
+    const float kf = (float)k, kinv = 1.f / kf;
     float wmean = 0.f, wm2 = 0.f, s1 = 0.f, s2 = 0.f;
     int wn = 0;
     for (long long q = q0 + py; q < q1; q += 4) {
@@ -1197,10 +1197,11 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f;
         if (MODE >= 2) {
             const float* rg = a.go + (size_t)q * 3 * a.ldgo + cc;
-            ge0 = rg[0] / kf; ge1 = rg[a.ldgo] / kf; ge2 = rg[2 * a.ldgo] / kf;           // vnp_mean_pool_bwd: g / gs
+            ge0 = rg[0] * kinv; ge1 = rg[a.ldgo] * kinv; ge2 = rg[2 * a.ldgo] * kinv;     // vnp_mean_pool_bwd: g / gs (gradients: 1 ulp, as EDIV)
         }
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f;                 // MODE 1: sum of outputs; MODE 3: gv (p | d)
         const int* nb = a.nbr + (size_t)q * k;
+#pragma unroll 4
         for (int j = 0; j < k; ++j) {
             const size_t urow = (size_t)nb[j] * 3;
             const float* ru = a.u + urow * a.ldu + cc;
@@ -1306,20 +1307,21 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
     const float mu = a.mean[cc], rs = a.rstd[cc], ga = a.gamma[cc], be = a.beta[cc];
     float m1 = 0.f, m2 = 0.f;
     if (a.sums) { m1 = a.sums[2 * cc] * a.inv_count; m2 = a.sums[2 * cc + 1] * a.inv_count; }
-    const float kf = (float)a.k;
+    const float kinv = 1.f / (float)a.k;
     for (long long sp = s0; sp < s1; ++sp) {
         const float* ru = a.u + (size_t)sp * 3 * a.ldu + cc;
         const float up0 = ru[0], up1 = ru[a.ldu], up2 = ru[2 * a.ldu];
         const float ud0 = ru[C], ud1 = ru[a.ldu + C], ud2 = ru[2 * a.ldu + C];
         double F0 = 0.0, F1 = 0.0, F2 = 0.0, E0 = 0.0, E1 = 0.0, E2 = 0.0;
         const int e1 = rstart[sp + 1];
+#pragma unroll 2
         for (int e = rstart[sp] + py; e < e1; e += 4) {
             const size_t q = (size_t)rev[e];
             const float* rv = a.v + q * 3 * a.ldv + cc;
             const float* rg = a.go + q * 3 * a.ldgo + cc;
             const float x0 = up0 + rv[0], x1 = up1 + rv[a.ldv], x2 = up2 + rv[2 * a.ldv];
             const float d0 = ud0 + rv[C], d1 = ud1 + rv[a.ldv + C], d2 = ud2 + rv[2 * a.ldv + C];
-            const float ge0 = rg[0] / kf, ge1 = rg[a.ldgo] / kf, ge2 = rg[2 * a.ldgo] / kf;
+            const float ge0 = rg[0] * kinv, ge1 = rg[a.ldgo] * kinv, ge2 = rg[2 * a.ldgo] * kinv;
             const float pn = ESQRT(vnp_sq3(x0, x1, x2));
             const float n = pn + VNP_EPS;
             const float xh = (n - mu) * rs;
