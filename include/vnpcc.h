@@ -321,6 +321,16 @@ int vnp_group_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, c
                          float* out, int ldo, const float* go, int ldgo, float* partial, const float* sums, long long count,
                          float* part5, float* gbias, float* gx_part, int coarse_per_chunk);
 
+/* ---- non-equivariant baselines ("foldingnet" decoder, "dgcnn_fps" encoder: /root/reference/models/pcn.py:274-317, dgcnn.py:19-161) ----
+ * nn.BatchNorm1d over the point-major rows x [P, C] of a [B, C, N] tensor together with the activation behind it (act: 0 none, 1 ReLU,
+ * 2 LeakyReLU(slope)).  mode 0: Welford partials [ceil(P / vnp_bn1d_chunk_rows())][C][2] (merge with vnp_vn_bn_finalize_chunked, which
+ * also updates the running statistics);  1: y = act((x - mean) rstd gamma + beta);  2: backward sums partials of the same shape
+ * (reduce with vnp_reduce_pairs: S [C][2] = (dL/dbeta, dL/dgamma));  3: y <- dL/dx from gy (sums = S, or NULL in eval mode). */
+int vnp_bn1d_chunk_rows(void);
+int vnp_bn1d_act(hipStream_t st, int mode, const float* x, int ldx, long long P, int C, const float* mean, const float* rstd,
+                 const float* gamma, const float* beta, int act, float slope, float* y, int ldy, const float* gy, int ldgy,
+                 float* partial, const float* sums, long long count);
+
 /* VNLinearLeakyReLU on a map whose VN vectors are all parallel to ONE unit direction u per point (the layer behind VN_PointNet's
  * single-channel first layer, models/pcn.py:165-173 + models/vn_layers.py:46-74), on per-POINT operands:
  *   p[(n,t)][c] = u[n][t] v[n][c] + bias[g(n)*3+t][c],   d[(n,t)][c] = u[n][t] v[n][C+c] + bias[g(n)*3+t][C+c],   g(n) = n / points_per_group

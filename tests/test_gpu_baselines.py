@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, t
+from conftest import load_golden, relerr, t
 
 pytestmark = pytest.mark.gpu
 
@@ -136,3 +136,39 @@ def test_plugin_surface_builds_every_type(lib_built):
     cd_loss_L1(co, c).backward()
     with pytest.raises(Exception):
         PCNNet(cfg, "vn_pointnet++", "foldingnet")                      # models/model.py:20-21
+
+
+@pytest.mark.parametrize("P,C,act,slope", [(5000, 96, 1, 0.0), (1027, 130, 2, 0.2), (64, 512, 0, 0.0), (3, 7, 2, 0.01)])
+def test_batchnorm1d_act_kernels_equal_torch(lib_built, P, C, act, slope):
+    """vnp_bn1d_act (BatchNorm1d over point-major rows + ReLU / LeakyReLU / nothing, the glue of the non-equivariant baselines) against
+    torch.nn.functional.batch_norm + the activation in float64: outputs, running statistics (momentum 0.1, unbiased variance), dL/dx,
+    dL/dgamma, dL/dbeta in training mode; outputs and dL/dx in eval mode; ragged chunks, a strided input view."""
+    import torch.nn.functional as F
+    from vn_pointcloudcompletion_amd.baselines import _bn_rows
+    g = torch.Generator().manual_seed(P + C)
+    wide = (torch.randn(P, C + 5, generator=g) * 3 + 1.5).cuda()
+    x0 = wide[:, 2:2 + C]
+    go = torch.randn(P, C, generator=g).cuda()
+
+    def actf(t):
+        return F.relu(t) if act == 1 else F.leaky_relu(t, slope) if act == 2 else t
+    for training in (True, False):
+        torch.manual_seed(1)
+        bn = torch.nn.BatchNorm1d(C).cuda()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2.0)
+        ref = torch.nn.BatchNorm1d(C).cuda().double()
+        ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+        bn.train(training); ref.train(training)
+        x = x0.clone().requires_grad_(True)
+        y = _bn_rows(bn, x, act=act, slope=slope)
+        y.backward(go)
+        xd = x0.double().clone().requires_grad_(True)
+        yd = actf(ref(xd))
+        yd.backward(go.double())
+        assert relerr(y, yd) < 2e-6, training
+        assert relerr(x.grad, xd.grad) < 2e-5, training
+        if training:
+            assert relerr(bn.weight.grad, ref.weight.grad) < 2e-5 and relerr(bn.bias.grad, ref.bias.grad) < 2e-5
+            assert relerr(bn.running_mean, ref.running_mean) < 2e-6 and relerr(bn.running_var, ref.running_var) < 2e-6
+            assert int(bn.num_batches_tracked) == 1

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "vnp_edge_gather_add": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_fold_fused": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll,
                        _vp, _vp, _i],
+    "vnp_bn1d_act": [_i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _ll],
     "vnp_group_fold_fused": [_i, _vp, _i, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _vp, _vp, _i],
     "vnp_vn_dir_layer": [_i, _vp, _i, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _i, _vp],
     "vnp_vn_dir_layer_ex": [_i, _vp, _i, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll, _vp, _i, _vp, _i],
@@ -136,7 +137,7 @@ _SIGNATURES = {
 }
 _NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i, _i],
-              "vnp_gemm_vn_stats_ws_floats": [_ll, _i], "vnp_gemm_tile_rows": [_i, _i, _i, _i, _i, _i]}
+              "vnp_gemm_vn_stats_ws_floats": [_ll, _i], "vnp_gemm_tile_rows": [_i, _i, _i, _i, _i, _i], "vnp_bn1d_chunk_rows": []}
 _RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,
             "vnp_gemm_vn_stats_ws_floats": _ll}
 

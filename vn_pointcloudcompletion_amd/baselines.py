@@ -9,8 +9,10 @@ so the same seed gives the same weights and reference checkpoints load).
 
 These are baselines outside the measured hot path.  Everything with real arithmetic in it runs on libvnpcc — every
 1x1 convolution / linear layer is ``vnp_gemm`` (point-major rows ``[B*N, C]``), neighbour search is ``vnp_knn``, sampling is
-``vnp_fps``, the loss is the HIP Chamfer — and there is no CPU path (CPU tensors raise).  The normalisation / activation /
-max glue between the GEMMs is expressed with ATen ops on the device; as in the VN networks, broadcast input channels are
+``vnp_fps``, the loss is the HIP Chamfer, BatchNorm1d with the ReLU / LeakyReLU behind it is ``vnp_bn1d_act`` (round 3) — and there is
+no CPU path (CPU tensors raise).  What is left in ATen on the device: the EdgeConv's GroupNorm(4) + LeakyReLU + max over the k
+neighbours (its backward is dense over all edges through the group statistics: a kernel family of its own, like the VN EdgeConv's), the
+coarse head's ReLU and the global max; as in the VN networks, broadcast input channels are
 never materialised: the decoder's first layer is a per-sample bias plus a rank-5 per-point term instead of a GEMM over a
 ``[B, 6149, 16384]`` tensor, and EdgeConv is ``W1 x_k[idx] + (W2 - W1) x_q`` (two per-point GEMMs and a gather) instead of a
 GEMM over the k-times larger edge tensor.
@@ -21,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 
 def _linear(rows, weight, bias=None):
@@ -30,11 +32,61 @@ def _linear(rows, weight, bias=None):
     return y if bias is None else y + bias
 
 
-def _bn_rows(bn: nn.BatchNorm1d, rows):
-    """nn.BatchNorm1d of a [B, C, N] tensor, evaluated on its point-major rows [B*N, C] (same statistics)."""
+class _BatchNorm1dActFn(torch.autograd.Function):
+    """nn.BatchNorm1d over point-major rows [P, C] + the activation behind it on libvnpcc (vnp_bn1d_act): Welford statistics merged in
+    double (running statistics updated as torch does), one forward pass, two backward passes with the pre-activation recomputed."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, slope):
+        from .ops import call, ptr, _ld, _rows, reduce_pairs
+        x = _rows(x)
+        P, C = x.shape
+        dev = x.device
+        if training:
+            nch = (P + _lib.lib().vnp_bn1d_chunk_rows() - 1) // _lib.lib().vnp_bn1d_chunk_rows()
+            part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_bn1d_act", 0, ptr(x), _ld(x), P, C, None, None, None, None, act, slope, None, 0, None, 0, ptr(part), None, 0)
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize_chunked", ptr(part), nch, _lib.lib().vnp_bn1d_chunk_rows(), C, P, ptr(mean), ptr(rstd),
+                 ptr(running_mean), ptr(running_var), float(momentum), float(eps))
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, float(eps))
+        y = torch.empty((P, C), device=dev, dtype=torch.float32)
+        call("vnp_bn1d_act", 1, ptr(x), _ld(x), P, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, slope, ptr(y), C, None, 0, None, None, 0)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (training, act, slope)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from .ops import call, ptr, _ld, _rows, reduce_pairs
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, act, slope = ctx.cfg
+        gy = _rows(gy)
+        P, C = x.shape
+        dev = x.device
+        nch = (P + _lib.lib().vnp_bn1d_chunk_rows() - 1) // _lib.lib().vnp_bn1d_chunk_rows()
+        part = torch.empty((nch, C, 2), device=dev, dtype=torch.float32)
+        bn = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), act, slope)
+        call("vnp_bn1d_act", 2, ptr(x), _ld(x), P, C, *bn, None, 0, ptr(gy), _ld(gy), ptr(part), None, 0)
+        S, planar = reduce_pairs(part, nch, C)
+        gx = torch.empty((P, C), device=dev, dtype=torch.float32)
+        call("vnp_bn1d_act", 3, ptr(x), _ld(x), P, C, *bn, ptr(gx), C, ptr(gy), _ld(gy), None, ptr(S) if training else None, P)
+        return gx, planar[1], planar[0], None, None, None, None, None, None, None
+
+
+def _bn_rows(bn: nn.BatchNorm1d, rows, act=0, slope=0.0):
+    """nn.BatchNorm1d of a [B, C, N] tensor, evaluated on its point-major rows [B*N, C] (same statistics), with the activation that
+    follows it (0 none, 1 ReLU, 2 LeakyReLU(slope)) in the same kernels."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return F.batch_norm(rows, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+    training = bn.training or not bn.track_running_stats
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    return _BatchNorm1dActFn.apply(rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, float(slope))
 
 
 class FoldingNet(nn.Module):
@@ -85,8 +137,8 @@ class FoldingNet(nn.Module):
         t_seed = seed @ W0[:, L:L + 2].t()                                                       # [S, 512]   (K = 2: ATen)
         t_coarse = _linear(coarse.reshape(B * Mc, 3), W0[:, L + 2:L + 5])                        # [B*Mc, 512]
         pre = (bias.view(B, 1, 1, -1) + t_coarse.view(B, Mc, 1, -1) + t_seed.view(1, 1, S, -1)).reshape(B * Mc * S, -1)
-        h = torch.relu(_bn_rows(bn0, pre))
-        h = torch.relu(_bn_rows(bn1, _linear(h, c1.weight[:, :, 0], c1.bias)))
+        h = _bn_rows(bn0, pre, act=1)
+        h = _bn_rows(bn1, _linear(h, c1.weight[:, :, 0], c1.bias), act=1)
         point_feat = coarse.unsqueeze(2).expand(-1, -1, S, -1).reshape(B * Mc * S, 3)
         fine = _linear(h, c2.weight[:, :, 0], c2.bias) + point_feat
         return fine.reshape(B, Mc * S, 3)
@@ -154,7 +206,7 @@ class DGCNN_fps(nn.Module):
         f = self._edge_conv(self.layer4, coor_q, f_q, coor, f)                           # [B,128,128]
         n4 = f.shape[1]
         c0, bn, c3 = self.increase_dim[0], self.increase_dim[1], self.increase_dim[3]
-        h = F.leaky_relu(_bn_rows(bn, _linear(f.reshape(B * n4, -1), c0.weight[:, :, 0], c0.bias)), 0.2)
+        h = _bn_rows(bn, _linear(f.reshape(B * n4, -1), c0.weight[:, :, 0], c0.bias), act=2, slope=0.2)
         h = _linear(h, c3.weight[:, :, 0], c3.bias).view(B, n4, -1)
         feature_global = h.max(dim=1)[0]                                                 # [B,1024]
         l0, l2 = self.coarse_pred[0], self.coarse_pred[2]
