@@ -464,7 +464,7 @@ def main():
             import glob
             summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_summary.json")))[-1]
             tr = json.load(open(summ)).get("traffic", {})
-            knames = ("vnp_gemm_split_kernel", "vnp_gemm_split_wide_kernel") if gemm_mode == "split" else ("vnp_gemm_kernel",)
+            knames = ("vnp_gemm_split_kernel", "vnp_gemm_split_wide_kernel", "vnp_gemm_split_wide_tn_kernel") if gemm_mode == "split" else ("vnp_gemm_kernel",)
             fam = [v for k, v in tr.items() if any(n in k for n in knames)]
             num = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam)
             den = sum(v["launches"] for v in fam)
@@ -474,7 +474,7 @@ def main():
             pass
         alg_bytes = sum(4.0 * (m * k + n * k + m * n) for _, _, _, (m, n, k), _, _ in mfma) / max(nlaunch, 1)
         if gemm_mode == "split":
-            kernel = ("vnp_gemm_split_kernel<*> + vnp_gemm_split_wide_kernel<*> (one arithmetic, two tile shapes: fp32 operands split exactly "
+            kernel = ("vnp_gemm_split_kernel<*> + vnp_gemm_split_wide_kernel<*> + vnp_gemm_split_wide_tn_kernel<*> (one arithmetic, three tile shapes: fp32 operands split exactly "
                       "into 3 bf16 terms; 6 x v_mfma_f32_16x16x32_bf16 per fp32 product block, fp32 accumulate)")
             peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
         else:
@@ -501,7 +501,7 @@ def main():
                     "ms_per_step": tot_t / args.steps * 1e3,
                     "timing": "HIP events recorded by the library around each launch of this kernel on its launch stream (vnp_gemm_profile_next): "
                               "kernel time only — no slab reduction, no launch gap; reproduce as sum(2MNK) / sum(duration) over the "
-                              "vnp_gemm_split_kernel and vnp_gemm_split_wide_kernel rows of profiles/rNN_bench_kernel_stats.csv",
+                              "vnp_gemm_split_kernel / vnp_gemm_split_wide_kernel / vnp_gemm_split_wide_tn_kernel rows of profiles/rNN_bench_kernel_stats.csv",
                     "note": ("achieved = EXECUTED fp32-equivalent flops (2MNK of the launches of this kernel; each is six bf16 MFMA products) / "
                              "kernel time.  Not in it: the arg-max pool's screening pass (own kernel, one fp16 product: roofline_other), the "
                              "streaming kernels of the degenerate shapes (roofline_other), slab reductions.  "

@@ -45,3 +45,35 @@ def test_einval_instead_of_launching(lib_built):
     with pytest.raises(_lib.VnpError):
         _lib.call("vnp_fps", 2, 8, ptr(a), 9, ptr(idx))
     torch.cuda.synchronize()                                    # nothing was launched, nothing faulted
+
+
+def test_pack_tensors_table_of_many_sources(lib_built):
+    """vnp_pack_tensors straight through the C ABI: 131 sources (three launches of up to 48 table entries), sizes from 1 to ~1 M elements,
+    NULL sources (zero fill), sources and slices that are not 16-byte aligned; the words between and around the slices stay untouched."""
+    import ctypes
+    import torch
+    from vn_pointcloudcompletion_amd._lib import call
+    g = torch.Generator().manual_seed(9)
+    sizes = [int(s) for s in torch.randint(1, 5000, (128,), generator=g)] + [1 << 20, 3, 1]
+    offs, off = [], 5                                                  # slices start at odd offsets, one guard word between them
+    for n in sizes:
+        offs.append(off)
+        off += n + 1
+    flat = torch.full((off + 7,), 123.0, device="cuda")
+    srcs = []
+    for i, n in enumerate(sizes):
+        if i % 7 == 3:
+            srcs.append(None)
+        else:
+            base = torch.randn(n + 3, generator=g).cuda()
+            srcs.append(base[i % 3:i % 3 + n])                          # misaligned views
+    n = len(sizes)
+    a_src = (ctypes.c_void_p * n)(*[None if s is None else s.data_ptr() for s in srcs])
+    a_off = (ctypes.c_longlong * n)(*offs)
+    a_num = (ctypes.c_longlong * n)(*sizes)
+    call("vnp_pack_tensors", n, ctypes.addressof(a_src), ctypes.addressof(a_off), ctypes.addressof(a_num), flat.data_ptr())
+    want = torch.full((off + 7,), 123.0, device="cuda")
+    for s, o, k in zip(srcs, offs, sizes):
+        want[o:o + k] = 0.0 if s is None else s
+    assert torch.equal(flat, want)
+    call("vnp_pack_tensors", 0, None, None, None, None)                 # an empty table is not an error
