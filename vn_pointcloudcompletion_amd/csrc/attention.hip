@@ -105,7 +105,21 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // a wave walks whole rows / whole head slices, its lanes the contiguous floats inside: the only divisions by run-time values are
     // per slice, not per element (with one flat index per element the kernel was bound by integer division, not by memory)
+    const float* rowsp = TO_HEADS ? src : dst;
+    const bool vec = (C & 3) == 0 && (ld & 3) == 0 && (((uintptr_t)rowsp) & 15) == 0;
     auto rows_side = [&](bool load) {
+        if (vec) {                                                    // float4 per lane, several rows in flight per wave
+            const int c4n = C >> 2;
+#pragma unroll 2
+            for (int pt = wave; pt < cnt * 3; pt += 4) {
+                const size_t g = ((size_t)tok0 * 3 + pt) * ld;
+                for (int c4 = lane; c4 < c4n; c4 += 64) {
+                    if (load) *(vnp_f4*)(tile + pt * C + c4 * 4) = *(const vnp_f4*)(src + g + c4 * 4);
+                    else *(vnp_f4*)(dst + g + c4 * 4) = *(const vnp_f4*)(tile + pt * C + c4 * 4);
+                }
+            }
+            return;
+        }
         for (int pt = wave; pt < cnt * 3; pt += 4) {                  // row pt = 3 p + t of the workgroup's tokens: C contiguous floats
             const size_t g = ((size_t)tok0 * 3 + pt) * ld;
             for (int c = lane; c < C; c += 64) {
@@ -115,6 +129,7 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
         }
     };
     auto heads_side = [&](bool load) {
+#pragma unroll 2
         for (int ph = wave; ph < cnt * H; ph += 4) {                  // head slice (p, h): 3 ch contiguous floats, [cl][t]
             const int p = ph / H, h = ph - p * H;
             const long long tok = tok0 + p;
