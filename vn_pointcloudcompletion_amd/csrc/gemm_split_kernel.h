@@ -104,21 +104,26 @@ __device__ __forceinline__ void vnp_h2_scale(unsigned amax_bits, float& s, float
 //              q ^ 0, (q ^ 1) ^ 3, (q ^ 1) ^ 2, q ^ 1 — distinct.  (g = (row >> 2) & 3, the rounds 1-2 choice, is conflict-free for 16
 //              CONSECUTIVE lanes and two-way conflicted on the real groups: SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE,
 //              profiles/r03_gemm_pmc.txt.)  Writers (ds_write_b64, 16 consecutive lanes): two whole rows, any g.
-//   T  layout: physical row = (row & 3) * R/4 + (row >> 2), g = (row & 3) ^ ((row >> 4) & 3): the row quad picks the bank quarter and
-//              the slot varies inside a quad, so any grouping that takes each row once is conflict-free
-//              (readers: 16 rows; writers: rows 4 m + e for 16 consecutive m)
+//   T  layout: physical row = (row & 3) * R/4 + (row >> 2), g = (row & 3) ^ ((row >> 3) & 3): the row quad picks the bank quarter and
+//              the slot varies inside a quad, so the fragment reads (each row of a 16-row tile once) are conflict-free for any such g.
+//              Writers: a ds_write_b64 is served in groups of 16 CONTIGUOUS lanes over 32 banks (128 bytes), so the 16 lanes of a group
+//              must hit 16 distinct 8-byte units mod 128: with the thread map of vnp_split_m4 / vnp_split_kq a group holds 8
+//              consecutive m4 (rows 4 m4 + e: two 64-byte row parities x four slots through g's (row >> 3) term) x both 8-byte halves
+//              of a slot (kq & 1).  Rounds 1-3 had 16 consecutive m4 per group with ONE half and g from (row >> 4): every store
+//              two-way conflicted (SQ_LDS_BANK_CONFLICT a third of SQ_LDS_IDX_ACTIVE on the weight-gradient kernels).
 template <int R, bool KC>
 __device__ __forceinline__ int vnp_split_row_off(int row, int q)
 {
     if (KC) return row * 64 + ((q ^ ((0 - (row >> 2)) & 3)) << 4);
-    return ((row & 3) * (R / 4) + (row >> 2)) * 64 + ((q ^ (row & 3) ^ ((row >> 4) & 3)) << 4);
+    return ((row & 3) * (R / 4) + (row >> 2)) * 64 + ((q ^ (row & 3) ^ ((row >> 3) & 3)) << 4);
 }
 
 // thread -> tile element maps.  KC (K-contiguous operand): float4 j of thread tid is row tid/8 + 32 j, k = 4 (tid % 8).
 // !KC (row-contiguous operand, R = 128 rows): float4 j is k = 4 kq + j, rows 4 m4 .. 4 m4 + 3, where a wave covers
-// 16 m4 x 4 kq (256-byte runs in memory; 64 distinct 8-byte LDS units per ds_write_b64).
-__device__ __forceinline__ int vnp_split_m4(int tid) { return (tid & 15) + 16 * ((tid >> 6) & 1); }
-__device__ __forceinline__ int vnp_split_kq(int tid) { return ((tid >> 4) & 3) + 4 * (tid >> 7); }
+// 16 m4 x 4 kq (256-byte runs in memory; every group of 16 contiguous lanes 16 distinct 8-byte LDS units per ds_write_b64).
+// tid bit 0: kq bit 0 (which 8-byte half of a 16-byte slot); bits 1-4: m4 bits 0-3; bit 5: kq bit 1; bit 6: m4 bit 4; bit 7: kq bit 2
+__device__ __forceinline__ int vnp_split_m4(int tid) { return ((tid >> 1) & 15) + 16 * ((tid >> 6) & 1); }
+__device__ __forceinline__ int vnp_split_kq(int tid) { return (tid & 1) + 2 * ((tid >> 5) & 1) + 4 * (tid >> 7); }
 
 template <int R, bool KC>
 __device__ __forceinline__ void vnp_split_offsets(int& voff0, int& step, int ld, int tid)
@@ -609,7 +614,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
         const unsigned short* A16 = (const unsigned short*)p.A;
         const unsigned short* B16 = (const unsigned short*)p.B;
         constexpr int BK2 = 2 * BK, AH = BM / 32, BH = BN / 32;          // 16-byte loads per thread and step: row tid/8 + 32 j, slot tid & 7
-        constexpr int APL2 = APL + 128, BPL2 = BPL + 128;                // where the second half-tile lives
+        constexpr int APL2 = APL + 64, BPL2 = BPL + 64;                  // where the second half-tile lives (64 bytes on: see screen_wide_kernel.h)
         const int nkt = p.K / BK2;                                       // (the host guarantees K % 64 == 0)
         int offA[AH], offB[BH];
 #pragma unroll

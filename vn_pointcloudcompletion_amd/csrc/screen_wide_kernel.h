@@ -18,7 +18,10 @@ __global__ void __launch_bounds__(512, 1) vnp_screen_f16_wide_kernel(const VnpGe
     constexpr int BM = 192, BN = 256, BK2 = 64;
     constexpr int TM = 6, TN = 4;                               // 16x16 MFMA tiles per wave: 96 x 64
     constexpr int APL = BM * 64, BPL = BN * 64;                 // bytes per 32-wide half-tile
-    constexpr int APL2 = APL + 128, BPL2 = BPL + 128;           // the second half sits 128 bytes further (bank spread of the 16-byte writes)
+    // the second half sits 64 bytes past the first: a ds_write_b128 is served in groups of 8 contiguous lanes over 32 banks (128 bytes), and
+    // the 8 lanes of a group write one row's four slots for BOTH halves — 128 bytes apart (rounds 2-3) they fell on the same banks
+    // (SQ_LDS_BANK_CONFLICT 0.28 of the LDS cycles of an LDS-bound kernel); the fragment reads only see a uniform shift
+    constexpr int APL2 = APL + 64, BPL2 = BPL + 64;
     constexpr int AH = BM / 64, BH = BN / 64;                   // 16-byte loads per thread and step
     // two stages (2 x 57 KB of dynamic LDS): step kt computes from stage kt & 1 while the next step's operands go into the other one
     constexpr int STAGE = 2 * APL2 + 2 * BPL2;
