@@ -1,8 +1,13 @@
 #!/bin/bash
-# LDS bank conflicts per kernel over a few bench steps (run on the GPU box from the repo root): scripts/experiments/pmc_lds.sh
+# LDS bank conflicts per kernel over a few steps (run on the GPU box from the repo root): scripts/experiments/pmc_lds.sh [config id]
+# (no argument: bench.py = config 2; 3 / 4 / 5: scripts/bench_configs.py)
 root=$(pwd); out=$root/gpurun_out/pmc_lds; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS --output-format csv -d $out/lds -- python3 $root/bench.py --no-cpu-baseline --no-fp32-mode --no-extras --steps 2 --warmup 1 > $out/lds.log 2>&1
+if [ -n "$1" ]; then
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS --output-format csv -d $out/lds -- python3 $root/scripts/bench_configs.py $1 --steps 1 > $out/lds.log 2>&1
+else
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS --output-format csv -d $out/lds -- python3 $root/bench.py --no-cpu-baseline --no-fp32-mode --no-extras --steps 2 --warmup 1 > $out/lds.log 2>&1
+fi
 cd $root
 python3 - <<'PY'
 import csv, glob, collections

@@ -98,7 +98,7 @@ template <bool TO_HEADS>
 __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H, int PN,
                                                               int ldh)
 {
-    extern __shared__ float tile[];                  // [PN][3][C] in the rows' order
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [PN][3][C] in the rows' order
     const int ch = C / H, Dh = ch * 3, per = 3 * C;
     const long long tok0 = (long long)blockIdx.x * PN, ntok = (long long)B * N;
     const int cnt = (int)(ntok - tok0 < PN ? ntok - tok0 : PN);
@@ -128,20 +128,32 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
             }
         }
     };
+    // heads side: lane = channel c = h ch + cl of a token; it moves the three components [t] of that channel — three LDS words a row
+    // (C words) apart, consecutive lanes on consecutive words: conflict-free — to / from the 12 contiguous bytes [cl][0..2] of head h's
+    // slice.  (The first LDS form of this kernel walked a slice with lane = cl * 3 + t: three lanes per bank, SQ_LDS_BANK_CONFLICT at two
+    // thirds of its LDS cycles.)  No division per element: (h, cl) advance with c.
     auto heads_side = [&](bool load) {
-#pragma unroll 2
-        for (int ph = wave; ph < cnt * H; ph += 4) {                  // head slice (p, h): 3 ch contiguous floats, [cl][t]
-            const int p = ph / H, h = ph - p * H;
+        const int pad = ldh - Dh;
+        for (int p = wave; p < cnt; p += 4) {
             const long long tok = tok0 + p;
             const int b = (int)(tok / N), n = (int)(tok - (long long)b * N);
-            const size_t g = (((size_t)b * H + h) * N + n) * ldh;             // slices of ldh >= Dh floats: [Dh, ldh) is zero padding
-            const int base = p * per + h * ch;
-            for (int r = lane; r < Dh; r += 64) {
-                const int cl = r / 3, t = r - cl * 3;
-                if (load) tile[base + t * C + cl] = src[g + r];
-                else dst[g + r] = tile[base + t * C + cl];
+            const size_t g0 = ((size_t)b * H * N + n) * ldh;                  // slice of head 0; head h: + h N ldh
+            const float* tp = tile + p * per;
+            int h = lane / ch, cl = lane - h * ch;
+#pragma unroll 2
+            for (int c = lane; c < C; c += 64) {
+                const size_t g = g0 + (size_t)h * N * ldh + cl * 3;
+                if (load) {
+                    const float v0 = src[g], v1 = src[g + 1], v2 = src[g + 2];
+                    tile[p * per + c] = v0; tile[p * per + C + c] = v1; tile[p * per + 2 * C + c] = v2;
+                } else {
+                    dst[g] = tp[c]; dst[g + 1] = tp[C + c]; dst[g + 2] = tp[2 * C + c];
+                }
+                cl += 64;
+                while (cl >= ch) { cl -= ch; ++h; }
             }
-            if (!load) for (int r = Dh + lane; r < ldh; r += 64) dst[g + r] = 0.f;
+            if (!load && pad > 0)
+                for (int i = lane; i < H * pad; i += 64) { const int hh = i / pad, r = i - hh * pad; dst[g0 + (size_t)hh * N * ldh + Dh + r] = 0.f; }
         }
     };
     if (TO_HEADS) { rows_side(true); __syncthreads(); heads_side(false); }
@@ -155,21 +167,26 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
 // feature-major side runs of 64 consecutive tokens.
 template <bool TO_HEADS>
 __global__ void __launch_bounds__(256) vnp_head_permute_fm_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H,
-                                                                 int FR, int TT, int vec)
+                                                                 int FR, int TT, int vec, int TS)
 {
-    extern __shared__ float tile[];                  // [TT][3 ch + 1] in the rows' order [t][cl], TT <= 64 tokens
-    const int ch = C / H, Dh = ch * 3, TS = Dh + 1;
+    extern __shared__ __attribute__((aligned(16))) float tile[];      // [TT][TS] in the rows' order [t][cl], TT <= 64 tokens
+    const int ch = C / H, Dh = ch * 3;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int n0 = blockIdx.x * TT, cnt = N - n0 < TT ? N - n0 : TT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // rows side: a (token, component) segment is ch contiguous floats of one row.  vec: ch % 4 == 0 and 16-byte aligned rows — a wave
-    // moves 64 / (ch / 4) segments per instruction as float4 (five 192-byte segments at ch = 48) instead of one with ch of its lanes;
-    // the loops are unrolled so that several loads are in flight per wave (one segment per trip was a chain of dependent round trips).
-    auto rows_side = [&](bool load) {
+    // vec (ch % 4 == 0, 16-byte aligned rows; TS % 4 == 0 with TS / 4 odd): every LDS access is 16 bytes wide and conflict-free —
+    //   rows side: a (token, component) segment is ch contiguous floats of one row; a wave moves 64 / (ch / 4) segments per instruction
+    //     as float4 (ds_write_b128: 8 contiguous lanes = 128 contiguous bytes);
+    //   feature-major side: lane = token reads four consecutive words [t][cl .. cl + 3] of its own row (ds_read_b128: the 16 lanes
+    //     of a group are 16 distinct tokens mod 16, their addresses n * TS words apart with TS / 4 odd: 16 distinct 16-byte units) and
+    //     stores them to the four feature rows (cl + j) * 3 + t, each a run of TT consecutive tokens.
+    // (The first form of this kernel — scalar LDS words at a stride of 3 ch + 1 — had SQ_LDS_BANK_CONFLICT at half of its LDS cycles.)
+    // Loops are unrolled so that several loads are in flight per wave.
+    if (vec) {
+        const int q4 = ch >> 2, per = 64 / q4, sl = lane / q4, quad = lane - sl * q4;
+        const bool on = sl < per;
         const int nseg = cnt * 3;
-        if (vec) {
-            const int q4 = ch >> 2, per = 64 / q4, sl = lane / q4, quad = lane - sl * q4;
-            const bool on = sl < per;
+        auto rows_side = [&](bool load) {
 #pragma unroll 4
             for (int s0 = wave * per; s0 < nseg; s0 += 4 * per) {
                 const int seg = s0 + sl;
@@ -177,25 +194,50 @@ __global__ void __launch_bounds__(256) vnp_head_permute_fm_kernel(const float* _
                     const int n = seg / 3, t = seg - n * 3;
                     const size_t g = (((size_t)b * N + n0 + n) * 3 + t) * ld + h * ch + quad * 4;
                     float* tp = tile + n * TS + t * ch + quad * 4;
-                    if (load) { const vnp_f4 v = *(const vnp_f4*)(src + g); tp[0] = v[0]; tp[1] = v[1]; tp[2] = v[2]; tp[3] = v[3]; }
-                    else *(vnp_f4*)(dst + g) = vnp_f4{tp[0], tp[1], tp[2], tp[3]};
+                    if (load) *(vnp_f4*)tp = *(const vnp_f4*)(src + g);
+                    else *(vnp_f4*)(dst + g) = *(const vnp_f4*)tp;
                 }
             }
-        } else {
-            for (int seg = wave; seg < nseg; seg += 4) {
-                const int n = seg / 3, t = seg - n * 3;
-                const size_t g = (((size_t)b * N + n0 + n) * 3 + t) * ld + h * ch;
-                for (int cl = lane; cl < ch; cl += 64) {
-                    if (load) tile[n * TS + t * ch + cl] = src[g + cl];
-                    else dst[g + cl] = tile[n * TS + t * ch + cl];
+        };
+        auto fm_side = [&](bool load) {
+            const int ngrp = Dh >> 2;                                   // groups of four consecutive words [t][cl .. cl + 3]
+#pragma unroll 3
+            for (int gi = wave; gi < ngrp; gi += 4) {
+                const int w = gi * 4, t = w / ch, cl = w - t * ch;
+                const size_t g = ((size_t)bh * FR + cl * 3 + t) * N + n0 + lane;      // feature row of word 0; words j: + 3 j rows
+                if (lane < cnt) {
+                    float* tp = tile + lane * TS + w;
+                    if (load) {
+                        vnp_f4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = src[g + (size_t)3 * j * N];
+                        *(vnp_f4*)tp = v;
+                    } else {
+                        const vnp_f4 v = *(const vnp_f4*)tp;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dst[g + (size_t)3 * j * N] = v[j];
+                    }
                 }
+            }
+            if (!load) for (int r = Dh + wave; r < FR; r += 4) if (lane < cnt) dst[((size_t)bh * FR + r) * N + n0 + lane] = 0.f;
+        };
+        if (TO_HEADS) { rows_side(true); __syncthreads(); fm_side(false); }
+        else          { fm_side(true); __syncthreads(); rows_side(false); }
+        return;
+    }
+    // general form (any ch): scalar words
+    auto rows_side = [&](bool load) {
+        for (int seg = wave; seg < cnt * 3; seg += 4) {
+            const int n = seg / 3, t = seg - n * 3;
+            const size_t g = (((size_t)b * N + n0 + n) * 3 + t) * ld + h * ch;
+            for (int cl = lane; cl < ch; cl += 64) {
+                if (load) tile[n * TS + t * ch + cl] = src[g + cl];
+                else dst[g + cl] = tile[n * TS + t * ch + cl];
             }
         }
     };
-    // feature-major side: feature row r = cl * 3 + t, TT consecutive tokens (lane = token: LDS stride 3 ch + 1 words, conflict-free)
     auto fm_side = [&](bool load) {
         const int nr = load ? Dh : FR;
-#pragma unroll 4
         for (int r = wave; r < nr; r += 4) {
             const size_t g = ((size_t)bh * FR + r) * N + n0;
             const int cl = r / 3, t = r - cl * 3;
@@ -334,17 +376,19 @@ extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int 
 static int vnp_heads_fm(hipStream_t st, bool to_heads, const float* src, float* dst, int ld, int B, int N, int C, int H, int fr)
 {
     if (!src || !dst || B <= 0 || N <= 0 || C <= 0 || H <= 0 || C % H || ld < C || fr < 3 * (C / H) || (long long)B * H > 65535) return VNP_EINVAL;
-    const int Dh = 3 * (C / H);
+    const int Dh = 3 * (C / H), ch = C / H;
+    const float* rows = to_heads ? src : dst;
+    const int vec = (ch % 4 == 0 && ch / 4 <= 64 && ld % 4 == 0 && ((uintptr_t)rows & 15) == 0) ? 1 : 0;
+    // LDS row stride in words: vec: a multiple of 4 whose quarter is odd (see the kernel); else 3 ch + 1 (odd: lane = token is conflict-free)
+    int ts = Dh + 1;
+    if (vec) { ts = Dh + 4; if (((ts >> 2) & 1) == 0) ts += 4; }
     int tt = 64;                                                     // tokens per workgroup: as many (64, 32, 16) as fit 64 KB of LDS
-    while (tt > 16 && (size_t)tt * (Dh + 1) * sizeof(float) > 65536) tt >>= 1;
-    const size_t lds = (size_t)tt * (Dh + 1) * sizeof(float);
+    while (tt > 16 && (size_t)tt * ts * sizeof(float) > 65536) tt >>= 1;
+    const size_t lds = (size_t)tt * ts * sizeof(float);
     if (lds > 65536) return VNP_EINVAL;
     dim3 grid((unsigned)((N + tt - 1) / tt), (unsigned)(B * H));
-    const float* rows = to_heads ? src : dst;
-    const int ch = C / H;
-    const int vec = (ch % 4 == 0 && ch / 4 <= 64 && ld % 4 == 0 && ((uintptr_t)rows & 15) == 0) ? 1 : 0;
-    if (to_heads) hipLaunchKernelGGL((vnp_head_permute_fm_kernel<true>), grid, dim3(256), lds, st, src, dst, ld, B, N, C, H, fr, tt, vec);
-    else          hipLaunchKernelGGL((vnp_head_permute_fm_kernel<false>), grid, dim3(256), lds, st, src, dst, ld, B, N, C, H, fr, tt, vec);
+    if (to_heads) hipLaunchKernelGGL((vnp_head_permute_fm_kernel<true>), grid, dim3(256), lds, st, src, dst, ld, B, N, C, H, fr, tt, vec, ts);
+    else          hipLaunchKernelGGL((vnp_head_permute_fm_kernel<false>), grid, dim3(256), lds, st, src, dst, ld, B, N, C, H, fr, tt, vec, ts);
     return vnp_last_error();
 }
 
