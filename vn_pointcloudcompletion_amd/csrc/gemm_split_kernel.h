@@ -390,7 +390,6 @@ __device__ __forceinline__ void vnp_split_epilogue(const VnpGemmArgs& p, vnp_f4 
         float wmean[TN], wm2[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) { wmean[j] = 0.f; wm2[j] = 0.f; }
-        int wn_cnt = 0;
 #pragma unroll
         for (int i3 = 0; i3 < 2; ++i3)
 #pragma unroll
@@ -402,7 +401,6 @@ __device__ __forceinline__ void vnp_split_epilogue(const VnpGemmArgs& p, vnp_f4 
                     b0 = p.bias + (size_t)(grp * 3) * p.ldbias; b1 = b0 + p.ldbias; b2 = b1 + p.ldbias;
                 }
                 float* d0 = Cz + (size_t)(m0 + lr) * p.ldc;
-                ++wn_cnt;
                 float xs[3][TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -410,9 +408,12 @@ __device__ __forceinline__ void vnp_split_epilogue(const VnpGemmArgs& p, vnp_f4 
                     float x0 = acc[3 * i3][j][e], x1 = acc[3 * i3 + 1][j][e], x2 = acc[3 * i3 + 2][j][e];
                     if (has_bias) { x0 += b0[col]; x1 += b1[col]; x2 += b2[col]; }
                     xs[0][j] = x0; xs[1][j] = x1; xs[2][j] = x2;
-                    const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2) + VNP_EPS;
+                    // statistics only (the stored x is untouched): hardware sqrt (1 ulp) and the reciprocal of the running count — a
+                    // compile-time constant 1 / 1 .. 1 / 8 after unrolling — instead of IEEE sqrtf and a division per point and column:
+                    // the epilogue was ~700 VALU instructions per lane and tile, on the critical path of the one workgroup per CU
+                    const float nrm = __builtin_amdgcn_sqrtf(x0 * x0 + x1 * x1 + x2 * x2) + VNP_EPS;
                     const float delta = nrm - wmean[j];
-                    wmean[j] += delta / (float)wn_cnt;
+                    wmean[j] += delta * (1.0f / (float)(4 * i3 + e + 1));
                     wm2[j] += delta * (nrm - wmean[j]);
                 }
                 // stores row by row, the TN segments of a row back to back (as the plain epilogue does): with the three rows of a point
