@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import vn_layers
 from .pcn import VN_FoldingNet, VN_PointNet
 
 ENCODERS = ("dgcnn_fps", "vn_dgcnn_fps", "vn_pointnet", "vn_pointr")
@@ -61,6 +62,13 @@ class PCNNet(nn.Module):
                 self.decoder.num_coarse, self.decoder.num_dense = 1248, 1248 * 16
 
     def forward(self, input, rot=None):
+        prev = vn_layers.begin_deferred_ticks()          # all BatchNorm step counters of this forward in one launch at its end
+        try:
+            return self._forward(input, rot)
+        finally:
+            vn_layers.end_deferred_ticks(prev)
+
+    def _forward(self, input, rot=None):
         coarse, feature_global = self.encoder(input)
         if self.num_coarse == 448:
             if self.only_coarse:

@@ -73,6 +73,30 @@ class VNLeakyReLU(nn.Module):
         return from_rows(self.forward_rows(rows), meta)
 
 
+# BatchNorm's num_batches_tracked counters: a layer called on its own increments its counter at once (one small launch); inside
+# PCNNet.forward the counters of all layers are collected and incremented together when the forward ends (VN-PoinTr: 22 launches -> 1).
+_DEFERRED_TICKS = None
+
+
+def begin_deferred_ticks():
+    """Start collecting counters; returns the previous collector (None if none was active) for ``end_deferred_ticks``."""
+    global _DEFERRED_TICKS
+    prev = _DEFERRED_TICKS
+    if prev is None:
+        _DEFERRED_TICKS = []
+    return prev
+
+
+def end_deferred_ticks(prev):
+    """Increment everything collected since the matching ``begin_deferred_ticks`` (the outermost pair does the work)."""
+    global _DEFERRED_TICKS
+    if prev is None and _DEFERRED_TICKS is not None:
+        pending, _DEFERRED_TICKS = _DEFERRED_TICKS, None
+        if pending:
+            with torch.no_grad():
+                torch._foreach_add_(pending, 1)
+
+
 class VNBatchNorm(nn.Module):
     """models/vn_layers.py:107-127."""
 
@@ -86,7 +110,10 @@ class VNBatchNorm(nn.Module):
 
     def _tick(self):
         if self.training and self.bn.track_running_stats and self.bn.num_batches_tracked is not None:
-            self.bn.num_batches_tracked.add_(1)
+            if _DEFERRED_TICKS is not None:
+                _DEFERRED_TICKS.append(self.bn.num_batches_tracked)      # PCNNet.forward: one launch for all counters at its end
+            else:
+                self.bn.num_batches_tracked.add_(1)
 
     def forward_rows(self, rows):
         self._tick()
