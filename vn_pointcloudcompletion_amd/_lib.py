@@ -237,10 +237,25 @@ def ptr(t):
     return t.data_ptr()
 
 
+_FN = {}                                               # entry point name -> bound ctypes function
+# the raw handle of torch's current stream without building a torch.cuda.Stream object per launch (the step of the transformer configs
+# is ~800 launches, and the host falls behind the GPU in their encoder's forward): a private torch call, with the public one as fallback
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def _current_stream():
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return _RAW_STREAM(_GET_DEVICE())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def call(name, *args):
     """Invoke a stream-taking entry point on torch's current HIP stream; raise on a non-zero status."""
-    st = torch.cuda.current_stream().cuda_stream
-    rc = getattr(lib(), name)(st, *args)
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(lib(), name)
+    rc = fn(_current_stream(), *args)
     if rc != 0:
         raise VnpError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
 
