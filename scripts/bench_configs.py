@@ -34,7 +34,7 @@ for cid in which:
     g = torch.Generator().manual_seed(1)
     p = (torch.rand(c["B"], 2048, 3, generator=g) - 0.5).cuda()
     gt = (torch.rand(c["B"], md, 3, generator=g) - 0.5).cuda()
-    for _ in range(2):
+    for _ in range(5):                       # warm-up (a one-off ~0.1 s stall half a second into a process's GPU work would land in a shorter one's timed steps)
         train_step(cfg, net, opt, p, gt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
