@@ -215,9 +215,8 @@ def roofline_other(B, N, Mc, Md):
              "pairs = 2*n*m per cloud (two one-sided scans, like chamfer3D.cu); peak = 78.6 T lane-op/s (one VALU op per lane per clock)")
         # the pruned search is priced on the pairs it EVALUATES: the kernel counts them (ws + 8, include/vnpcc.h)
         stats = []
-        ops.CHAMFER_STATS = stats
-        ops.ChamferFn.apply(dense, gt)
-        ops.CHAMFER_STATS = None
+        with ops.hooks(chamfer_stats=stats):
+            ops.ChamferFn.apply(dense, gt)
         torch.cuda.synchronize()
         visited = float(stats[0].item())
         valu("vnp_chamfer_pruned_kernel + vnp_chamfer_bin_kernel (dense loss 16384 x 16384, uniform random clouds)",
@@ -355,17 +354,16 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     prof = []
-    ops.GEMM_PROFILE = prof
     waits = [] if (D.collectives_on() and overlap) else None
     D.EXPOSED_WAIT = waits
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, loss1, loss2 = train_step(cfg, model, opt, p, c)
-    torch.cuda.synchronize()
-    D.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ops.GEMM_PROFILE = None
+    with ops.hooks(gemm_profile=prof):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, loss1, loss2 = train_step(cfg, model, opt, p, c)
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     D.EXPOSED_WAIT = None
     elapsed = D.allreduce_scalar_max(elapsed)
     ranks_joined = D.world_size()
@@ -391,14 +389,13 @@ def main():
             train_step(cfg, model, opt, p, c)
         torch.cuda.synchronize()
         prof32 = []
-        ops.GEMM_PROFILE = prof32
-        t1 = time.perf_counter()
         n32 = max(2, min(5, args.steps))
-        for _ in range(n32):
-            train_step(cfg, model, opt, p, c)
-        torch.cuda.synchronize()
-        dt32 = time.perf_counter() - t1
-        ops.GEMM_PROFILE = None
+        with ops.hooks(gemm_profile=prof32):
+            t1 = time.perf_counter()
+            for _ in range(n32):
+                train_step(cfg, model, opt, p, c)
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t1
         _lib.set_gemm_mode("split")
         mf = [(x[1], x[4].seconds()) for x in prof32 if x[4].kind == 1]
         f32 = sum(f for f, _ in mf)

@@ -85,6 +85,9 @@ int vnp_gemm_tile_rows(int op_b, int M, int N, int nsplit, int nbatch, int has_b
  * 0 six-product bf16 split kernel, 1 fp32-input MFMA kernel, 2 streaming kernel of a degenerate shape (K = 1, N = 1, M = 1: no
  * MFMA), 3 screening pass with one fp16 product, 4 screening pass with three bf16 products, 5 two fp16 planes / three products. */
 int vnp_gemm_profile_next(hipEvent_t e0, hipEvent_t e1, int* kind);
+/* Drop a pending request.  (Every matrix-product entry point also drops a request it did not consume when it returns — argument error,
+ * a path that brackets no kernel — so a request never outlives the call it was armed for.) */
+int vnp_gemm_profile_cancel(void);
 int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, int ldbias, int rows_per_group,

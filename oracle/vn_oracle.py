@@ -208,6 +208,68 @@ def pcnnet_forward(sd, xyz, rot_R=None, training=True, new_stats=None):
 
 
 # ------------------------------------------------------------------- graph helpers / VN-DGCNN
+class Teacher:
+    """Teacher forcing for the full-resolution / gradient parity tests (tests/test_gpu_grad_parity.py): the DISCRETE choices of a network
+    — kNN tables [B,Nq,k], FPS picks [B,m], arg-max pool indices [B,C] — recorded from the path under test, consumed here in call order
+    instead of this oracle's own searches.  Every search still runs; for each forced choice ``report`` receives how far it is from the
+    oracle's own optimum in the oracle's arithmetic, so that the test can assert that each forced choice is one the reference's
+    arithmetic could have made (a rounding-level tie), and how many choices are identical outright."""
+
+    def __init__(self, knn=None, fps=None, pool=None):
+        self.knn = [t.long() for t in knn] if knn is not None else None
+        self.fps = [t.long() for t in fps] if fps is not None else None
+        self.pool = [t.long() for t in pool] if pool is not None else None
+        self.report = []                                            # (kind, shape, identical fraction, worst relative gap)
+        self.taken = {"knn": [], "fps": [], "pool": []}             # what was used, in call order (a free run records its own choices)
+
+    def take_knn(self, ref, query, k):
+        own = knn_torch(ref, query, k)
+        if self.knn is None:
+            self.taken["knn"].append(own)
+            return own
+        idx = self.knn.pop(0)
+        self.taken["knn"].append(idx)
+        assert idx.shape == own.shape, (idx.shape, own.shape)
+        with torch.no_grad():
+            def kth(i):                                             # largest of the k selected squared distances, per query
+                sel = torch.gather(ref.unsqueeze(1).expand(-1, query.shape[1], -1, -1), 2, i[..., None].expand(-1, -1, -1, ref.shape[-1]))
+                return ((sel - query.unsqueeze(2)) ** 2).sum(-1).max(-1)[0]
+            mine, best = kth(idx), kth(own)
+            gap = ((mine - best) / best.clamp_min(1e-30)).max().item()
+            same = (torch.sort(idx, -1)[0] == torch.sort(own, -1)[0]).all(-1).float().mean().item()
+        self.report.append(("knn", tuple(idx.shape), same, gap))
+        return idx
+
+    def take_fps(self, xyz, m):
+        if self.fps is None:
+            self.taken["fps"].append(fps_torch(xyz, m))
+            return self.taken["fps"][-1]
+        idx = self.fps.pop(0)
+        self.taken["fps"].append(idx)
+        own = fps_torch(xyz, m)
+        assert idx.shape == own.shape, (idx.shape, own.shape)
+        self.report.append(("fps", tuple(idx.shape), (idx == own).float().mean().item(), float("nan")))
+        return idx
+
+    def take_pool(self, dot_shape):
+        return self.pool.pop(0) if self.pool is not None else None
+
+    def note_pool(self, idx, dot):
+        """dot [B,C,N]: the oracle's own scores of the pool whose indices were forced."""
+        with torch.no_grad():
+            chosen = dot.gather(-1, idx.unsqueeze(-1)).squeeze(-1)
+            best, lo = dot.max(-1)[0], dot.min(-1)[0]
+            gap = ((best - chosen) / (best - lo).clamp_min(1e-30)).max().item()
+            same = (dot.argmax(-1) == idx).float().mean().item()
+        self.report.append(("pool", tuple(idx.shape), same, gap))
+
+    def exhausted(self):
+        return not (self.knn or self.fps or self.pool)
+
+
+_FREE = Teacher()
+
+
 def knn_torch(ref, query, k):
     """ref [B,Nr,D], query [B,Nq,D] -> idx [B,Nq,k]: k smallest squared-L2 distances, ascending (direct-form distances).
     Stands for KNN_CUDA 0.2 (third party, source absent; call sites models/dgcnn.py:236,257-259): PARITY UNPINNED for
@@ -431,19 +493,20 @@ def _lin_and_leaky_bn(sd, prefix, x, training, new_stats):
     return vn_leaky_relu(y, sd[f"{prefix}.leaky_relu.map_to_dir.weight"])
 
 
-def vn_dgcnn_grouper_forward(sd, prefix, coords, training=True, k=16, new_stats=None):
+def vn_dgcnn_grouper_forward(sd, prefix, coords, training=True, k=16, new_stats=None, teacher=None):
     """models/pointr/utils/dgcnn_group.py:214-247: every kNN graph is built on the flattened VN FEATURES.
-    coords [B,N,3] -> (proxy coords [B,128,3], features [B,128,3,128])."""
+    coords [B,N,3] -> (proxy coords [B,128,3], features [B,128,3,128]).  ``teacher``: see Teacher."""
     p = prefix
+    T = teacher or _FREE
 
     def conv(name, f):
         B, C, _, N = f.shape
         feats = f.permute(0, 3, 1, 2).reshape(B, N, C * 3)
-        e = vn_graph_feature(f, knn_torch(feats, feats, k))
+        e = vn_graph_feature(f, T.take_knn(feats.detach(), feats.detach(), k))
         return mean_pool(_lin_leaky(sd, f"{p}.{name}", e, training, new_stats))
 
     def down(c, f, m):
-        i = fps_torch(c, m)
+        i = T.take_fps(c, m)
         return (torch.gather(c, 1, i[..., None].expand(-1, -1, 3)),
                 torch.gather(f, 3, i[:, None, None, :].expand(-1, f.shape[1], 3, -1)))
 
@@ -478,16 +541,18 @@ def pointr_vn_block(sd, prefix, x, knn_idx, training=True, new_stats=None):
     return vn_x.reshape(B, -1, N).transpose(1, 2)
 
 
-def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encoder", new_stats=None):
+def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encoder", new_stats=None, teacher=None):
     """models/pointr/vn_pointr.py:575-722 (VN_PCTransformer.forward, dgcnn='vn_dgcnn', trans='vn_trans', only_coarse=True).
-    inpc [B,N,3] -> (coarse [B,1248,3], global_feature [B,1024,3,1])."""
+    inpc [B,N,3] -> (coarse [B,1248,3], global_feature [B,1024,3,1]).  ``teacher``: see Teacher (call order: the grouper's four graphs
+    and two FPS stages, the k = 8 coordinate graph, the global pool, the FPS-224 subset)."""
     p = prefix
     B = inpc.shape[0]
-    coor, f = vn_dgcnn_grouper_forward(sd, f"{p}.grouper", inpc, training, 16, new_stats)      # [B,128,3], [B,128,3,128]
+    T = teacher or _FREE
+    coor, f = vn_dgcnn_grouper_forward(sd, f"{p}.grouper", inpc, training, 16, new_stats, teacher=T)      # [B,128,3], [B,128,3,128]
     nc = f.shape[-1]
     f = vn_linear(_lin_leaky(sd, f"{p}.vn_input_proj.0", f, training, new_stats), sd[f"{p}.vn_input_proj.1.map_to_feat.weight"])
     x = f.reshape(B, -1, nc).transpose(1, 2)
-    knn_idx = knn_torch(coor, coor, 8)
+    knn_idx = T.take_knn(coor, coor, 8)
     centers = inpc.mean(dim=1)
     pos_in = torch.cat([coor.transpose(1, 2).unsqueeze(1), centers.unsqueeze(-1).expand(-1, -1, nc).unsqueeze(1)], dim=1)   # [B,2,3,nc]
     pos = vn_linear(_lin_and_leaky_bn(sd, f"{p}.fourth_vn_pos_embed.0", pos_in, training, new_stats),
@@ -496,11 +561,16 @@ def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encod
         x = pointr_vn_block(sd, f"{p}.encoder.{i}", x + pos, knn_idx if i < knn_layer else None, training, new_stats)
     vn_x = x.transpose(1, 2).reshape(B, -1, 3, nc)
     g = vn_linear(_lin_and_leaky_bn(sd, f"{p}.vn_increase_dim.0", vn_x, training, new_stats), sd[f"{p}.vn_increase_dim.1.map_to_feat.weight"])
-    g = vn_max_pool(g, sd[f"{p}.vn_global_pool.map_to_dir.weight"]).unsqueeze(-1)                 # [B,1024,3,1]
+    forced = T.take_pool(None)
+    g, own_idx, dot = vn_max_pool(g, sd[f"{p}.vn_global_pool.map_to_dir.weight"], True, forced)
+    T.taken["pool"].append(own_idx)
+    if forced is not None:
+        T.note_pool(forced, dot)
+    g = g.unsqueeze(-1)                                                                         # [B,1024,3,1]
     h = vn_linear(g, sd[f"{p}.vn_coarse_pred.0.map_to_feat.weight"])
     h = vn_leaky_relu(h, sd[f"{p}.vn_coarse_pred.1.map_to_dir.weight"])
     h = vn_linear(h, sd[f"{p}.vn_coarse_pred.2.map_to_feat.weight"]).squeeze(-1)                  # [B,1024,3]
-    i = fps_torch(inpc, 224)
+    i = T.take_fps(inpc, 224)
     sparse = torch.gather(inpc, 1, i[..., None].expand(-1, -1, 3))
     return torch.cat([h, sparse], dim=1).contiguous(), g
 

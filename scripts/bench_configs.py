@@ -48,10 +48,9 @@ for cid in which:
     if shapes:
         from vn_pointcloudcompletion_amd import ops
         prof = []
-        ops.GEMM_PROFILE = prof
-        train_step(cfg, net, opt, p, gt)
-        torch.cuda.synchronize()
-        ops.GEMM_PROFILE = None
+        with ops.hooks(gemm_profile=prof):
+            train_step(cfg, net, opt, p, gt)
+            torch.cuda.synchronize()
         per = {}
         for variant, flops, nsplit, shape, timer in prof:
             if timer.seconds() is None:

@@ -21,7 +21,7 @@ for (B, n, m) in [(32, 16384, 1024), (32, 19968, 1248), (32, 16384, 2048)]:
     pred = (torch.rand(B, m, 3, generator=g) * 0.6 - 0.3).cuda()
     cd = chamfer_3DDist()
     for thr in (4096, 512):
-        ops.CHAMFER_PRUNED_MIN_POINTS = thr
+        ops.SW.CHAMFER_PRUNED_MIN_POINTS = thr
         us = t(lambda: cd(gt, pred))
         print(f"B={B} gt={n} pred={m} pruned-threshold {thr}: {us:.1f} us")
-    ops.CHAMFER_PRUNED_MIN_POINTS = 4096
+    ops.SW.CHAMFER_PRUNED_MIN_POINTS = 4096

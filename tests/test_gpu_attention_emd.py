@@ -263,9 +263,9 @@ def test_attention_layouts_agree(lib_built, B, N, C, H):
     go = torch.randn(B * N * 3, C, generator=g).cuda()
     scale = 0.3
     res = {}
-    floor = ops.ATTN_FM_MIN_FLOP
+    floor = ops.SW.ATTN_FM_MIN_FLOP
     for tm in (False, True):
-        ops.ATTN_TOKEN_MAJOR, ops.ATTN_FM_MIN_FLOP = tm, 0.0              # no size floor: these small cases take the padded layouts too
+        ops.SW.ATTN_TOKEN_MAJOR, ops.SW.ATTN_FM_MIN_FLOP = tm, 0.0              # no size floor: these small cases take the padded layouts too
         try:
             x = qkv.clone().requires_grad_(True)
             out = ops.VNAttentionPackedFn.apply(x, B, N, H, scale)
@@ -275,7 +275,7 @@ def test_attention_layouts_agree(lib_built, B, N, C, H):
             out2.backward(go)
             res[tm] = (out.detach(), x.grad, out2.detach(), torch.cat([q.grad, k.grad, v.grad], dim=1))
         finally:
-            ops.ATTN_TOKEN_MAJOR, ops.ATTN_FM_MIN_FLOP = False, floor
+            ops.SW.ATTN_TOKEN_MAJOR, ops.SW.ATTN_FM_MIN_FLOP = False, floor
     assert not ops._attn_token_major(16, 1024, 384, 8) and ops._attn_token_major(32, 128, 384, 4)       # configs 4 and 5
     assert torch.equal(res[False][0], res[False][2]) and torch.equal(res[False][1], res[False][3])        # packed == unpacked
     assert relerr(res[False][0], res[True][0]) < 2e-6 and relerr(res[False][1], res[True][1]) < 5e-6
@@ -304,7 +304,7 @@ def test_group_fold_fused_equals_the_unfused_layer(lib_built, G, S, C, needs_x):
     go = torch.randn(G * S * 3, C, generator=g).cuda()
     res = {}
     for fused in (True, False):
-        ops.GROUP_FOLD = fused
+        ops.SW.GROUP_FOLD = fused
         try:
             torch.manual_seed(3)
             layer = VNLinearLeakyReLU(cg + 1, C, dim=4).cuda().train()
@@ -313,9 +313,8 @@ def test_group_fold_fused_equals_the_unfused_layer(lib_built, G, S, C, needs_x):
             x = x0.clone().requires_grad_(needs_x)
             f = f0.clone().requires_grad_(True)
             tr = {}
-            ops.TRACE = tr
-            y = layer.forward_rows(x, global_rows=f, rows_per_group=S * 3, global_first=False)
-            ops.TRACE = None
+            with ops.hooks(trace=tr):
+                y = layer.forward_rows(x, global_rows=f, rows_per_group=S * 3, global_first=False)
             assert ("group_fold_fused" in tr) == fused
             y.backward(go)
             grads = [f.grad] + ([x.grad] if needs_x else []) + [p.grad for p in layer.parameters()]
@@ -325,7 +324,7 @@ def test_group_fold_fused_equals_the_unfused_layer(lib_built, G, S, C, needs_x):
                 ye = layer.forward_rows(x0, global_rows=f0, rows_per_group=S * 3, global_first=False)
             res[fused] = (y.detach(), grads, stats, ye)
         finally:
-            ops.GROUP_FOLD, ops.TRACE = True, None
+            ops.SW.GROUP_FOLD = True
     assert relerr(res[True][0], res[False][0]) < 2e-6 and relerr(res[True][3], res[False][3]) < 2e-6
     for a, b in zip(res[True][2], res[False][2]):
         assert relerr(a, b) < 1e-6
@@ -351,14 +350,13 @@ def test_attention_decoder_fused_stage_tails_equal_layer_by_layer(lib_built):
             dec = Attention_VN_FoldingNet(SimpleNamespace(num_coarse=128, latent_dim=2048)).cuda().train()
             c = coarse.clone().requires_grad_(True)
             tr = {}
-            ops.TRACE = tr
-            out = dec(c, feat)
-            ops.TRACE = None
+            with ops.hooks(trace=tr):
+                out = dec(c, feat)
             assert tr.get("decoder_tail_fused", 0) == (2 if fused else 0) and tr.get("group_fold_fused", 0) == 2
             out.backward(go)
             res[fused] = (out.detach(), c.grad, [(n, p.grad) for n, p in dec.named_parameters() if p.grad is not None])
         finally:
-            Attention_VN_FoldingNet.FUSED_TAIL, ops.TRACE = True, None
+            Attention_VN_FoldingNet.FUSED_TAIL = True
     assert relerr(res[True][0], res[False][0]) < 5e-6 and relerr(res[True][1], res[False][1]) < 5e-5
     assert [n for n, _ in res[True][2]] == [n for n, _ in res[False][2]]
     for (n, a), (_, b) in zip(res[True][2], res[False][2]):

@@ -76,7 +76,7 @@ def test_fps_pointnet2_near_origin_convention(lib_built):
     is plain FPS).  Both conventions against the oracle's restatement, on clouds seeded with near-origin points."""
     from oracle import vn_oracle as O
     from vn_pointcloudcompletion_amd import ops
-    assert ops.FPS_SKIP_NEAR_ORIGIN is True
+    assert ops.SW.FPS_SKIP_NEAR_ORIGIN is True
     g = torch.Generator().manual_seed(4)
     x = torch.rand(3, 2048, 3, generator=g) - 0.5
     x[:, 5::97] *= 0.04                                           # ~21 points per cloud inside the r = 0.0316 ball
@@ -255,10 +255,10 @@ def test_edge_reverse_is_the_reverse_adjacency(lib_built, Pq, k, Pu):
 
 
 @pytest.mark.parametrize("P,k,C", [(512, 20, 64), (1000, 16, 128), (2048, 16, 32)])
-def test_edge_grad_gather_is_deterministic_and_equals_the_atomic_form(lib_built, P, k, C, monkeypatch):
-    """The neighbour-feature gradient of the fused EdgeConv as a gather over the reverse adjacency (vnp_edge_fused_gather, the default):
-    the same bits on every run although the order inside a source's list is unspecified (sums taken in double), and equal to the
-    float-atomics form (VNP_EDGE_ATOMICS=1) to summation rounding; gv and the parameter gradients are the same kernels' output."""
+def test_edge_grad_gather_is_deterministic_and_equals_the_unfused_form(lib_built, P, k, C):
+    """The neighbour-feature gradient of the fused EdgeConv as a gather over the reverse adjacency (vnp_edge_fused_gather): the same bits
+    on every run (sums taken in double over a list in edge order), and equal to the layer evaluated as gather-add -> BatchNorm / leaky ->
+    mean pool on the materialised edge tensor to summation rounding; gv and the parameter gradients are the same kernels' output."""
     from vn_pointcloudcompletion_amd import ops
     g = torch.Generator().manual_seed(P + C)
     u0, v0 = torch.randn(P * 3, 2 * C, generator=g), torch.randn(P * 3, 2 * C, generator=g)
@@ -267,20 +267,23 @@ def test_edge_grad_gather_is_deterministic_and_equals_the_atomic_form(lib_built,
     gam0, bet0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
     gout = torch.randn(P * 3, C, generator=g).cuda()
 
-    def run(atomics):
-        monkeypatch.setattr(ops, "EDGE_GRAD_ATOMICS", atomics)
+    def run(fused):
         u, v = u0.cuda().requires_grad_(True), v0.cuda().requires_grad_(True)
         gam, bet = gam0.cuda().requires_grad_(True), bet0.cuda().requires_grad_(True)
         rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
-        out = ops.EdgeConvFn.apply(u, v, nbr.cuda(), gam, bet, rm, rv, True, 0.2)
+        if fused:
+            out = ops.EdgeConvFn.apply(u, v, nbr.cuda(), gam, bet, rm, rv, True, 0.2)
+        else:
+            pd = ops.EdgeGatherAddFn.apply(u, v, nbr.cuda())
+            out = ops.VNMeanPoolFn.apply(ops.VNBnLeakyFn.apply(pd, True, gam, bet, rm, rv, True, 0.2), P, k)
         (out * gout).sum().backward()
         return u.grad, v.grad, gam.grad, bet.grad
-    a, b, c = run(False), run(False), run(True)
+    a, b, c = run(True), run(True), run(False)
     for x, y in zip(a, b):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))             # bit-for-bit repeatable
     for name, x, y in zip(("gu", "gv", "ggamma", "gbeta"), a, c):
         scale = y.abs().max().item() + 1e-12
-        assert (x - y).abs().max().item() <= 1e-5 * scale, (name, (x - y).abs().max().item(), scale)
+        assert (x - y).abs().max().item() <= 2e-5 * scale, (name, (x - y).abs().max().item(), scale)
 
 
 @pytest.mark.parametrize("Nr,Nq,k", [(2048, 2048, 20), (512, 512, 16), (128, 128, 16), (700, 300, 8), (4096, 100, 32), (40, 40, 40), (70, 33, 64)])

@@ -76,13 +76,31 @@ def _worker(rank, world, port, q):
             D.allreduce_gradients(opt)
             grads.append(opt.flat_buffers[0].flat_grad.cpu().numpy().copy())      # numpy: pickled by value (no fd passing)
             opt.step()
+        # two more steps in which RANK 1 ALONE produces no gradient for one parameter: its slice must hold rank 0's
+        # contribution / world after BOTH steps — a slice the gather left "known zero" on rank 1 holds the average after the collective
+        # and has to be zero-filled again before the next one, or the stale average is reduced a second time (1.5x at step two)
+        fb = opt.flat_buffers[0]
+        victim = model.decoder.final_conv[0].batchnorm.bn.weight
+        vi = next(i for i, q_ in enumerate(fb.params) if q_ is victim)
+        lo = fb.offsets[vi]
+        skipped = []
+        for _ in range(2):
+            opt.zero_grad()
+            victim.requires_grad_(rank != 1)
+            coarse, fine = model(p)
+            loss, _, _ = compute_losses(cfg, coarse, fine, c)
+            loss.backward()
+            victim.requires_grad_(True)
+            D.allreduce_gradients(opt)
+            skipped.append(fb.flat_grad[lo:lo + victim.numel()].cpu().numpy().copy())
+            opt.step()
         torch.cuda.synchronize()
-        q.put((rank, "ok", grads, launched, len(red.buckets)))
+        q.put((rank, "ok", grads, launched, len(red.buckets), skipped))
         D.barrier()
         dist.destroy_process_group()
     except Exception as e:                                            # report instead of hanging the parent
         import traceback
-        q.put((rank, "error", f"{type(e).__name__}: {e}\n{traceback.format_exc()}", None, None))
+        q.put((rank, "error", f"{type(e).__name__}: {e}\n{traceback.format_exc()}", None, None, None))
 
 
 def test_two_ranks_overlapped_allreduce_matches_manual_average(lib_built):
@@ -115,6 +133,11 @@ def test_two_ranks_overlapped_allreduce_matches_manual_average(lib_built):
     import numpy as np
     for g0, g1 in zip(out[0][2], out[1][2]):
         assert np.array_equal(g0, g1)                                    # both replicas hold the same averaged gradient
+    # a parameter without a gradient on rank 1 for two steps: both ranks hold the same slice, and the second step's equals the first's
+    for r in range(world):
+        a, b = out[r][5]
+        assert np.array_equal(out[0][5][0], out[1][5][0]) and np.abs(a).max() > 0
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max(), (r, np.abs(a - b).max(), np.abs(a).max())
     assert out[0][4] >= 3                                             # several buckets at this bucket size
     assert out[0][3][0] == 0 and all(n >= 1 for n in out[0][3][1:])   # from step 2 on, buckets leave during backward
 

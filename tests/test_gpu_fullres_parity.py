@@ -5,7 +5,7 @@ oracle finishes in well under a minute.
 Why a second end-to-end test beside test_gpu_e2e.py (config 1, 256 -> 64 -> 1024): at fixture size the layers have
 R = 1536 rows, so the code paths the benchmark actually runs — BatchNorm statistics in the GEMM epilogue (needs whole
 1024-point chunks), the exact screened arg-max pool fused into the GEMM epilogue, the fused FoldingNet layer 0 and decoder tail, the
-pruned Chamfer search — are never taken there.  This test asserts (ops.TRACE) that they ARE taken here.
+pruned Chamfer search — are never taken there.  This test asserts (ops.hooks(trace=...)) that they ARE taken here.
 
 The two arg-max pools are discontinuous: two points whose scores agree to ~1e-7 relative swap under any change of
 summation order (the reference's own CPU BLAS vs einsum do that too), and the pooled VECTOR then changes
@@ -51,14 +51,12 @@ def run(lib_built):
     p = torch.rand(B, N, 3, generator=g) - 0.5
     c = torch.rand(B, MD, 3, generator=g) - 0.5
 
-    ops.TRACE = tr = {}
-    try:
+    tr = {}
+    with ops.hooks(trace=tr):
         coarse, fine = net(p.cuda())
         loss1, loss2 = cd_loss_L1(coarse, c.cuda()), cd_loss_L1(fine, c.cuda())
         (loss1 + loss2).backward()
         torch.cuda.synchronize()
-    finally:
-        ops.TRACE = None
     idx1, idx2 = [i.cpu().long() for i in tr["pool_idx"]]
 
     # ---- oracle, pools teacher-forced with our indices: in fp32 (the reference's arithmetic) and in fp64 (the yardstick that
@@ -195,11 +193,9 @@ def test_pruned_chamfer_16384_squared_bit_exact_vs_c_oracle(lib_built):
     g = torch.Generator().manual_seed(3)
     a = torch.rand(1, MD, 3, generator=g) - 0.5
     b = (torch.rand(1, MD, 3, generator=g) - 0.5) * torch.tensor([1.0, 0.6, 0.3])          # anisotropic: uneven Morton bins
-    ops.TRACE = tr = {}
-    try:
+    tr = {}
+    with ops.hooks(trace=tr):
         d1, d2, i1, i2 = chamfer_3DDist()(a.cuda(), b.cuda())
-    finally:
-        ops.TRACE = None
     assert tr == {"chamfer_pruned": 1}
     o1, o2, j1, j2 = CO.chamfer_forward(a.numpy(), b.numpy())
     assert np.array_equal(d1.cpu().numpy(), o1) and np.array_equal(d2.cpu().numpy(), o2)
@@ -225,14 +221,12 @@ def test_cfg3_dgcnn_full_resolution_vs_oracle(lib_built):
     g = torch.Generator().manual_seed(12)
     p = torch.rand(B, N, 3, generator=g) - 0.5
     c = torch.rand(B, MD, 3, generator=g) - 0.5
-    ops.TRACE = tr = {}
-    try:
+    tr = {}
+    with ops.hooks(trace=tr):
         coarse, fine = net(p.cuda())
         loss1, loss2 = cd_loss_L1(coarse, c.cuda()), cd_loss_L1(fine, c.cuda())
         (loss1 + loss2).backward()
         torch.cuda.synchronize()
-    finally:
-        ops.TRACE = None
     assert tr.get("fold_layer0_fused", 0) == 1 and tr.get("decoder_tail_fused", 0) == 1 and tr.get("chamfer_pruned", 0) == 1, tr
     (idx5,) = [i.cpu().long() for i in tr["pool_idx"]]
 

@@ -162,12 +162,8 @@ def test_screened_pool_on_surface_like_clouds_needs_no_fallback(net):
     p = (v * (0.35 + 0.05 * torch.sin(7 * v[..., :1]))).cuda()
     net.train()
     stats = []
-    ops.POOL_SCREEN_STATS = stats
-    try:
-        with torch.no_grad():
-            net(p)
-    finally:
-        ops.POOL_SCREEN_STATS = None
+    with ops.hooks(pool_screen_stats=stats), torch.no_grad():
+        net(p)
     cand, flag, cap = stats[-1].tolist()
     per_pair = cand / (4 * 2048)
     print(f"surface-like clouds: {per_pair:.1f} candidates per (sample, channel), capacity {cap / (4 * 2048):.0f}, fallback flag {flag}")

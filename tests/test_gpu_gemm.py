@@ -224,12 +224,10 @@ def test_degenerate_shapes_take_streaming_kernels():
 def _gemm_h2(A, B, op_a, op_b, nsplit=None):
     """ops.gemm forced onto the two-plane path (whatever the size threshold says), asserting that it was taken."""
     from vn_pointcloudcompletion_amd import ops
-    keep, ops.GEMM_FP16X2, ops.GEMM_FP16X2_MIN_FLOP, ops.TRACE = (ops.GEMM_FP16X2, ops.GEMM_FP16X2_MIN_FLOP), True, 0.0, {}
-    try:
+    tr = {}
+    with ops.switches(GEMM_FP16X2=True, GEMM_FP16X2_MIN_FLOP=0.0), ops.hooks(trace=tr):
         C = ops.gemm(A, B, op_a=op_a, op_b=op_b, nsplit=nsplit)
-        assert ops.TRACE.get("gemm_fp16x2", 0) == 1, ops.TRACE
-    finally:
-        (ops.GEMM_FP16X2, ops.GEMM_FP16X2_MIN_FLOP), ops.TRACE = keep, None
+    assert tr.get("gemm_fp16x2", 0) == 1, tr
     return C
 
 
@@ -378,7 +376,7 @@ def test_dgrad_nt_form_equals_the_nn_form(lib_built, _mode):
     g = torch.Generator().manual_seed(77)
     gy = torch.randn(192 * 300, 512, generator=g).cuda()
     W = torch.randn(512, 256, generator=g).cuda()
-    assert gy.shape[0] >= ops.DGRAD_NT_ROWS
+    assert gy.shape[0] >= ops.SW.DGRAD_NT_ROWS
     got = ops._dgrad(gy, W)
     assert torch.equal(got, ops.gemm(gy, W, op_b=1))
     assert relerr(got, gy.double() @ W.double()) < 2e-5
@@ -427,3 +425,26 @@ def test_wide_weight_gradient_kernel_is_the_narrow_kernel_bit_for_bit(lib_built,
     narrow = torch.cat([ops.gemm(A[:, r:r + 128].contiguous(), B, op_a=1, op_b=1, nsplit=nsplit) for r in range(0, M, 128)], dim=0)
     assert torch.equal(wide, narrow)
     assert relerr(wide, A.double().t() @ B.double()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_transposed_product_with_a_per_group_bias(lib_built):
+    """op_a = op_b = 1 with a per-group bias whose groups are NOT a multiple of the 256-row wide tile (rows_per_group = 132: a 256-row
+    tile would span three groups): the bias-carrying call stays on the 128-row kernel and every row gets its own group's
+    bias — against float64."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(77)
+    M, N, K, rpg = 132 * 16, 256, 32 * 2048, 132
+    A, B = torch.randn(K, M, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+    bias = torch.randn(M // rpg * 3, N, generator=g).cuda()
+    got = ops.gemm(A, B, op_a=1, op_b=1, bias=bias, rows_per_group=rpg, nsplit=1)
+    r = torch.arange(M, device="cuda")
+    want = A.double().t() @ B.double() + bias.double()[(r // rpg) * 3 + (r % 3)]
+    assert relerr(got, want) < 2e-5
+    M2 = 256 * 8                                                    # a shape the wide kernel would take without a bias
+    A2 = torch.randn(K, M2, generator=g).cuda()
+    bias2 = torch.randn(M2 // rpg * 3 + 3, N, generator=g).cuda()
+    got2 = ops.gemm(A2, B, op_a=1, op_b=1, bias=bias2, rows_per_group=rpg, nsplit=1)
+    r2 = torch.arange(M2, device="cuda")
+    want2 = A2.double().t() @ B.double() + bias2.double()[(r2 // rpg) * 3 + (r2 % 3)]
+    assert relerr(got2, want2) < 2e-5

@@ -162,15 +162,12 @@ def _pool_three_ways(f, W, Wd, G, gs, stats=None):
     res = {}
     for name, fused, screened, pas in (("screened", True, True, "fp16"), ("screened_bf16x3", True, True, "bf16x3"), ("fused", True, False, "fp16"),
                                        ("unfused", False, False, "fp16")):
-        ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED, ops.POOL_SCREEN_PASS = fused, screened, pas
-        ops.POOL_SCREEN_STATS = stats if name == "screened" else None
-        try:
+        with ops.switches(POOL_FUSED_EPILOGUE=fused, POOL_SCREENED=screened, POOL_SCREEN_PASS=pas), \
+                ops.hooks(pool_screen_stats=stats if name == "screened" else None):
             fx, Wx = f.cuda().requires_grad_(True), W.cuda().requires_grad_(True)
             out, idx = ops.VNLinearMaxPoolFn.apply(fx, Wx, Wd.cuda(), G, gs)
             (out * torch.arange(out.numel(), device="cuda").reshape(out.shape).cos()).sum().backward()
             res[name] = (out.detach(), idx, fx.grad, Wx.grad)
-        finally:
-            ops.POOL_FUSED_EPILOGUE, ops.POOL_SCREENED, ops.POOL_SCREEN_STATS, ops.POOL_SCREEN_PASS = True, True, None, "fp16"
     return res
 
 
@@ -291,13 +288,9 @@ def test_screened_pool_random_shapes_and_magnitudes(lib_built):
         Wd = torch.randn(C, C, generator=rng) / C ** 0.5
         out = {}
         for name, screened, pas in (("fp16", True, "fp16"), ("bf16x3", True, "bf16x3"), ("full", False, "fp16")):
-            ops.POOL_SCREENED, ops.POOL_SCREEN_PASS = screened, pas
             st = []
-            ops.POOL_SCREEN_STATS = st if screened else None
-            try:
+            with ops.switches(POOL_SCREENED=screened, POOL_SCREEN_PASS=pas), ops.hooks(pool_screen_stats=st if screened else None):
                 out[name] = ops.VNLinearMaxPoolFn.apply(f.cuda(), W.cuda(), Wd.cuda(), G, gs)
-            finally:
-                ops.POOL_SCREENED, ops.POOL_SCREEN_PASS, ops.POOL_SCREEN_STATS = True, "fp16", None
             if st:
                 flags += int(st[0][1].item())
         for name in ("fp16", "bf16x3"):
@@ -317,19 +310,17 @@ def test_screened_pool_backs_off_after_a_fallback(lib_built):
     W, Wd = (torch.randn(C, K, generator=g) / K ** 0.5).cuda(), (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
     key = (torch.cuda.current_device(), G, gs, C, K)
     ops._screen_state.pop(key, None)
-    old, old_k = ops.POOL_SCREEN_BACKOFF, ops.POOL_SCREEN_MIN_K
-    ops.POOL_SCREEN_BACKOFF, ops.POOL_SCREEN_MIN_K = 3, 0          # (a K this small takes the full epilogue by default)
     try:
         paths = []
-        for _ in range(7):
-            ops.TRACE = tr = {}
-            ops.VNLinearMaxPoolFn.apply(same, W, Wd, G, gs)
-            torch.cuda.synchronize()                       # lets the flag of this call be visible to the next one
-            ops.TRACE = None
-            paths.append("screened" if "linear_pool_screened" in tr else "full")
+        with ops.switches(POOL_SCREEN_BACKOFF=3, POOL_SCREEN_MIN_K=0):        # (a K this small takes the full epilogue by default)
+            for _ in range(7):
+                tr = {}
+                with ops.hooks(trace=tr):
+                    ops.VNLinearMaxPoolFn.apply(same, W, Wd, G, gs)
+                    torch.cuda.synchronize()                   # lets the flag of this call be visible to the next one
+                paths.append("screened" if "linear_pool_screened" in tr else "full")
         assert paths == ["screened", "full", "full", "full", "screened", "full", "full"], paths
     finally:
-        ops.POOL_SCREEN_BACKOFF, ops.POOL_SCREEN_MIN_K, ops.TRACE = old, old_k, None
         ops._screen_state.pop(key, None)
 
 
@@ -346,11 +337,8 @@ def test_screened_pool_non_finite_inputs_take_the_fallback(lib_built):
     stats = []
     out = {}
     for name, screened in (("screened", True), ("fused", False)):
-        ops.POOL_SCREENED, ops.POOL_SCREEN_STATS = screened, (stats if screened else None)
-        try:
+        with ops.switches(POOL_SCREENED=screened), ops.hooks(pool_screen_stats=stats if screened else None):
             out[name] = ops.VNLinearMaxPoolFn.apply(f.cuda(), W.cuda(), Wd.cuda(), G, gs)
-        finally:
-            ops.POOL_SCREENED, ops.POOL_SCREEN_STATS = True, None
     assert stats[0][1].item() == 1
     assert torch.equal(out["screened"][1], out["fused"][1])
     assert torch.equal(out["screened"][0].view(torch.int32), out["fused"][0].view(torch.int32))
@@ -373,7 +361,7 @@ def test_bn_backward_two_pass_equals_bwd1_bwd2(lib_built, training, rank1):
     grow, gcol = torch.randn(P * 3, generator=g).cuda(), torch.randn(C, generator=g).cuda()
     res = {}
     for two in (True, False):
-        ops.BN_BWD_TWO_PASS = two
+        ops.SW.BN_BWD_TWO_PASS = two
         try:
             if rank1:
                 res[two] = ops._bn_leaky_backward(None, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2,
@@ -381,7 +369,7 @@ def test_bn_backward_two_pass_equals_bwd1_bwd2(lib_built, training, rank1):
             else:
                 res[two] = ops._bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, training, 0.2)     # (matrix form: both take bwd1 -> bwd2 today)
         finally:
-            ops.BN_BWD_TWO_PASS = True
+            ops.SW.BN_BWD_TWO_PASS = True
     for a, b in zip(res[True], res[False]):
         assert relerr(a, b) < 2e-6
 
@@ -401,11 +389,11 @@ def test_bn_backward_fused_per_sample_colsum(lib_built, P, rpg):
     go = torch.randn(P * 3, C, generator=g).cuda()
     res = {}
     for two in (True, False):
-        ops.BN_BWD_TWO_PASS = two
+        ops.SW.BN_BWD_TWO_PASS = two
         try:
             res[two] = ops._bn_leaky_backward(go, pd[:, :C], pd[:, C:], C, gamma, beta, mean, rstd, True, 0.2, colsum_rows_per_group=rpg)
         finally:
-            ops.BN_BWD_TWO_PASS = True
+            ops.SW.BN_BWD_TWO_PASS = True
     assert len(res[True]) == 4 and res[True][3].shape == (P * 3 // rpg * 3, 2 * C)
     for a, b in zip(res[True], res[False]):
         assert relerr(a, b) < 5e-6
@@ -481,8 +469,8 @@ def test_linear_pool_tap_fused_equals_linear_then_tap(lib_built, G, gs, C, K):
 
 @pytest.mark.parametrize("B,N,Mc", [(2, 256, 64), (2, 2048, 128)])
 def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
-    """VN_PointNet with second_conv[0] folded onto first_conv[1]'s input channels ((W2 W1) a, ops.ENC_LINEAR_REASSOCIATE: the 512-channel
-    map is never stored) — on per-point scalars (ops.ENC_DIR_LAYER, vnp_vn_dir_layer: every vector behind the single-channel first layer
+    """VN_PointNet with second_conv[0] folded onto first_conv[1]'s input channels ((W2 W1) a, ops.SW.ENC_LINEAR_REASSOCIATE: the 512-channel
+    map is never stored) — on per-point scalars (ops.SW.ENC_DIR_LAYER, vnp_vn_dir_layer: every vector behind the single-channel first layer
     is parallel to its point's direction) and in the rows layout — against the evaluation order of models/pcn.py:168-173 (W2 (W1 a),
     VNP_ENC_AS_WRITTEN=1): outputs equal to fp32 re-association noise (1e-5 of the largest element), every parameter gradient equal to
     1e-4 of its largest element (1e-3 in the coarse head), running statistics to 1e-6.
@@ -491,7 +479,7 @@ def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
     maximum tie to rounding (differences O(d|x|^2)) and ~0.4 % of the picks depend on the evaluation order — as they do against the
     reference (tests/test_gpu_fullres_parity.py: 99.5 % identical picks); one moved pooled vector changes the B = 2 batch statistics of
     every later layer.  Each order therefore runs twice: FREE (its own picks: at most 1 % of maxpool1's may differ from the as-written
-    run's, everything finite) and with the as-written run's picks FORCED (ops.POOL_IDX_FORCE), and on the forced run every output,
+    run's, everything finite) and with the as-written run's picks FORCED (ops.hooks(pool_idx_force=...)), and on the forced run every output,
     gradient and running statistic is asserted — on every cloud, not only on a tie-free one."""
     from types import SimpleNamespace
     from vn_pointcloudcompletion_amd import ops
@@ -504,20 +492,15 @@ def test_encoder_linear_reassociation_equals_as_written(lib_built, B, N, Mc):
     # tiny — the arg-max would then depend on the evaluation order; the origin is covered by test_dir_layer_equals_rows_layer)
     xyz = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
     cot_c, cot_g = torch.randn(B, Mc, 3, generator=g).cuda(), torch.randn(B, 512, 3, 1, generator=g).cuda()
-    keep = ops.ENC_LINEAR_REASSOCIATE, ops.ENC_DIR_LAYER
 
     def run(fold, dirl, force=None):
-        ops.ENC_LINEAR_REASSOCIATE, ops.ENC_DIR_LAYER = fold, dirl
-        ops.POOL_IDX_FORCE = [i.clone() for i in force] if force is not None else None
         enc.load_state_dict(sd0)
         enc.zero_grad(set_to_none=True)
-        ops.TRACE = tr = {}
-        try:
+        tr = {}
+        left = [i.clone() for i in force] if force is not None else None
+        with ops.switches(ENC_LINEAR_REASSOCIATE=fold, ENC_DIR_LAYER=dirl), ops.hooks(trace=tr, pool_idx_force=left):
             coarse, fg = enc(xyz)
             ((coarse * cot_c).sum() + (fg * cot_g).sum()).backward()
-        finally:
-            (ops.ENC_LINEAR_REASSOCIATE, ops.ENC_DIR_LAYER), ops.TRACE = keep, None
-            left, ops.POOL_IDX_FORCE = ops.POOL_IDX_FORCE, None
         assert not left, "a forced index tensor was not consumed"
         assert (tr.get("linear_folded_onto_producer", 0) == 1) == fold and (tr.get("dir_layer", 0) == 1) == dirl, tr
         return (coarse.detach(), fg.detach(), [i.clone() for i in tr["pool_idx"]],
@@ -697,11 +680,7 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
     part_ref = torch.empty(R // 3072, C, 2, device="cuda")
     call("vnp_vn_norm_stats", ptr(pd_ref), 2 * C, R // 3, C, ptr(part_ref), 0)
     pd = torch.empty(R, 2 * C, device="cuda")
-    keep, ops.STATS_IN_EPILOGUE = ops.STATS_IN_EPILOGUE, True          # (whatever VNP_STATS_UNFUSED says: this test is about that path)
-    try:
-        part = ops.gemm_pd_stats(x, W, pd, bias, rpg, C, True)
-    finally:
-        ops.STATS_IN_EPILOGUE = keep
+    part = ops.gemm_pd_stats(x, W, pd, bias, rpg, C, True)
     assert part is not None and torch.equal(pd, pd_ref)
     assert (part[..., 0] - part_ref[..., 0]).abs().max().item() <= 2e-6 * part_ref[..., 0].abs().max().item()
     assert (part[..., 1] - part_ref[..., 1]).abs().max().item() <= 2e-5 * part_ref[..., 1].abs().max().item()
@@ -710,16 +689,13 @@ def test_gemm_epilogue_stats_equal_separate_pass(lib_built, R, K, C, rpg):
     gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
     go = torch.randn(R, C, generator=g).cuda()
     for on in (True, False):
-        ops.STATS_IN_EPILOGUE = on
-        try:
+        with ops.switches(STATS_IN_EPILOGUE=on):
             xx = x.clone().requires_grad_(True)
             Wf, Wd = W[:C].clone().requires_grad_(True), W[C:].clone().requires_grad_(True)
             rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
             out = ops.VNLinearLeakyFn.apply(xx, Wf, Wd, gam, bet, rm, rv, bias, rpg, True, 0.2)
             (out * go).sum().backward()
             res.append((out.detach(), xx.grad, Wf.grad, Wd.grad, rm, rv))
-        finally:
-            ops.STATS_IN_EPILOGUE = keep
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-12)
 

@@ -256,3 +256,27 @@ def test_dcd_and_fscore_oracle_vs_reference_golden(tag):
     d1, d2 = torch.as_tensor(G[f"d1_{tag}"]), torch.as_tensor(G[f"d2_{tag}"])
     for th in (0.001, 0.0001, 0.01):
         assert np.array_equal(torch.stack(O.fscore_oracle(d1, d2, th)).numpy(), G[f"f_{tag}_{th}"])
+
+
+def test_teacher_forcing_with_the_oracles_own_choices_is_the_free_run():
+    """oracle.Teacher (tests/test_gpu_grad_parity.py): a free run records its discrete choices; a second run forced with them gives the
+    same bits, reports every choice as identical with zero gap, and consumes every entry."""
+    P = load_golden("pointr_small.npz")
+    from vn_pointcloudcompletion_amd.vn_pointr import VN_PCTransformer
+    torch.manual_seed(int(P["seed"]))
+    net = VN_PCTransformer(in_chans=3, embed_dim=384, depth=[6, 8], drop_rate=0., num_query=224, knn_layer=1,
+                           dgcnn="vn_dgcnn", trans="vn_trans", memory_profile=False, only_coarse=True)
+    sd = {"encoder." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.as_tensor(P["x"])
+    free = O.Teacher()
+    with torch.no_grad():
+        c0, g0 = O.vn_pctransformer_forward(sd, x, True, teacher=free)
+        assert [len(free.taken[k]) for k in ("knn", "fps", "pool")] == [5, 3, 1]
+        T = O.Teacher(knn=free.taken["knn"], fps=free.taken["fps"], pool=free.taken["pool"])
+        c1, g1 = O.vn_pctransformer_forward(sd, x, True, teacher=T)
+    assert T.exhausted() and torch.equal(c0, c1) and torch.equal(g0, g1)
+    assert len(T.report) == 9
+    for kind, shape, same, gap in T.report:
+        assert same == 1.0 and (gap != gap or gap == 0.0), (kind, shape, same, gap)
+    # and the free run is the pinned forward: the last 224 coarse points are the FPS subset of the input, exactly as in the fixture
+    assert torch.equal(c0[:, 1024:], torch.as_tensor(P["coarse"][:, 1024:]))

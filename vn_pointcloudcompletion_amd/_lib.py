@@ -27,7 +27,19 @@ def sources():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into csrc/libvnpcc.so (cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 into csrc/libvnpcc.so (cross-compiles without a GPU).  Serialised across processes by a
+    file lock: the ranks of a multi-GPU launch that find the library stale build it once, not N times into the same files."""
+    import fcntl
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     srcs = sources()
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h"))
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps):
@@ -35,7 +47,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for s in srcs:
         o = os.path.join(CSRC, "build", os.path.basename(s)[:-4] + ".o")
         objs.append(o)
@@ -50,8 +61,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{out.decode()}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    subprocess.check_call(cmd)
+    tmp = LIB_PATH + ".tmp"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+    os.replace(tmp, LIB_PATH)                     # a process that has the old file mapped keeps it; nobody sees a half-written one
     return LIB_PATH
 
 
@@ -135,7 +147,7 @@ _SIGNATURES = {
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
     "vnp_pack_tensors": [_i, _vp, _vp, _vp, _vp],
 }
-_NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
+_NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_gemm_profile_cancel": [], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i, _i],
               "vnp_gemm_vn_stats_ws_floats": [_ll, _i], "vnp_gemm_tile_rows": [_i, _i, _i, _i, _i, _i], "vnp_bn1d_chunk_rows": []}
 _RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,
@@ -205,6 +217,8 @@ class KernelTimer:
 
     def __del__(self):
         try:                                    # (at interpreter shutdown the class attribute may already be gone)
+            if self._kind.value < 0 and _LIB is not None:
+                _LIB.vnp_gemm_profile_cancel()   # never consumed: make sure the library does not keep these handles
             h = KernelTimer._hip
             for e in (self.e0, self.e1):
                 if h is not None and e:

@@ -50,6 +50,17 @@ extern "C" int vnp_gemm_profile_next(hipEvent_t e0, hipEvent_t e1, int* kind)
     return 0;
 }
 
+// Drop a pending request (its events are about to be destroyed, or the armed call took a path that brackets no kernel).
+extern "C" int vnp_gemm_profile_cancel(void)
+{
+    g_vnp_prof = {nullptr, nullptr, nullptr};
+    return 0;
+}
+
+// Every matrix-product entry point holds one of these: a request that the call did not consume (argument error, a path without a
+// bracketed kernel) is dropped when the call returns instead of arming some later, unrelated launch with stale event handles.
+struct VnpProfScope { ~VnpProfScope() { g_vnp_prof = {nullptr, nullptr, nullptr}; } };
+
 static inline void vnp_prof_begin(hipStream_t st) { if (g_vnp_prof.e0) (void)hipEventRecord(g_vnp_prof.e0, st); }
 static inline void vnp_prof_end(hipStream_t st, int kind)
 {
@@ -71,27 +82,6 @@ static int vnp_num_cus()
         cached.store(n, std::memory_order_relaxed);
     }
     return n;
-}
-
-// VNP_GEMM_NO_XCD_SPLIT=1: split-K items in (slice, tile) order as before (A/B measurement of VnpGemmArgs::xcd_split)
-static bool vnp_no_xcd_split()
-{
-    static const bool v = getenv("VNP_GEMM_NO_XCD_SPLIT") != nullptr;
-    return v;
-}
-
-// VNP_GEMM_NO_ROWS96=1: no 96-row tiles (A/B measurement of the tile choice in vnp_gemm_impl)
-static bool vnp_no_rows96()
-{
-    static const bool v = getenv("VNP_GEMM_NO_ROWS96") != nullptr;
-    return v;
-}
-
-// VNP_GEMM_NO_WIDE=1: big aligned NT products on the 256-thread 192 x 128 kernel as before (A/B measurement of vnp_gemm_split_wide_kernel)
-static bool vnp_no_wide()
-{
-    static const bool v = getenv("VNP_GEMM_NO_WIDE") != nullptr;
-    return v;
 }
 
 // out[r][c] (+)= sum_z ws[z][r][c]; ws slabs are dense [M, N].  A workgroup = 64 consecutive outputs x 4 slab lanes: lane q sums the
@@ -252,11 +242,11 @@ static int vnp_choose_tile(int op_b, int M, int N, int nsplit, int nbatch, bool 
     double best = cost(192, 1.0, 1.45);
     const double c128 = cost(128, 0.77, 1.08);
     if (c128 < 0.97 * best) { best = c128; bm = 128; }
-    if (!has_bias && nbatch == 1 && !vnp_no_rows96()) {           // (the 96-row instantiations carry no bias epilogue and no batch walk)
+    if (!has_bias && nbatch == 1) {           // (the 96-row instantiations carry no bias epilogue and no batch walk)
         const double c96 = cost(96, 0.68, 0.95);
         if (c96 < 0.97 * best) { best = c96; bm = 96; }
     }
-    if (op_b == 0 && M % 192 == 0 && N % 256 == 0 && !vnp_no_wide()) {
+    if (op_b == 0 && M % 192 == 0 && N % 256 == 0) {
         const long long items_w = (long long)(M / 192) * (N / 256) * sb;
         const double cw = (double)((items_w + vnp_num_cus() - 1) / vnp_num_cus()) * 1.38;
         if (cw < 0.99 * best) { best = cw; bm = 192; wide = true; }
@@ -352,7 +342,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         p.C = C; p.ldc = ldc; p.slab = 0; p.accumulate = accumulate;
     }
     p.nsplit = nsplit; p.nbatch = nbatch;
-    p.xcd_split = (nsplit > 1 && nsplit % 8 == 0 && nbatch == 1 && vnp_gemm_get_mode() == 0 && !vnp_no_xcd_split()) ? 1 : 0;
+    p.xcd_split = (nsplit > 1 && nsplit % 8 == 0 && nbatch == 1 && vnp_gemm_get_mode() == 0) ? 1 : 0;
     p.col_group = 8;                     // measured: +3 % at N = 2048 (B panels of 8 column tiles stay in the XCD's L2)
     p.pool_val = nullptr; p.pool_idx = nullptr; p.pool_x = nullptr; p.pool_gs = 0;
     const bool split = vnp_gemm_get_mode() == 0;
@@ -396,7 +386,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     }
     else if (op_a == 0 && op_b == 0) VNP_LAUNCH(192, true, true);
     else if (op_a == 0 && op_b == 1) VNP_LAUNCH(192, true, false);
-    else if (op_a == 1 && op_b == 1 && split && fast && !h2 && M % 256 == 0 && !vnp_no_wide() &&
+    else if (op_a == 1 && op_b == 1 && split && fast && !h2 && !bias && M % 256 == 0 &&
              (long long)(M / 256) * (N / 128) * nsplit * nbatch >= vnp_num_cus() &&
              ((long long)(M / 256) * (N / 128) * nsplit * nbatch % vnp_num_cus() == 0 ||
               (long long)(M / 256) * (N / 128) * nsplit * nbatch >= 4LL * vnp_num_cus())) {
@@ -976,7 +966,7 @@ extern "C" int vnp_gemm_vn_stats_ex(hipStream_t st, int M, int N, int K, const f
     const long long items_w = (long long)(M / 192) * (N / 256);
     vnp_prof_begin(st);
     if (amax_a && K >= 64) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2, 1>), grid, block, 0, st, p);
-    else if (N % 256 == 0 && !vnp_no_wide() &&                                     // the wide tile where its rounds are cheaper (vnp_gemm_impl)
+    else if (N % 256 == 0 &&                                     // the wide tile where its rounds are cheaper (vnp_gemm_impl)
              (double)((items_w + vnp_num_cus() - 1) / vnp_num_cus()) * 1.38 <
              0.99 * ((double)(items / cap) * 1.45 + (items % cap == 0 ? 0.0 : 2 * (items % cap) <= cap ? 1.0 : 1.45)))
         hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<2>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, st, p);

@@ -213,9 +213,8 @@ extern "C" int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, in
     hipError_t e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_knn_select_kernel, 16384 * 4);
     if (e != hipSuccess) return (int)e;
     const dim3 rows((unsigned)((long long)B * Nq));
-    static const bool sorted_cols = getenv("VNP_KNN_SORTED_COLUMNS") != nullptr;          // A/B: the sorted-column selection
     // threshold selection (vnp_knc_select, defined with the coordinate kernel below): k <= 64
-    if (k <= 64 && Nr <= 4096 && !sorted_cols) {
+    if (k <= 64 && Nr <= 4096) {
         if (Nr <= 512)       hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<8>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
         else if (Nr <= 1024) hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<16>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
         else if (Nr <= 2048) hipLaunchKernelGGL(vnp_knn_select_threshold_kernel<32>, rows, dim3(64), 0, st, (const float*)ws, Nr, k, idx, dist);
@@ -385,8 +384,7 @@ extern "C" int vnp_knn(hipStream_t st, int B, int D, const float* ref, int Nr, c
                        int* idx, float* dist)
 {
     if (!ref || !qry || !idx || B <= 0 || D <= 0 || Nr <= 0 || Nq <= 0 || k <= 0 || k > Nr || B > 65535) return VNP_EINVAL;
-    static const bool no_coords = getenv("VNP_KNN_COORDS") != nullptr && getenv("VNP_KNN_COORDS")[0] == '0';
-    if (D == 3 && Nr <= 4096 && k <= 64 && !no_coords) {
+    if (D == 3 && Nr <= 4096 && k <= 64) {
         // one wave per query on register-resident distances, threshold selection (vnp_knn_coords_kernel)
         if (Nr <= 512)  return vnp_knn_coords_launch<8>(st, B, ref, Nr, qry, Nq, k, idx, dist);
         if (Nr <= 1024) return vnp_knn_coords_launch<16>(st, B, ref, Nr, qry, Nq, k, idx, dist);

@@ -23,7 +23,7 @@ def edge_conv_rows(layer: VNLinearLeakyReLU, x_rows, nbr, k):
     Cout = Wf.shape[0]
     bn = layer.batchnorm.bn
     layer.batchnorm._tick()
-    if ops.EDGE_FUSED:
+    if ops.SW.EDGE_FUSED:
         # ONE GEMM for u | v (x is read once, forward and backward), edge pre-activations u[nbr] + v recomputed inside each pass: the
         # [P*k*3, 2C'] tensor is never written
         uv = ops.VNLinearFn.apply(x_rows, ops.EdgeWeightsFn.apply(Wf, Wd), None, 0)        # [P*3, 4C']: u (feat | dir), v (feat | dir)

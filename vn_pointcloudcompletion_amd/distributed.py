@@ -46,6 +46,10 @@ def init_from_env(backend=None, timeout_s=None):
     rank, local_rank, world = env_world()
     if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         import datetime
+        if torch.cuda.is_available():
+            from . import _lib
+            _lib.build()             # a stale library is compiled BEFORE the rendezvous: a cold hipcc run must not eat a collective's timeout
+            _lib.lib()
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -282,6 +286,8 @@ class OverlappedGradReducer:
             self.works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=True), None))
         else:
             self.works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
+        if hasattr(self.fb, "mark_written"):
+            self.fb.mark_written(range(lo_i, hi_i))          # the slices hold the ranks' average from here on, not this rank's zeros
         self.launched = b + 1
 
     def _hook(self, p):
@@ -369,6 +375,7 @@ def allreduce_gradients(optimizer_or_params):
         for fb in flats:
             fb.check_views()
             allreduce_mean_(fb.flat_grad)
+            fb.mark_written()
         return
     for p in optimizer_or_params:
         if p.grad is not None:

@@ -1,0 +1,61 @@
+"""chamfer_3DFunction on libvnpcc (/root/reference/extensions/chamfer_distance/chamfer_distance.py:29-71)."""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+from .._lib import call, ptr
+from ._state import HK, SW, POOL_PATH_COUNTS, prof_arm, trace
+
+
+# both clouds at least this large -> vnp_chamfer_fwd_pruned (below it the brute-force kernel's slicing fills the chip better);
+# VNP_CHAMFER_BRUTE=1 forces the brute-force kernel everywhere
+# bench.py sets this to a list to receive, per pruned call, the device word with the number of (query, target) pairs the two scans
+# evaluated (int64 [1]; a full scan evaluates 2 B n m)
+
+
+class ChamferFn(Function):
+    """chamfer_3DFunction (extensions/chamfer_distance/chamfer_distance.py:29-71) on libvnpcc."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        _lib.require_gpu(xyz1, xyz2)
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        dev = xyz1.device
+        dist1 = torch.empty((B, n), device=dev, dtype=torch.float32)
+        dist2 = torch.empty((B, m), device=dev, dtype=torch.float32)
+        idx1 = torch.empty((B, n), device=dev, dtype=torch.int32)
+        idx2 = torch.empty((B, m), device=dev, dtype=torch.int32)
+        nbytes = _lib.lib().vnp_chamfer_pruned_ws_bytes(B, n, m) if min(n, m) >= SW.CHAMFER_PRUNED_MIN_POINTS else 0
+        if nbytes > 0:
+            # dense clouds: pruned exact search (same bits as the brute-force kernel; tests/test_gpu_chamfer.py)
+            ws = torch.empty((nbytes + 7) // 8, device=dev, dtype=torch.int64)
+            call("vnp_chamfer_fwd_pruned", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
+            trace("chamfer_pruned")
+            if HK.chamfer_stats is not None:
+                HK.chamfer_stats.append(ws[1:2].clone())
+        else:
+            trace("chamfer_brute")
+            ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
+            call("vnp_chamfer_fwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1), ptr(idx1), ptr(dist2), ptr(idx2), ptr(ws))
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, dist2, idx1, idx2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g1, g2, _gi1, _gi2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        gx1 = torch.empty_like(xyz1)
+        gx2 = torch.empty_like(xyz2)
+        call("vnp_chamfer_bwd", B, n, ptr(xyz1), m, ptr(xyz2), ptr(g1), ptr(idx1), ptr(g2), ptr(idx2), ptr(gx1), ptr(gx2))
+        return gx1, gx2
+
+

@@ -1,0 +1,261 @@
+"""kNN, FPS, point gathers and the EdgeConv Functions of configs 3 and 5 (replace KNN_CUDA / pointnet2_ops and
+/root/reference/models/dgcnn.py:201-278)."""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+from .._lib import call, ptr
+from ._state import HK, SW, POOL_PATH_COUNTS, prof_arm, trace
+from .core import (BN_EPS, BN_MOMENTUM, _bn_leaky_backward, _bn_leaky_forward, _bn_statistics, _chunk_pc, _dgrad, _ld, _nchunk,
+                   _per_sample_colsum, _rows, _wgrad, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
+
+
+def knn_indices(ref, query, k, return_dist=False):
+    """ref [B,Nr,D], query [B,Nq,D] (point-major, fp32, contiguous) -> idx [B,Nq,k] int32 local indices, sorted by
+    (squared distance, index).  Replaces KNN_CUDA (models/dgcnn.py:11,236)."""
+    _lib.require_gpu(ref, query)
+    ref, query = ref.contiguous().float(), query.contiguous().float()
+    B, Nr, D = ref.shape
+    Nq = query.shape[1]
+    idx = torch.empty((B, Nq, k), device=ref.device, dtype=torch.int32)
+    dist = torch.empty((B, Nq, k), device=ref.device, dtype=torch.float32) if return_dist else None
+    forced = HK.knn_force
+    if forced is not None and not return_dist:
+        # TEST HOOK (teacher forcing, tests/test_gpu_grad_parity.py): the next recorded neighbour table instead of this search
+        f = forced.pop(0).to(device=ref.device, dtype=torch.int32).contiguous()
+        if f.shape != idx.shape:
+            raise _lib.VnpError(f"knn_force: table {tuple(f.shape)} offered to a search of shape {tuple(idx.shape)}")
+        trace("knn_forced", f, key="knn_idx")
+        return f
+    if D == 3 and Nr <= 4096 and k <= 64:
+        # coordinate graphs: one wave per query on register-resident distances with a threshold selection, no distance matrix
+        # (vnp_knn_coords_kernel behind vnp_knn; same bits and order)
+        call("vnp_knn", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist))
+    elif Nr <= 16384 and Nq * Nr >= 4096 and B * Nq * Nr <= (1 << 29):
+        # distance matrix once + per-row selection instead of k full passes per query (same bits as vnp_knn; ~50x faster for the
+        # feature-space graphs at D = 192, ~3x for coordinates)
+        ws = torch.empty(B * Nq * Nr, device=ref.device, dtype=torch.float32)
+        call("vnp_knn_matrix", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist), ptr(ws))
+    else:
+        call("vnp_knn", B, D, ptr(ref), Nr, ptr(query), Nq, k, ptr(idx), ptr(dist))
+    if not return_dist:
+        trace("knn", idx, key="knn_idx")
+    return (idx, dist) if return_dist else idx
+
+
+def fps_indices(xyz, m, skip_near_origin=None):
+    """furthest_point_sample(xyz[B,N,3], m) -> idx [B,m] int32 (starts at 0).  Replaces pointnet2_ops (models/pcn.py:7).
+    pointnet2_ops' furthest_point_sampling_kernel skips candidates with |p|^2 <= 1e-3 (`if (mag <= 1e-3) continue;`): on clouds
+    centred at the origin ~0.3 points per 2048 fall inside that ball and would be picked by plain FPS but never by the package the
+    reference calls.  Default: the package's convention (so reference checkpoints see the centres they were trained with);
+    VNP_FPS_PLAIN=1 (or skip_near_origin=False) selects plain FPS.  PARITY UNPINNED either way (third-party source absent)."""
+    _lib.require_gpu(xyz)
+    xyz = xyz.contiguous().float()
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, m), device=xyz.device, dtype=torch.int32)
+    skip = SW.FPS_SKIP_NEAR_ORIGIN if skip_near_origin is None else bool(skip_near_origin)
+    call("vnp_fps_ex", B, N, ptr(xyz), m, ptr(idx), 1 if skip else 0)
+    trace("fps", idx, key="fps_idx")
+    return idx
+
+
+class GatherPointsFn(Function):
+    """rows layout: out point i <- x point src[i] (global point ids, int32 [Pout]).  gather_operation of pointnet2_ops
+    (models/dgcnn.py:214-218) on VN features; backward = scatter-add."""
+
+    @staticmethod
+    def forward(ctx, x, src):
+        x = _rows(x)
+        src = src.reshape(-1).contiguous()
+        P_out, W = src.numel(), x.shape[1]
+        out = torch.empty((P_out * 3, W), device=x.device, dtype=torch.float32)
+        call("vnp_gather_points", ptr(x), _ld(x), ptr(src), P_out, W, ptr(out), W)
+        ctx.save_for_backward(src)
+        ctx.cfg = (x.shape[0] // 3, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (src,) = ctx.saved_tensors
+        P_in, W = ctx.cfg
+        g = _rows(g)
+        gx = torch.empty((P_in * 3, W), device=g.device, dtype=torch.float32)
+        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(src), src.numel(), W, ptr(gx), W, P_in)
+        return gx, None
+
+
+class EdgeGatherAddFn(Function):
+    """Edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278) after the layer's linear maps:
+    out[(p,j)] = u[nbr[p,j]] + v[p], with u = x W1^T and v = x (W2-W1)^T computed per POINT (k times fewer GEMM rows than
+    applying W to cat(feature - x, x) per EDGE).  nbr: global point ids [P,k] int32."""
+
+    @staticmethod
+    def forward(ctx, u, v, nbr):
+        u, v = _rows(u), _rows(v)
+        nbr = nbr.contiguous()
+        P, k = nbr.shape
+        W = u.shape[1]
+        out = torch.empty((P * k * 3, W), device=u.device, dtype=torch.float32)
+        call("vnp_edge_gather_add", ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), P, k, W, ptr(out), W)
+        ctx.save_for_backward(nbr)
+        ctx.cfg = (u.shape[0] // 3, P, k, W)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (nbr,) = ctx.saved_tensors
+        Pu, P, k, W = ctx.cfg
+        g = _rows(g)
+        dev = g.device
+        gu = torch.empty((Pu * 3, W), device=dev, dtype=torch.float32)
+        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(nbr), P * k, W, ptr(gu), W, Pu)
+        gv = torch.empty((P * 3, W), device=dev, dtype=torch.float32)
+        call("vnp_vn_mean_pool_fwd", ptr(g), _ld(g), P, k, W, ptr(gv), W)          # mean over k ...
+        gv.mul_(float(k))                                                          # ... times k = sum
+        return gu, gv, None
+
+
+
+
+def edge_reverse(nbr, Pu):
+    """Reverse adjacency (start [Pu + 1], rev [Pq * k]) of a neighbour table, cached on the tensor: layers that share a graph share it."""
+    cached = getattr(nbr, "_vnp_rev", None)
+    if cached is not None and cached[0].shape[0] == Pu + 1:
+        return cached
+    Pq, k = nbr.shape
+    start = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
+    rev = torch.empty(Pq * k, device=nbr.device, dtype=torch.int32)
+    ws = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
+    call("vnp_edge_reverse", ptr(nbr), Pq, k, Pu, ptr(start), ptr(rev), ptr(ws))
+    nbr._vnp_rev = (start, rev)
+    return start, rev
+
+
+def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
+    """The two forward passes of the fused EdgeConv on u [Pu*3, >= 2C], v [Pq*3, >= 2C] (row strides free): (out, mean, rstd, nblk)."""
+    Pq, k = nbr.shape
+    C = u.shape[1] // 2
+    dev = u.device
+    qb = _lib.lib().vnp_edge_block_queries()
+    nblk = (Pq + qb - 1) // qb
+    if training:
+        part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
+        call("vnp_edge_fused", 0, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
+             ptr(part), None, 0, None, 0, None, 0, None, 0, 0, None, 0)
+        mean = torch.empty(C, device=dev, dtype=torch.float32)
+        rstd = torch.empty(C, device=dev, dtype=torch.float32)
+        call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
+             ptr(running_var), BN_MOMENTUM, BN_EPS)
+    else:
+        mean = running_mean
+        rstd = torch.empty(C, device=dev, dtype=torch.float32)
+        call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+    out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
+    call("vnp_edge_fused", 1, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+         float(ns), None, ptr(out), C, None, 0, None, 0, None, 0, 0, None, 0)
+    return out, mean, rstd, nblk
+
+
+def _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv):
+    """The backward passes: fills gu [Pu*3, >= 2C] and gv [Pq*3, >= 2C] (row strides free: column halves of one buffer in the packed
+    form) and returns the per-channel sums as planar [2, C] rows (dL/dbeta, dL/dgamma)."""
+    Pq, k = nbr.shape
+    C = u.shape[1] // 2
+    Pu = u.shape[0] // 3
+    part = torch.empty((nblk, C, 2), device=go.device, dtype=torch.float32)
+    call("vnp_edge_fused", 2, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+         ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0, 0, None, 0)
+    S, planar = reduce_pairs(part, nblk, C)
+    sums = ptr(S) if training else None
+    # gv per query; gu per SOURCE point through the reverse adjacency (built once per graph: conv4 / conv5 share theirs) — a gather
+    # with plain stores instead of float atomics
+    start, rev = edge_reverse(nbr, Pu)
+    call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+         None, None, 0, ptr(go), _ld(go), sums, Pq * k, None, 0, 0, ptr(gv), _ld(gv))
+    call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
+         ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
+    return planar
+
+
+class EdgeConvFn(Function):
+    """VNLinearLeakyReLU on the kNN edge tensor followed by mean_pool over the k neighbours, with the edge tensor never
+    materialised (vnp_edge_fused): u, v = the layer's linear maps applied per point ([P*3, 2C'], columns feat | dir),
+    nbr [Pq, k] global neighbour ids.  Equivalent to EdgeGatherAddFn -> VNBnLeakyFn -> VNMeanPoolFn."""
+
+    @staticmethod
+    def forward(ctx, u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
+        u, v = _rows(u), _rows(v)
+        nbr = nbr.contiguous()
+        out, mean, rstd, nblk = _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns)
+        ctx.save_for_backward(u, v, nbr, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), float(ns), nblk)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        u, v, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, ns, nblk = ctx.cfg
+        go = _rows(go)
+        C = u.shape[1] // 2
+        gu = torch.empty((u.shape[0], 2 * C), device=go.device, dtype=torch.float32)
+        gv = torch.empty((v.shape[0], 2 * C), device=go.device, dtype=torch.float32)
+        S = _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv)
+        return gu, gv, None, S[1], S[0], None, None, None, None
+
+
+class EdgeConvPackedFn(Function):
+    """EdgeConvFn for a graph on ONE point set with u and v side by side in one matrix uv [P*3, 4C'] = x [Wu; Wv]^T (one GEMM instead
+    of two, forward and backward): u = uv[:, :2C'], v = uv[:, 2C':]; the gradient comes back as one [P*3, 4C'] matrix whose column halves
+    the backward kernels fill in place (no zero-padded slice gradients, no add)."""
+
+    @staticmethod
+    def forward(ctx, uv, nbr, gamma, beta, running_mean, running_var, training, ns):
+        uv = _rows(uv)
+        nbr = nbr.contiguous()
+        C2 = uv.shape[1] // 2
+        out, mean, rstd, nblk = _edge_conv_forward(uv[:, :C2], uv[:, C2:], nbr, gamma, beta, running_mean, running_var, training, ns)
+        ctx.save_for_backward(uv, nbr, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), float(ns), nblk)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        uv, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, ns, nblk = ctx.cfg
+        go = _rows(go)
+        C2 = uv.shape[1] // 2
+        guv = torch.empty_like(uv)
+        S = _edge_conv_backward(go, uv[:, :C2], uv[:, C2:], nbr, gamma, beta, mean, rstd, training, ns, nblk, guv[:, :C2], guv[:, C2:])
+        return guv, None, S[1], S[0], None, None, None, None
+
+
+class EdgeWeightsFn(Function):
+    """[Wu; Wv] [4C', C] of an EdgeConv layer from its VNLinearLeakyReLU weights Wf, Wd [C', 2C] (input channels: C of feature - x, then C
+    of x): W cat(f_j - x, x) = W1 f_j + (W2 - W1) x, so Wu = [Wf1; Wd1] acts on the neighbour and Wv = [Wf2 - Wf1; Wd2 - Wd1] on the centre.
+    One Function instead of eight autograd nodes of slices, subtractions and concatenations per layer and step."""
+
+    @staticmethod
+    def forward(ctx, Wf, Wd):
+        C = Wf.shape[1] // 2
+        W = torch.stack([Wf, Wd])                                # [2, C', 2C]
+        a, b = W[:, :, :C], W[:, :, C:]
+        ctx.C = C
+        return torch.cat([a.reshape(-1, C), (b - a).reshape(-1, C)], dim=0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        C = ctx.C
+        half = g.shape[0] // 2
+        gu, gv = g[:half], g[half:]
+        gW = torch.cat([(gu - gv).reshape(2, -1, C), gv.reshape(2, -1, C)], dim=2)      # [2, C', 2C]: d/dW1 = gu - gv, d/dW2 = gv
+        return gW[0], gW[1]
+
+

@@ -26,7 +26,7 @@ class FlatBuffers:
     """Re-homes ``params`` (and their ``.grad``) into one flat parameter buffer and one flat gradient buffer.
 
     Two ways for the gradients to reach the flat buffer:
-      * in place (CPU tensors; ``VNP_GRAD_INPLACE=1``): every ``p.grad`` IS its slice of ``flat_grad``, the buffer is zeroed per step and
+      * in place (CPU tensors; ``gathered=False``): every ``p.grad`` IS its slice of ``flat_grad``, the buffer is zeroed per step and
         autograd adds each incoming gradient into the slice — one small add launch per parameter per step (config 5: 190 of them);
       * gathered (device tensors, the default): ``zero_grad`` empties ``p.grad``, autograd keeps each incoming gradient tensor as it is
         (no add, no zero-fill), and ``gather`` copies them to their slices with one launch per 48 tensors (``vnp_pack_tensors``), after
@@ -48,7 +48,7 @@ class FlatBuffers:
         self.numel = off
         self.flat_param = torch.zeros(off, device=dev, dtype=torch.float32)
         self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.gathered = (dev.type == "cuda" and os.environ.get("VNP_GRAD_INPLACE", "0") != "1") if gathered is None else bool(gathered)
+        self.gathered = (dev.type == "cuda") if gathered is None else bool(gathered)
         if self.gathered and dev.type != "cuda":
             raise ValueError("gathered gradients need the device library (vnp_pack_tensors)")
         self._zero = [True] * len(self.params)            # slice i of flat_grad is known to hold zeros
@@ -118,6 +118,15 @@ class FlatBuffers:
                 _lib.call("vnp_pack_tensors", n, ctypes.addressof(a_src), ctypes.addressof(a_off), ctypes.addressof(a_num),
                           self.flat_grad.data_ptr())
         del keep                                      # the sources stayed alive until the launch was queued on their stream
+
+    def mark_written(self, indices=None):
+        """Something other than ``gather`` wrote into the slices of ``indices`` (default: all) — a collective that left the average of
+        the ranks' gradients there, a host-staged transport, a test.  A slice that ``gather`` had left as known zeros (its parameter
+        received no gradient on THIS rank) may hold another rank's contribution now, so it loses the mark and is zero-filled again the
+        next time its parameter comes up without a gradient; otherwise the stale average would be reduced and applied once more."""
+        zero = self._zero
+        for i in (range(len(zero)) if indices is None else indices):
+            zero[i] = False
 
     def check_views(self):
         """Every gradient produced by autograd must be in the flat buffer before it is reduced or applied."""

@@ -58,12 +58,12 @@ class VN_PointNet(nn.Module):
         B, N, _ = xyz.shape
         W1 = self.first_conv[1].map_to_feat.weight
         l1, l2 = self.first_conv[0], self.second_conv[0]
-        dir_ok = (ops.ENC_LINEAR_REASSOCIATE and ops.ENC_DIR_LAYER and not l1.share_nonlinearity and not l2.share_nonlinearity
+        dir_ok = (ops.SW.ENC_LINEAR_REASSOCIATE and ops.SW.ENC_DIR_LAYER and not l1.share_nonlinearity and not l2.share_nonlinearity
                   and ops.VNDirLinearLeakyFn.supported(B * N, l2.map_to_feat.weight.shape[0], N, True))
         # first_conv[0] has ONE input channel, the point itself (x = u |x| with the unit direction u): each of its output vectors is a
         # multiple of u, a1 = u (x) h, and second_conv[0] — folded onto first_conv[1]'s 128 input channels, see below — runs on the
         # per-point scalars h and rebuilds its pre-activations u v + bias in registers (ops.VNDirLinearLeakyFn)
-        if dir_ok and ops.ENC_FIRST_LAYER_SCALAR and _lib.get_gemm_mode() == "split":
+        if dir_ok and ops.SW.ENC_FIRST_LAYER_SCALAR and _lib.get_gemm_mode() == "split":
             # the first layer itself on the per-point scalar |x|, returning h (scalar_out).  (Default GEMM mode only: VNP_GEMM_MODE=fp32 is the conservative comparison path and keeps the
             # first layer in the rows layout)
             u, r = ops.unit_dirs(xyz, return_norm=True)
@@ -75,7 +75,7 @@ class VN_PointNet(nn.Module):
             if dir_ok:
                 u = ops.unit_dirs(xyz)
                 h = ops.DirContractFn.apply(a1, u)
-        if ops.ENC_LINEAR_REASSOCIATE:
+        if ops.SW.ENC_LINEAR_REASSOCIATE:
             # first_conv[1] is a linear map whose output f = W1 a1 [B*N*3, 512] feeds maxpool1 and — behind the concatenation —
             # second_conv[0]'s linear maps (pcn.py:168-173): the pool takes f from its fused GEMM without storing it, and
             # second_conv[0] contracts (W W1) with a1 over first_conv[1]'s 128 input channels instead of W with f over 512

@@ -4,7 +4,7 @@
 Every class has two entry points:
   * ``forward(x)`` takes / returns the reference layout ``[B, C, 3, N]`` or ``[B, C, 3, N, K]`` and is what a
     user of the reference calls;
-  * ``forward_rows(rows, ...)`` takes / returns the internal rows layout ``[P*3, C]`` (see ops.py) and is what
+  * ``forward_rows(rows, ...)`` takes / returns the internal rows layout ``[P*3, C]`` (see ops/__init__.py) and is what
     the networks in pcn.py chain, so that no layout conversion happens between layers.
 Parameters are held by ``nn.Linear(bias=False)`` / ``nn.BatchNorm*`` members exactly as in the reference, which
 keeps the ``state_dict`` keys and the default-init RNG stream identical (same seed -> same weights).
@@ -93,8 +93,17 @@ def end_deferred_ticks(prev):
     if prev is None and _DEFERRED_TICKS is not None:
         pending, _DEFERRED_TICKS = _DEFERRED_TICKS, None
         if pending:
+            # a layer that ran twice in this forward is in the list twice: the multi-tensor add does not order its read-modify-writes on
+            # one tensor, so duplicates are counted and each counter is touched once
+            counts = {}
+            for c in pending:
+                counts.setdefault(id(c), [c, 0])[1] += 1
             with torch.no_grad():
-                torch._foreach_add_(pending, 1)
+                if all(n == 1 for _, n in counts.values()):
+                    torch._foreach_add_(pending, 1)
+                else:
+                    for c, n in counts.values():
+                        c.add_(n)
 
 
 class VNBatchNorm(nn.Module):
@@ -157,7 +166,7 @@ class VNLinearLeakyReLU(nn.Module):
         cat([global.expand(n), x], dim=1) (``global_first``, models/pcn.py:172) or cat([x, global.expand(n)], dim=1)
         (models/pcn.py:486,488) without materialising the broadcast; a group is ``rows_per_group``/3 consecutive points.
         ``pre_linear`` [Cx, K0]: the per-point input x is the (never materialised) output ``rows @ pre_linear.T`` of a VNLinear; the
-        layer's weights are folded onto that layer's K0 input channels (ops.ENC_LINEAR_REASSOCIATE)."""
+        layer's weights are folded onto that layer's K0 input channels (ops.SW.ENC_LINEAR_REASSOCIATE)."""
         bn = self.batchnorm.bn
         self.batchnorm._tick()
         Wf, Wd = self.map_to_feat.weight, self.map_to_dir.weight
@@ -174,7 +183,7 @@ class VNLinearLeakyReLU(nn.Module):
             bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
                               ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
         if pre_linear is not None:
-            ops._trace("linear_folded_onto_producer")
+            ops.trace("linear_folded_onto_producer")
             Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
         if (bias is not None and pre_linear is None and rows_per_group % 3 == 0 and rows.dim() == 2
                 and ops.group_fold_ok(rows.shape[1], rows_per_group // 3, Wf.shape[0])):
@@ -201,7 +210,7 @@ class VNLinearLeakyReLU(nn.Module):
             bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
                               ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
         if pre_linear is not None:
-            ops._trace("linear_folded_onto_producer")
+            ops.trace("linear_folded_onto_producer")
             Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
         return ops.VNDirLinearLeakyFn.apply(h, u, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                             points_per_group, self.training, self.negative_slope, pre_linear is not None, scalar_out)
@@ -245,7 +254,7 @@ class VNMaxPool(nn.Module):
 
     def forward_rows(self, rows, groups, group_size, return_index=False, producer=None):
         """``producer`` = (x_prev, VNLinear) when ``rows`` is that layer's output: lets the direction GEMM contract over the
-        producer's input channels (ops.POOL_DIRECTION_REASSOCIATE)."""
+        producer's input channels (ops.SW.POOL_DIRECTION_REASSOCIATE)."""
         xp, wp = (producer[0].detach(), producer[1].map_to_feat.weight.detach()) if producer is not None else (None, None)
         out, idx = ops.VNMaxPoolFn.apply(rows, self.map_to_dir.weight.detach(), groups, group_size, xp, wp)
         return (out, idx) if return_index else out
