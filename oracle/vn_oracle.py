@@ -541,26 +541,30 @@ def pointr_vn_block(sd, prefix, x, knn_idx, training=True, new_stats=None):
     return vn_x.reshape(B, -1, N).transpose(1, 2)
 
 
-def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encoder", new_stats=None, teacher=None):
-    """models/pointr/vn_pointr.py:575-722 (VN_PCTransformer.forward, dgcnn='vn_dgcnn', trans='vn_trans', only_coarse=True).
-    inpc [B,N,3] -> (coarse [B,1248,3], global_feature [B,1024,3,1]).  ``teacher``: see Teacher (call order: the grouper's four graphs
-    and two FPS stages, the k = 8 coordinate graph, the global pool, the FPS-224 subset)."""
+def pointr_embed(sd, prefix, f, coor, inpc, training=True, new_stats=None):
+    """models/vn_pointr.py:585-637 (vn_input_proj on the grouper's features; fourth_vn_pos_embed on [proxy coordinate, cloud centre]).
+    f [B,128,3,nc], coor [B,nc,3], inpc [B,N,3] -> (tokens x [B,nc,384], pos [B,nc,384])."""
     p = prefix
-    B = inpc.shape[0]
-    T = teacher or _FREE
-    coor, f = vn_dgcnn_grouper_forward(sd, f"{p}.grouper", inpc, training, 16, new_stats, teacher=T)      # [B,128,3], [B,128,3,128]
-    nc = f.shape[-1]
+    B, nc = f.shape[0], f.shape[-1]
     f = vn_linear(_lin_leaky(sd, f"{p}.vn_input_proj.0", f, training, new_stats), sd[f"{p}.vn_input_proj.1.map_to_feat.weight"])
     x = f.reshape(B, -1, nc).transpose(1, 2)
-    knn_idx = T.take_knn(coor, coor, 8)
     centers = inpc.mean(dim=1)
     pos_in = torch.cat([coor.transpose(1, 2).unsqueeze(1), centers.unsqueeze(-1).expand(-1, -1, nc).unsqueeze(1)], dim=1)   # [B,2,3,nc]
     pos = vn_linear(_lin_and_leaky_bn(sd, f"{p}.fourth_vn_pos_embed.0", pos_in, training, new_stats),
                     sd[f"{p}.fourth_vn_pos_embed.1.map_to_feat.weight"]).reshape(B, -1, nc).transpose(1, 2)
-    for i in range(6):
-        x = pointr_vn_block(sd, f"{p}.encoder.{i}", x + pos, knn_idx if i < knn_layer else None, training, new_stats)
+    return x, pos
+
+
+def pointr_head(sd, prefix, x, training=True, new_stats=None, teacher=None, trace=None):
+    """models/vn_pointr.py:655-668, 700-719: vn_increase_dim -> vn_global_pool -> vn_coarse_pred.
+    x [B,nc,384] tokens -> (coarse [B,1024,3], global_feature [B,1024,3,1])."""
+    p = prefix
+    T = teacher or _FREE
+    B, nc, _ = x.shape
     vn_x = x.transpose(1, 2).reshape(B, -1, 3, nc)
     g = vn_linear(_lin_and_leaky_bn(sd, f"{p}.vn_increase_dim.0", vn_x, training, new_stats), sd[f"{p}.vn_increase_dim.1.map_to_feat.weight"])
+    if trace is not None:
+        trace["pre_pool"] = g.detach()
     forced = T.take_pool(None)
     g, own_idx, dot = vn_max_pool(g, sd[f"{p}.vn_global_pool.map_to_dir.weight"], True, forced)
     T.taken["pool"].append(own_idx)
@@ -570,6 +574,29 @@ def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encod
     h = vn_linear(g, sd[f"{p}.vn_coarse_pred.0.map_to_feat.weight"])
     h = vn_leaky_relu(h, sd[f"{p}.vn_coarse_pred.1.map_to_dir.weight"])
     h = vn_linear(h, sd[f"{p}.vn_coarse_pred.2.map_to_feat.weight"]).squeeze(-1)                  # [B,1024,3]
+    return h, g
+
+
+def vn_pctransformer_forward(sd, inpc, training=True, knn_layer=1, prefix="encoder", new_stats=None, teacher=None, trace=None):
+    """models/pointr/vn_pointr.py:575-722 (VN_PCTransformer.forward, dgcnn='vn_dgcnn', trans='vn_trans', only_coarse=True).
+    inpc [B,N,3] -> (coarse [B,1248,3], global_feature [B,1024,3,1]).  ``teacher``: see Teacher (call order: the grouper's four graphs
+    and two FPS stages, the k = 8 coordinate graph, the global pool, the FPS-224 subset).  ``trace`` receives the stage tensors
+    (grouper_coor / grouper_f, tok_in, pos, knn8, blk0 .. blk5, pre_pool) for the stage-wise parity tests."""
+    p = prefix
+    T = teacher or _FREE
+    cap = (lambda k, v: trace.__setitem__(k, v.detach())) if trace is not None else (lambda k, v: None)
+    coor, f = vn_dgcnn_grouper_forward(sd, f"{p}.grouper", inpc, training, 16, new_stats, teacher=T)      # [B,128,3], [B,128,3,128]
+    cap("grouper_coor", coor)
+    cap("grouper_f", f)
+    x, pos = pointr_embed(sd, p, f, coor, inpc, training, new_stats)
+    cap("tok_in", x)
+    cap("pos", pos)
+    knn_idx = T.take_knn(coor, coor, 8)
+    cap("knn8", knn_idx)
+    for i in range(6):
+        x = pointr_vn_block(sd, f"{p}.encoder.{i}", x + pos, knn_idx if i < knn_layer else None, training, new_stats)
+        cap(f"blk{i}", x)
+    h, g = pointr_head(sd, p, x, training, new_stats, T, trace)
     i = T.take_fps(inpc, 224)
     sparse = torch.gather(inpc, 1, i[..., None].expand(-1, -1, 3))
     return torch.cat([h, sparse], dim=1).contiguous(), g

@@ -38,7 +38,8 @@ class _BatchNorm1dActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, slope):
-        from .ops import call, ptr, _ld, _rows, reduce_pairs
+        from ._lib import call, ptr
+        from .ops import _ld, _rows, reduce_pairs
         x = _rows(x)
         P, C = x.shape
         dev = x.device
@@ -63,7 +64,8 @@ class _BatchNorm1dActFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        from .ops import call, ptr, _ld, _rows, reduce_pairs
+        from ._lib import call, ptr
+        from .ops import _ld, _rows, reduce_pairs
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         training, act, slope = ctx.cfg
         gy = _rows(gy)

@@ -51,7 +51,7 @@ class _DensitySideFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dist, idx, n_targets, alpha, n_lambda, frac):
-        from .ops import call, ptr
+        from ._lib import call, ptr
         dist = dist.contiguous()
         idx = idx.to(torch.int32).contiguous()
         B, N = dist.shape

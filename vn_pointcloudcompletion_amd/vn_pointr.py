@@ -206,26 +206,37 @@ class VN_PCTransformer(nn.Module):
             nn.init.constant_(m.weight.data, 1)
             nn.init.constant_(m.bias.data, 0)
 
-    def forward(self, inpc):
-        """inpc [B,N,3] -> (coarse [B, 1024+224, 3], global_feature [B,1024,3,1])."""
-        B = inpc.shape[0]
-        inpc = inpc.contiguous().float()
-        coor, f = self.grouper.forward_rows(inpc)                               # [B,128,3], [B*128*3, 128]
-        nc = coor.shape[1]
+    def embed_rows(self, inpc, coor, f):
+        """vn_pointr.py:585-637: (token rows x [B*nc*3, 128], position rows [B*nc*3, 128]) from the grouper's proxies."""
+        B, nc = coor.shape[0], coor.shape[1]
         x = self.vn_input_proj[1].forward_rows(self.vn_input_proj[0].forward_rows(f))
-        nbr = knn_graph(coor, 8)                                                # get_knn_index(coor), k = 8 (vn_pointr.py:10,17-29)
         centers = inpc.mean(dim=1)                                              # [B,3]
         pos_in = torch.stack([coor, centers.unsqueeze(1).expand(-1, nc, -1)], dim=-1).reshape(B * nc * 3, 2)
         pos = self.fourth_vn_pos_embed[1].forward_rows(self.fourth_vn_pos_embed[0].forward_rows(pos_in))
-        for i, blk in enumerate(self.encoder):
-            x = blk.forward_rows(x + pos, B, nc, nbr if i < self.knn_layer else None)
+        return x, pos
+
+    def head_rows(self, x, B, nc):
+        """vn_pointr.py:655-668, 700-719: vn_increase_dim -> vn_global_pool -> vn_coarse_pred on token rows x [B*nc*3, 128]:
+        (coarse [B,1024,3], global_feature [B,1024,3,1])."""
         g = self.vn_increase_dim[0].forward_rows(x)
         pooled, _ = ops.VNLinearMaxPoolFn.apply(g, self.vn_increase_dim[1].map_to_feat.weight,
                                                 self.vn_global_pool.map_to_dir.weight.detach(), B, nc)   # [B*3, 1024]
         h = self.vn_coarse_pred[0].forward_rows(pooled)
         h = self.vn_coarse_pred[1].forward_rows(h)
         h = self.vn_coarse_pred[2].forward_rows(h)                              # [B*3, 1024]
-        coarse = h.reshape(B, 3, -1).permute(0, 2, 1).contiguous()
+        return h.reshape(B, 3, -1).permute(0, 2, 1).contiguous(), rows_to_global(pooled, B)
+
+    def forward(self, inpc):
+        """inpc [B,N,3] -> (coarse [B, 1024+224, 3], global_feature [B,1024,3,1])."""
+        B = inpc.shape[0]
+        inpc = inpc.contiguous().float()
+        coor, f = self.grouper.forward_rows(inpc)                               # [B,128,3], [B*128*3, 128]
+        nc = coor.shape[1]
+        x, pos = self.embed_rows(inpc, coor, f)
+        nbr = knn_graph(coor, 8)                                                # get_knn_index(coor), k = 8 (vn_pointr.py:10,17-29)
+        for i, blk in enumerate(self.encoder):
+            x = blk.forward_rows(x + pos, B, nc, nbr if i < self.knn_layer else None)
+        coarse, global_feature = self.head_rows(x, B, nc)
         inp_sparse = fps(inpc, 224)
         coarse = torch.cat([coarse, inp_sparse], dim=1).contiguous()
-        return coarse, rows_to_global(pooled, B)
+        return coarse, global_feature
