@@ -51,7 +51,8 @@ def parse_args():
     ap.add_argument("--num-coarse", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-input-MFMA comparison steps (clean profiles)")
-    ap.add_argument("--no-extras", action="store_true", help="skip roofline_other / chamfer_op (clean profiles)")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_other / chamfer_op / configs (clean profiles)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 3, 4, 5 leg (`configs`)")
     ap.add_argument("--deadline", type=float, default=float(os.environ.get("VNP_BENCH_DEADLINE_S", "900")),
                     help="self-launched ranks (--gpus N without a launcher): wall-clock limit in seconds after which the launcher "
                          "terminates every rank and exits non-zero (a rank stuck in the rendezvous would otherwise hold the others)")
@@ -141,7 +142,10 @@ def cpu_baseline(threads):
                 v.grad = None
         per_b[B] = min(times)
     best_b = max(per_b, key=lambda b: b * 16384.0 / per_b[b])
-    return {"value": best_b * 16384.0 / per_b[best_b], "unit": "points/s", "cores": threads, "kind": "port",
+    return {"value": best_b * 16384.0 / per_b[best_b], "unit": "points/s", "cores": threads, "threads_used": threads,
+            "cores_available": os.cpu_count(), "kind": "port",
+            "nearest_neighbour_search": "oracle/chamfer_oracle.c (OpenMP restatement of chamfer3D.cu), NOT the reference's pure-PyTorch "
+                                        "distChamfer (~80 s per 16384^2 cloud): a faster CPU baseline than the reference's own",
             "s_per_step": {f"B={b}": round(t, 2) for b, t in per_b.items()},
             "s_per_cloud": {f"B={b}": round(t / b, 2) for b, t in per_b.items()},
             "sample": "torch-CPU oracle, B=1 and B=2 of the B=32 step at full resolution (2048->1024->16384), fwd+2xCD-L1+bwd, "
@@ -536,7 +540,13 @@ def main():
         if world == 1 and not args.no_extras:
             del model, opt
             torch.cuda.empty_cache()
-            for key, fn in (("roofline_other", lambda: roofline_other(B, N, Mc, Md)), ("chamfer_op", chamfer_op_bench)):
+            import bench_extras
+            legs = [("roofline_other", lambda: roofline_other(B, N, Mc, Md) + bench_extras.roofline_other_configs()),
+                    ("chamfer_op", chamfer_op_bench)]
+            if not args.no_configs:
+                # the other BASELINE configurations at full batch and resolution: 3 untimed + 5 timed steps each
+                legs.append(("configs", lambda: bench_extras.other_configs(steps=5, warmup=3)))
+            for key, fn in legs:
                 try:
                     out[key] = fn()
                 except Exception as e:                              # an extra leg must never hide the GPU number
@@ -549,7 +559,8 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))      # the GPU box gives 16 cores per GPU
             except Exception as e:                                  # the baseline must never hide the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
+                out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": min(16, os.cpu_count() or 1),
+                                       "cores_available": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out))
     D.barrier()
