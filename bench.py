@@ -441,7 +441,7 @@ def main():
             nprod = 1.0 if scr[0][4] == 3 else 3.0
             sf, st = sum(r[1] for r in scr) * nprod, sum(r[5] for r in scr)
             speak = PEAK_BF16_MFMA_TFLOPS                    # fp16 and bf16 dense MFMA peaks are equal
-            screen_entry = {"kernel": ("vnp_screen_f16_wide_kernel / vnp_gemm_split_kernel<..., EPI = 4>: screening pass of the exact arg-max pool "
+            screen_entry = {"kernel": ("vnp_screen_f16_xwide_kernel (384 x 256 tile, LDS-DMA staging; other shapes: vnp_screen_f16_wide_kernel / vnp_gemm_split_kernel<..., EPI = 4>): screening pass of the exact arg-max pool "
                                        "(VNLinear -> VNMaxPool), ONE v_mfma_f32_16x16x32_f16 product per operand pair on fp16 operand images"
                                        if nprod == 1.0 else
                                        "vnp_gemm_split_kernel<..., EPI = 3>: screening pass of the exact arg-max pool, three bf16 products"),

@@ -221,6 +221,11 @@ int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx, const flo
  * the candidates, 60 % less pass time; operands beyond fp16's range raise the fallback flag; needs K % 64 == 0, else the three-product
  * pass runs).  The fp16 pass reads fp16 images of x and Wcat that the row-norm pass writes into ws.  Either way the result is exact. */
 #define VNP_POOL_SCREEN_FP16 1
+/* The fp16 pass picks its tile from the shape: 384 x 256 on LDS-DMA staging (M % 384 == 0, 2C % 256 == 0: screen_xwide_kernel.h),
+ * else 192 x 256 (2C % 256 == 0), else 192 x 128; all three write the same slots bit for bit.  These two flags only narrow the choice
+ * (tests hold the tiles against each other): no 384-row tile / no 256-column tile either. */
+#define VNP_POOL_SCREEN_NO_XWIDE 2
+#define VNP_POOL_SCREEN_NARROW 4
 long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int C, int K);
 int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
                                  int K, int* idx, float* out, int ldo, void* ws, int flags);

@@ -2,8 +2,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vn_pointcloudcompletion_amd/csrc -I scripts/experiments scripts/experiments/screen_bench.hip -o scripts/experiments/screen_bench.bin
 #include "screen_wide_kernel.h"
 #include "screen_variants.h"
+#include "screen_xwide_kernel.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 template <typename F> float time_it(F launch, int iters)
@@ -38,6 +40,40 @@ int main()
 #define RUN(name, kern) do { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         const float t = time_it([&] { hipLaunchKernelGGL(kern, grid, block, lds, 0, p); }, 10); \
         printf("%-52s %8.3f ms  %6.0f TF/s of one fp16 product\n", name, t, 2.0 * M * N * K / t * 1e-9); } while (0)
+    // the 384 x 256 tile (LDS-DMA staging): time, then its slots against the 192 x 256 kernel's, bit for bit
+    {
+        constexpr int xlds = 2 * (2 * 384 * 64 + 2 * 256 * 64);
+        CK(hipFuncSetAttribute((const void*)vnp_screen_f16_xwide_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, xlds));
+        std::vector<float> ref(nslot * 4), got(nslot * 4);
+        std::vector<int> refi(nslot), goti(nslot);
+        CK(hipMemset(slots, 0xff, nslot * 16)); CK(hipMemset(sidx, 0xff, nslot * 4));
+        CK(hipFuncSetAttribute((const void*)vnp_screen_f16_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(vnp_screen_f16_wide_kernel, grid, block, lds, 0, p);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ref.data(), slots, nslot * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(refi.data(), sidx, nslot * 4, hipMemcpyDeviceToHost));
+        for (int cg : {2, 1, 4, 16}) {
+            p.col_group = cg;
+            CK(hipMemset(slots, 0xff, nslot * 16)); CK(hipMemset(sidx, 0xff, nslot * 4));
+            const float t = time_it([&] { hipLaunchKernelGGL(vnp_screen_f16_xwide_kernel<0>, grid, dim3(512), xlds, 0, p); }, 10);
+            CK(hipMemcpy(got.data(), slots, nslot * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(goti.data(), sidx, nslot * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0;
+            for (size_t i = 0; i < nslot * 4; ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+            for (size_t i = 0; i < nslot; ++i) bad += refi[i] != goti[i];
+            printf("%-52s %8.3f ms  %6.0f TF/s   col_group %2d   words differing from the 192 x 256 kernel: %zu\n", "384 x 256 tile, LDS-DMA (xwide)", t,
+                   2.0 * M * N * K / t * 1e-9, cg, bad);
+        }
+        p.col_group = 4;
+#define XRUN(name, V) do { CK(hipFuncSetAttribute((const void*)vnp_screen_f16_xwide_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, xlds)); \
+        const float t = time_it([&] { hipLaunchKernelGGL(vnp_screen_f16_xwide_kernel<V>, grid, dim3(512), xlds, 0, p); }, 10); \
+        printf("xwide %-46s %8.3f ms  %6.0f TF/s\n", name, t, 2.0 * M * N * K / t * 1e-9); } while (0)
+        XRUN("as it is", 0);
+        XRUN("no DMA in the K loop", 1);
+        XRUN("fragments read once per item", 2);
+        XRUN("no DMA, fragments once (MFMAs + barriers)", 3);
+        XRUN("no MFMAs", 4);
+        XRUN("no MFMAs, no DMA (fragment reads + barriers)", 5);
+        p.col_group = 8;
+    }
     for (int round = 0; round < 2; ++round) {
         RUN("library kernel", vnp_screen_f16_wide_kernel);
         RUN("copy, VAR = 0", vnp_screen_f16_wide_var_kernel<0>);

@@ -299,6 +299,33 @@ def test_screened_pool_random_shapes_and_magnitudes(lib_built):
     print(f"fallback flag raised in {flags} of 48 screened calls")
 
 
+@pytest.mark.parametrize("G,gs,C,K", [(2, 256, 128, 128), (3, 1024, 256, 192), (4, 2048, 512, 256)])
+def test_screen_pass_tiles_write_the_same_slots(lib_built, G, gs, C, K):
+    """The fp16 screening pass on its three tiles — 384 x 256 with LDS-DMA staging (screen_xwide_kernel.h, what maxpool2 takes), 192 x 256
+    (screen_wide_kernel.h) and 192 x 128 — on shapes all three accept: the same candidate count (a sum over every slot's bracket: it moves
+    if one bound of one slot moves), no fallback, the same picks and pooled vectors bit for bit, equal to the full six-product epilogue's.
+    (On maxpool2's own shape the slots of the two wide tiles were compared word for word: profiles/r04_screen_ablation.txt.)"""
+    require_split_gemm()
+    from vn_pointcloudcompletion_amd import ops
+    assert (G * gs * 3) % 384 == 0 and (2 * C) % 256 == 0 and K % 64 == 0
+    g = torch.Generator().manual_seed(G * gs + C + K)
+    f = (torch.randn(G * gs * 3, K, generator=g) * torch.exp2(torch.randint(-3, 4, (G * gs * 3, 1), generator=g).float())).cuda()
+    W = (torch.randn(C, K, generator=g) / K ** 0.5).cuda()
+    Wd = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    res = {}
+    for tile in ("auto", "wide", "narrow"):
+        st = []
+        with ops.switches(POOL_SCREEN_TILE=tile, POOL_SCREEN_MIN_K=0), ops.hooks(pool_screen_stats=st):
+            out, idx = ops.VNLinearMaxPoolFn.apply(f, W, Wd, G, gs)
+        res[tile] = (out, idx, st[0].tolist())
+    with ops.switches(POOL_SCREENED=False):
+        full = ops.VNLinearMaxPoolFn.apply(f, W, Wd, G, gs)
+    for tile in ("auto", "wide", "narrow"):
+        out, idx, (cand, flag, cap) = res[tile]
+        assert flag == 0 and cand == res["narrow"][2][0], (tile, cand, res["narrow"][2])
+        assert torch.equal(idx, full[1]) and torch.equal(out.view(torch.int32), full[0].view(torch.int32)), tile
+
+
 def test_screened_pool_backs_off_after_a_fallback(lib_built):
     """After a call whose candidate list overflowed, the next calls of that shape skip the bracketing pass (the flag travels to the host
     through a non-blocking copy: no sync in the forward) and the search is tried again once the back-off has run out."""

@@ -20,6 +20,7 @@
 #include "gemm_split_kernel.h"
 #include "gemm_split_wide_kernel.h"
 #include "screen_wide_kernel.h"
+#include "screen_xwide_kernel.h"
 
 // 0 = bf16x3 split (fp32-grade), 1 = fp32 MFMA.  The library's only process-wide setting: an atomic switch that every vnp_gemm*
 // call reads once on entry (a concurrent vnp_gemm_set_mode affects later calls, never a launch in progress).
@@ -547,6 +548,8 @@ __global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restri
 
 struct VnpScreenHead { int count; int flag; int cap; int pad; };     // head of the workspace (device memory)
 #define VNP_POOL_SCREEN_FP16 1
+#define VNP_POOL_SCREEN_NO_XWIDE 2
+#define VNP_POOL_SCREEN_NARROW 4
 
 __global__ void vnp_pool_screen_init_kernel(VnpScreenHead* head, int cap) { head->count = 0; head->flag = 0; head->cap = cap; head->pad = 0; }
 
@@ -810,7 +813,7 @@ extern "C" long long vnp_linear_pool_screened_ws_bytes(long long G, int gs, int 
 extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int ldx, const float* Wcat, int ldw, long long G, int gs, int C,
                                             int K, int* idx, float* out, int ldo, void* ws, int flags)
 {
-    if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0 || (flags & ~1)) return VNP_EINVAL;
+    if (!x || !Wcat || !idx || !out || !ws || G <= 0 || gs <= 0 || C <= 0 || K <= 0 || (flags & ~7)) return VNP_EINVAL;
     const long long M = G * gs * 3;
     if (vnp_gemm_get_mode() != 0 || M % 192 || gs % 32 || C % 64 || K % 32 || ldx % 4 || ldw % 4 || M > 2147483647LL ||
         (uintptr_t)x % 16 || (uintptr_t)Wcat % 16 || G > 65535 || G * gs > 2147483647LL || gs / 32 > 4 * SEL_MAXQ)
@@ -859,8 +862,20 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
         p.screen_eps = 9.78e-4f + 7.2f * (float)K * 5.9605e-8f;
         p.screen_abs = 3.0e-8f * sqrtf((float)K) * 1.01f;
         p.A = (const float*)x16; p.B = (const float*)w16; p.lda = K; p.ldb = K;          // the pass reads the fp16 images (halves)
-        static const bool narrow = getenv("VNP_SCREEN_WIDE") != nullptr && getenv("VNP_SCREEN_WIDE")[0] == '0';
-        if ((2 * C) % 256 == 0 && !narrow) {
+        const bool narrow = (flags & VNP_POOL_SCREEN_NARROW) != 0;
+        if ((2 * C) % 256 == 0 && M % 384 == 0 && !narrow && !(flags & VNP_POOL_SCREEN_NO_XWIDE)) {
+            // 384 x 256 tiles, operands by LDS-DMA straight into the two 80 KB stages (screen_xwide_kernel.h): 0.71x the bytes into the
+            // CU and 0.7x the fragment reads per MFMA of the 192 x 256 pass, no staging registers, no ds_write pass; same slots.
+            // maxpool2 (196608 x 4096 x 1024): 1.85-1.95 -> 1.56-1.61 ms (profiles/r04_screen_ablation.txt)
+            const long long iw = (M / 384) * (2LL * C / 256);
+            const long long cw = vnp_num_cus();
+            p.col_group = 16;                       // measured 1 / 2 / 4 / 16 column tiles per XCD run: 1.68 / 1.61 / 1.61 / 1.57 ms
+            constexpr int xwide_lds = 2 * (2 * 384 * 64 + 2 * 256 * 64);          // two stages of a 384 x 256 x 64 fp16 tile: all 160 KB
+            static std::atomic<unsigned long long> xwide_ok{0};
+            hipError_t ex = vnp_allow_dynamic_lds(xwide_ok, (const void*)vnp_screen_f16_xwide_kernel<0>, xwide_lds);
+            if (ex != hipSuccess) return (int)ex;
+            hipLaunchKernelGGL(vnp_screen_f16_xwide_kernel<0>, dim3((unsigned)(iw < cw ? iw : cw)), dim3(512), xwide_lds, st, p);
+        } else if ((2 * C) % 256 == 0 && !narrow) {
             // 192 x 256 tiles on eight waves, one workgroup per CU: 0.70x the operand bytes per MFMA (screen_wide_kernel.h); same slots
             const long long iw = (M / 192) * (2LL * C / 256);
             const long long cw = vnp_num_cus();

@@ -37,6 +37,7 @@ class _Switches:
     STATS_IN_EPILOGUE = True        # BatchNorm statistics from the GEMM's accumulators vs a vnp_vn_norm_stats pass
     POOL_FUSED_EPILOGUE = True      # VNLinear -> VNMaxPool in the GEMM epilogue vs two GEMMs + pool kernels
     POOL_SCREEN_PASS = "fp16"       # bracketing pass of the screened pool: one fp16 product, or "bf16x3"
+    POOL_SCREEN_TILE = "auto"       # its tile: "auto" (384 x 256 / 192 x 256 / 192 x 128 by shape), "wide" (no 384-row tile), "narrow"
     POOL_SCREEN_MIN_K = 256         # shorter contractions: the full epilogue costs less than the search's fixed passes
     POOL_SCREEN_BACKOFF = 64        # calls of a shape that skip the search after a device-side fallback
     BN_BWD_TWO_PASS = True          # BatchNorm + leaky backward as sums pass + final-gradient pass vs bwd1 -> reduce -> bwd2

@@ -238,8 +238,11 @@ class VNLinearMaxPoolFn(Function):
             POOL_PATH_COUNTS["screened" if screened else "full_epilogue"] += 1
             if screened:
                 if SW.POOL_SCREEN_PASS not in ("fp16", "bf16x3"):
-                    raise _lib.VnpError(f"VNP_POOL_SCREEN_PASS must be 'fp16' or 'bf16x3', got {SW.POOL_SCREEN_PASS!r}")
-                call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws), 1 if SW.POOL_SCREEN_PASS == "fp16" else 0)
+                    raise _lib.VnpError(f"POOL_SCREEN_PASS must be 'fp16' or 'bf16x3', got {SW.POOL_SCREEN_PASS!r}")
+                if SW.POOL_SCREEN_TILE not in ("auto", "wide", "narrow"):
+                    raise _lib.VnpError(f"POOL_SCREEN_TILE must be 'auto', 'wide' or 'narrow', got {SW.POOL_SCREEN_TILE!r}")
+                flags = (1 if SW.POOL_SCREEN_PASS == "fp16" else 0) | {"auto": 0, "wide": 2, "narrow": 4}[SW.POOL_SCREEN_TILE]
+                call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws), flags)
             else:
                 call(entry, ptr(x), _ld(x), ptr(Wcat), K, G, gs, C, K, ptr(idx), ptr(out), C, ptr(ws))
             if timer is not None:
