@@ -231,6 +231,15 @@ def roofline_other(B, N, Mc, Md):
         out[-1]["pairs_of_a_full_scan"] = 2.0 * B * Md * Md
         out[-1]["visited_fraction"] = round(visited / (2.0 * B * Md * Md), 4)
         out[-1]["full_scan_equivalent_pairs_per_s"] = 2.0 * B * Md * Md / (out[-1]["ms"] * 1e-3)
+        wc = stats[1].float()                                  # chunks of 64 targets scanned by each wave of 64 queries (256 possible)
+        half = wc.numel() // 2
+        out[-1]["chunks_scanned_per_wave"] = {
+            name: {"mean": round(w_.mean().item(), 1), "median": w_.median().item(), "p99": w_.kthvalue(int(0.99 * w_.numel())).values.item(),
+                   "max": w_.max().item(),
+                   "waves_with_0_16_32_64_128_to_256_chunks": [int(((w_ >= lo) & (w_ < hi)).sum()) for lo, hi in ((0, 16), (16, 32), (32, 64), (64, 128), (128, 257))]}
+            for name, w_ in (("queries = prediction", wc[:half]), ("queries = ground truth", wc[half:]))}
+        out[-1]["note"] += ("; a wave's walk is a dependent chain, so the launch lasts as long as its longest chain: chunks_scanned_per_wave shows "
+                            "the imbalance (mean vs max)")
         valu("vnp_knn_coords_kernel (k = 16 graph on 2048 x 2048 coordinates, config 3 first layer)", lambda: ops.knn_indices(part, part, 16),
              1.0 * B * N * N, B * N * 12 * 2 + B * N * 16 * 4,
              "one wave per query: distances in registers, threshold selection (k-th smallest lane minimum), no distance matrix; "
@@ -383,6 +392,22 @@ def main():
         allreduce = {"backend": None, "bytes_per_step": 0, "mode": "none (single rank)"}
 
     pool_paths = dict(ops.POOL_PATH_COUNTS)
+    # one more step (untimed) with the pruned Chamfer's diagnostics attached: pairs evaluated and chunks scanned per query wave on the
+    # step's OWN clouds (prediction vs ground truth), the imbalance the launch time follows
+    chamfer_step = None
+    if world == 1:
+        cst = []
+        with ops.hooks(chamfer_stats=cst):
+            train_step(cfg, model, opt, p, c)
+        torch.cuda.synchronize()
+        if len(cst) >= 2:
+            wc = cst[-1].float()
+            half = wc.numel() // 2
+            chamfer_step = {"pairs_evaluated": float(cst[-2].item()), "pairs_of_a_full_scan": 2.0 * B * Md * Md,
+                            "chunks_scanned_per_wave_of_256": {
+                                name: {"mean": round(w_.mean().item(), 1), "p99": w_.kthvalue(max(1, int(0.99 * w_.numel()))).values.item(), "max": w_.max().item(),
+                                       "waves_with_0_16_32_64_128_to_256_chunks": [int(((w_ >= lo) & (w_ < hi)).sum()) for lo, hi in ((0, 16), (16, 32), (32, 64), (64, 128), (128, 257))]}
+                                for name, w_ in (("queries = prediction", wc[:half]), ("queries = ground truth", wc[half:]))}}
 
     # the same step on the fp32-input MFMA kernels, outside the timed region (single GPU only; a comparison, not `value`)
     fp32_mode = None
@@ -534,7 +559,7 @@ def main():
                           "parallelism": f"dp{world}", "allreduce": allreduce["mode"]},
                "points_per_s_per_gpu": value / world, "ranks_joined": ranks_joined, "allreduce": allreduce,
                "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
-               "roofline": roofline, "pool_path": pool_path}
+               "roofline": roofline, "pool_path": pool_path, "chamfer_dense_loss_in_step": chamfer_step}
         if fp32_mode is not None:
             out["fp32_mfma_mode"] = fp32_mode
         if world == 1 and not args.no_extras:

@@ -45,6 +45,9 @@ int vnp_chamfer_bwd(hipStream_t st, int B, int n, const float* xyz1, int m, cons
  * Diagnostics: after the call the 64-bit word at ws + 8 holds the (query, target) pairs the two scans evaluated (a full scan
  * evaluates 2 B n m): bench.py prices the kernel on this executed work. */
 long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m);
+/* Diagnostics: byte offset inside ws of the per-wave scanned-chunk counts every call leaves there — unsigned [B][ceil(n / 64)] for
+ * direction 1 (queries xyz1), then [B][ceil(m / 64)] for direction 2; a wave = 64 consecutive queries of the Morton-sorted cloud. */
+long long vnp_chamfer_pruned_ws_wave_counts(int B, int n, int m);
 int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                            float* dist1, int* idx1, float* dist2, int* idx2, void* ws);
 /* One side of the density-aware Chamfer distance, calc_dcd (/root/reference/metrics/loss.py:77-118; the reference loops over the batch

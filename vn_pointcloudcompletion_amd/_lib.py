@@ -147,10 +147,10 @@ _SIGNATURES = {
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
     "vnp_pack_tensors": [_i, _vp, _vp, _vp, _vp],
 }
-_NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_gemm_profile_cancel": [], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i],
+_NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_gemm_profile_cancel": [], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i], "vnp_chamfer_pruned_ws_wave_counts": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i, _i],
               "vnp_gemm_vn_stats_ws_floats": [_ll, _i], "vnp_gemm_tile_rows": [_i, _i, _i, _i, _i, _i], "vnp_bn1d_chunk_rows": []}
-_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,
+_RESTYPE = {"vnp_chamfer_pruned_ws_bytes": _ll, "vnp_chamfer_pruned_ws_wave_counts": _ll, "vnp_linear_pool_ws_bytes": _ll, "vnp_linear_pool_screened_ws_bytes": _ll,
             "vnp_gemm_vn_stats_ws_floats": _ll}
 
 

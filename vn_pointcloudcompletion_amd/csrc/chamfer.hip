@@ -336,14 +336,16 @@ __global__ void __launch_bounds__(1024) vnp_chamfer_bin_kernel(const float* __re
     }
 }
 
-template <int QPT>
+// NG: chunk groups of 64 (one ballot word each) the target cloud may have: 4 (up to 16384 points: 8 KB of boxes in LDS, 17 workgroups per
+// CU) or 8 (up to 32768: 16 KB, 9 per CU)
+template <int QPT, int NG>
 __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __restrict__ qs, int n, const float4* __restrict__ rs,
                                                                 int m, const float4* __restrict__ rbox, const int* __restrict__ flag,
                                                                 float* __restrict__ dist, int* __restrict__ idx,
-                                                                unsigned long long* __restrict__ visited)
+                                                                unsigned long long* __restrict__ visited, unsigned* __restrict__ wave_chunks)
 {
-    constexpr int NG = CHP_MAXN / CHP_CHUNK / 64;             // chunk groups of 64 (one ballot word each)
-    __shared__ float4 box[2 * (CHP_MAXN / CHP_CHUNK)];
+    static_assert(NG * 64 * CHP_CHUNK <= CHP_MAXN, "chunk groups beyond the binning kernel's range");
+    __shared__ float4 box[2 * 64 * NG];
     // the chunk being scanned, two points interleaved per 32 bytes {x0 x1 y0 y1 | z0 z1 i0 i1}: a lane evaluates TWO targets per step
     // with packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma: 6 instructions for the two distances instead of 12), each distance
     // by the same fmaf chain as before
@@ -408,11 +410,12 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
     const int c0 = __builtin_amdgcn_readfirstlane(cmin);
     __syncthreads();
 
-    int npairs = 0;                                               // (query, target) pairs this wave evaluates: the kernel's executed work
+    int npairs = 0, nvisit = 0;                                   // (query, target) pairs / chunks this wave evaluates: the kernel's executed work
     auto visit = [&](int c) {
         const int r0 = c * CHP_CHUNK;
         const int cnt = min(CHP_CHUNK, m - r0);
         npairs += cnt;
+        ++nvisit;
         __syncthreads();                                          // one wave per workgroup: orders the LDS reuse only
         {
             float4 v = make_float4(NAN, NAN, NAN, 0.f);           // slots past the chunk's end: NaN distances never win
@@ -492,7 +495,24 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
             idx[(size_t)b * n + qo[u]] = (int)(unsigned)(best[u] & 0xffffffffu);
         }
     }
-    if (lane == 0) atomicAdd(visited, (unsigned long long)npairs * (unsigned long long)min(64 * QPT, n - base));
+    if (lane == 0) {
+        atomicAdd(visited, (unsigned long long)npairs * (unsigned long long)min(64 * QPT, n - base));
+        if (wave_chunks) wave_chunks[(size_t)b * gridDim.x + blockIdx.x] = (unsigned)nvisit;
+    }
+}
+
+// byte offset inside ws of the per-wave scanned-chunk counts (unsigned [B][waves of direction 1], then [B][waves of direction 2]; a wave
+// = 64 consecutive queries of the Morton-sorted cloud), written by every call: diagnostics.
+// What they showed (round 4, bench.py `chamfer_dense_loss_in_step`): on the training step's clouds a wave scans 14-18 of 256 chunks on
+// average and 86-114 at worst.  Two restructurings aimed at that longest chain were measured and dropped: the next needed chunk loaded
+// behind the scan of the current one (359 -> 395 us per direction: no gain), and four waves per query group, each owning every fourth
+// chunk, sharing their minima through 64-bit LDS atomic minima (bit-identical results, 465 us: the per-wave set-up — 512 box bounds,
+// the group reductions — is paid four times and outweighs the shorter chains).  The launch is not bound by its longest chain.
+extern "C" long long vnp_chamfer_pruned_ws_wave_counts(int B, int n, int m)
+{
+    if (B <= 0 || n < 1 || m < 1 || n > CHP_MAXN || m > CHP_MAXN) return 0;
+    const long long c1 = vnp_cdiv(n, CHP_CHUNK), c2 = vnp_cdiv(m, CHP_CHUNK);
+    return 16LL * B * ((long long)n + m) + 32LL * B * (c1 + c2) + 256;
 }
 
 // bytes of scratch vnp_chamfer_fwd_pruned needs (0: sizes outside the pruned path's range)
@@ -500,7 +520,7 @@ extern "C" long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m)
 {
     if (B <= 0 || n < 1 || m < 1 || n > CHP_MAXN || m > CHP_MAXN) return 0;
     const long long c1 = vnp_cdiv(n, CHP_CHUNK), c2 = vnp_cdiv(m, CHP_CHUNK);
-    return 16LL * B * ((long long)n + m) + 32LL * B * (c1 + c2) + 256;
+    return 16LL * B * ((long long)n + m) + 32LL * B * (c1 + c2) + 256 + 4LL * B * (vnp_cdiv(n, 64 * CHP_QPT) + vnp_cdiv(m, 64 * CHP_QPT));
 }
 
 // Same contract as vnp_chamfer_fwd, by the pruned search.  n, m <= 32768; ws of vnp_chamfer_pruned_ws_bytes(B, n, m) bytes.
@@ -517,17 +537,28 @@ extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float*
     float4* s1 = (float4*)w;                   w += 16LL * B * n;
     float4* s2 = (float4*)w;                   w += 16LL * B * m;
     float4* b1 = (float4*)w;                   w += 32LL * B * c1;
-    float4* b2 = (float4*)w;
+    float4* b2 = (float4*)w;                   w += 32LL * B * c2;
+    // diagnostics (bench.py's imbalance histogram): chunks scanned by each query wave, direction 1 then direction 2
+    unsigned* wc1 = (unsigned*)w;              w += 4LL * B * vnp_cdiv(n, 64 * CHP_QPT);
+    unsigned* wc2 = (unsigned*)w;
     hipError_t e = hipMemsetAsync(flag, 0, 256, st);
     if (e != hipSuccess) return (int)e;
     static std::atomic<unsigned long long> lds_ok{0};
     e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_chamfer_bin_kernel, CHP_BINS * 4);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B, 2), dim3(1024), (size_t)CHP_BINS * 4, st, xyz1, n, s1, b1, xyz2, m, s2, b2, flag);
-    hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
-                       (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2));
-    hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
-                       (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2));
+    if (c2 <= 256)
+        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 4>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
+                           (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2), wc1);
+    else
+        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 8>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
+                           (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2), wc1);
+    if (c1 <= 256)
+        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 4>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
+                           (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2), wc2);
+    else
+        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 8>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
+                           (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2), wc2);
     return vnp_last_error();
 }
 

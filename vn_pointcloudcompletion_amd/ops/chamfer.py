@@ -38,6 +38,9 @@ class ChamferFn(Function):
             trace("chamfer_pruned")
             if HK.chamfer_stats is not None:
                 HK.chamfer_stats.append(ws[1:2].clone())
+                off = _lib.lib().vnp_chamfer_pruned_ws_wave_counts(B, n, m)
+                nw = B * ((n + 63) // 64 + (m + 63) // 64)
+                HK.chamfer_stats.append(ws.view(torch.int32)[off // 4: off // 4 + nw].clone())      # chunks scanned per query wave
         else:
             trace("chamfer_brute")
             ws = torch.empty(B * max(n, m), device=dev, dtype=torch.int64)
