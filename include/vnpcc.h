@@ -276,19 +276,21 @@ int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const
 #define VNP_FPS_SKIP_NEAR_ORIGIN 1
 int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx);
 int vnp_fps_ex(hipStream_t st, int B, int N, const float* xyz, int M, int* idx, int flags);
-/* rows layout: out point i <- x point src[i] (gather_operation); and its adjoint gx[src[i]] += g[i] (gx zeroed here) */
+/* rows layout: out point i <- x point src[i] (gather_operation); and its adjoint gx[s] = sum over the i with src[i] == s of g[i]:
+ * a gather over the reverse adjacency of src (vnp_edge_reverse), summed in ascending i in double — no atomics, every row of gx written,
+ * the same bits on every run.  ws: 2 * (Pin + 1) + 2 * Pout ints. */
 int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo);
 int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* src, long long Pout, int W,
-                           float* gx, int ldgx, long long Pin);
+                           float* gx, int ldgx, long long Pin, int* ws);
 /* Fused EdgeConv: VNLinearLeakyReLU on the kNN edge tensor + mean over the k neighbours (models/dgcnn.py:250-278 and the
  * conv1/4/5/6 blocks; VN-PoinTr grouper) without materialising the edge tensor: (p | d)(q, j) = u[nbr[q][j]] + v[q] is recomputed
  * in each pass from the per-point matrices u = x W1^T, v = x (W2 - W1)^T (columns [feat | dir]).
  * mode 0: Welford partials of |p| per block of vnp_edge_block_queries() queries -> vnp_vn_bn_finalize_chunked(chunk = 64 k);
  * mode 1: out[q] = mean_j leaky(bn(p), d); mode 2: backward sums (dL/dbeta, dL/dgamma partials); mode 3: gv[q] = sum_j g(q, j),
- * and, when gu != NULL, gu[nbr] += g(q, j) (float atomics; gu zeroed here).  count = number of edges (Pq * k).
- * Default for gu: vnp_edge_fused_gather — gu[s] = sum over the edges INTO s (reverse adjacency from vnp_edge_reverse: start [Pu + 1],
- * rev [Pq * k] query ids grouped by source; ws (Pu + 1) ints), the edge gradient recomputed term for term and summed in double: no
- * atomics, no zero fill, deterministic. */
+ * gu / ldgu / Pu must be NULL / 0 / 0 (kept in the signature; the scatter form with float atomics is gone).  count = number of edges.
+ * The source points' gradient: vnp_edge_fused_gather — gu[s] = sum over the edges INTO s (reverse adjacency from vnp_edge_reverse:
+ * start [Pu + 1], rev [Pq * k] query ids grouped by source and ASCENDING inside a source's list; ws (Pu + 1) + Pq * k ints), the edge
+ * gradient recomputed term for term and summed in double in list order: no atomics, no zero fill, the same bits on every run. */
 int vnp_edge_block_queries(void);
 int vnp_vn_bn_finalize_chunked(hipStream_t st, const float* partial, int nchunk, int chunk_points, int C, long long count,
                                float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps);
@@ -310,8 +312,9 @@ int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v,
  *   mode 0: partial [nchunk][C][2] = (mean, M2) of |p|+eps           (then vnp_vn_bn_finalize)
  *   mode 1: out [P*3][ldo] = leaky(bn(p), d)
  *   mode 2: partial [nchunk][C][2] = (sum g_nhat, sum g_nhat*xhat) from the upstream gradient go
- *   mode 3: part5 [nchunk][5][2C] = per-chunk sums for dbias (rows 0-2), dwseed (3), dwcoarse (4); gcoarse [B*Mc][3]
- *           (zero-filled here, accumulated atomically); sums [C][2] = reduced mode-2 partials (NULL: eval-mode BatchNorm)
+ *   mode 3: part5 [nchunk][5][2C] = per-chunk sums for dbias (rows 0-2), dwseed (3), dwcoarse (4); gcoarse [ceil(C / 64)][B*Mc][3]
+ *           = dL/dcoarse as one partial per 64-column block (plain stores; the caller sums the first axis: no atomics, the same bits
+ *           on every run); sums [C][2] = reduced mode-2 partials (NULL: eval-mode BatchNorm)
  * nchunk = B*Mc / coarse_per_chunk; coarse_per_chunk divides Mc and coarse_per_chunk*S <= vnp_chunk_points() (0: vnp_chunk_points()/S):
  * a chunk is coarse_per_chunk consecutive coarse points with their S dense points each and never straddles two samples. */
 int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* wseed, const float* wcoarse,

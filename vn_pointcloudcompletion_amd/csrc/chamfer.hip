@@ -109,19 +109,23 @@ __global__ void vnp_chamfer_grad_kernel(int n, const float* __restrict__ xyz1, i
     }
 }
 
-// The scatter half of the backward without global atomics.  Workgroup (part, b, direction) owns CHG_TARGETS consecutive points of
-// the cloud that RECEIVES the scatter, keeps their three gradient components as doubles in LDS, scans the nearest-neighbour indices of
-// all points of the other cloud and adds  -2 g_j (q_j - r_idx[j])  for those that land in its range (ds_add_f64: order of arrival
-// varies, but a double sum of <= 32768 fp32 terms rounds to the same float except on rounding ties — where the 1.5 M scattered
-// global float atomics of the previous version (0.67 ms per step: each lane its own 64-B memory-side request) differed run to run in the
-// last bits), then adds the sums to the points' own terms, which vnp_chamfer_own_kernel has stored.
+// The scatter half of the backward without global atomics and INDEPENDENT OF ARRIVAL ORDER.  Workgroup (part, b, direction) owns
+// CHG_TARGETS consecutive points of the cloud that RECEIVES the scatter, scans the nearest-neighbour indices of all points of the other
+// cloud and adds  -2 g_j (q_j - r_idx[j])  for those that land in its range into LDS accumulators, then adds the sums to the points' own
+// terms, which vnp_chamfer_own_kernel has stored.  The accumulators are 64-bit INTEGERS: a first scan finds the largest |term| landing
+// in the workgroup's range (integer atomic max on the float's bits), 2^e above it; the second scan adds each term as
+// rint(term * 2^(40 - e)) with ds_add_u64.  Integer addition is associative, so the sum is the same whatever order the lanes arrive in:
+// run-to-run identical bits (rounds 1-3 summed in double, exact only up to rounding ties; before that 1.5 M global float atomics, 0.67 ms
+// per step).  A term carries 40 bits below the largest one — an absolute error of 2^-41 of it per term, four orders below the fp32
+// rounding of the result — and <= 32768 terms stay below 2^56.
 #define CHG_TARGETS 2048
 __global__ void __launch_bounds__(1024) vnp_chamfer_scatter_kernel(int n, const float* __restrict__ xyz1, int m, const float* __restrict__ xyz2,
                                                                    const float* __restrict__ gd1, const int* __restrict__ idx1,
                                                                    const float* __restrict__ gd2, const int* __restrict__ idx2,
                                                                    float* __restrict__ g1, float* __restrict__ g2)
 {
-    __shared__ double acc[CHG_TARGETS * 3];
+    __shared__ unsigned long long acc[CHG_TARGETS * 3];
+    __shared__ unsigned maxbits;
     const int b = blockIdx.y, dir = blockIdx.z;
     // dir 0: queries = cloud 1 (n points, idx1 into cloud 2), receiver = cloud 2;  dir 1: the converse
     const int nq = dir == 0 ? n : m, nr = dir == 0 ? m : n;
@@ -132,8 +136,47 @@ __global__ void __launch_bounds__(1024) vnp_chamfer_scatter_kernel(int n, const 
     const float* gd = (dir == 0 ? gd1 : gd2) + (size_t)b * nq;
     const int* ix = (dir == 0 ? idx1 : idx2) + (size_t)b * nq;
     float* out = (dir == 0 ? g2 : g1) + (size_t)b * nr * 3;
-    for (int i = threadIdx.x; i < CHG_TARGETS * 3; i += 1024) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < CHG_TARGETS * 3; i += 1024) acc[i] = 0ull;
+    if (threadIdx.x == 0) maxbits = 0u;
     __syncthreads();
+    unsigned mb = 0u;
+    for (int j = threadIdx.x; j < nq; j += 1024) {
+        const int t = ix[j] - t0;
+        if ((unsigned)t >= (unsigned)CHG_TARGETS) continue;
+        const float g = gd[j] * 2.f;
+        const float* rp = r + (size_t)(t0 + t) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned bits = __float_as_uint(g * (q[(size_t)j * 3 + c] - rp[c])) & 0x7fffffffu;
+            mb = bits > mb ? bits : mb;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned ob = (unsigned)__shfl_xor((int)mb, o); mb = ob > mb ? ob : mb; }
+    if ((threadIdx.x & 63) == 0 && mb) atomicMax(&maxbits, mb);
+    __syncthreads();
+    const unsigned mx = maxbits;
+    const int lim = min(CHG_TARGETS, nr - t0) * 3;
+    if (mx >= 0x7f800000u) {
+        // a non-finite term (Inf / NaN gradient or coordinate) lands in this range: sum in double as rounds 1-3 did, so that it poisons
+        // exactly the receivers a float sum would (determinism is moot for such a step)
+        double* dacc = (double*)acc;                             // (zero bits are 0.0)
+        for (int j = threadIdx.x; j < nq; j += 1024) {
+            const int t = ix[j] - t0;
+            if ((unsigned)t >= (unsigned)CHG_TARGETS) continue;
+            const float g = gd[j] * 2.f;
+            const float* rp = r + (size_t)(t0 + t) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(&dacc[t * 3 + c], -(double)(g * (q[(size_t)j * 3 + c] - rp[c])));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < lim; i += 1024) out[(size_t)t0 * 3 + i] += (float)dacc[i];
+        return;
+    }
+    // every term is below 2^(ef - 126), ef the largest biased exponent: scaled by 2^sh it is below 2^40
+    const int ef = (int)(mx >> 23);
+    const int sh = (166 - ef) > 127 ? 127 : 166 - ef;            // (>= -88; the clamp only matters for sums of denormals)
+    const float scale = ldexpf(1.f, sh);
     for (int j = threadIdx.x; j < nq; j += 1024) {
         const int t = ix[j] - t0;
         if ((unsigned)t >= (unsigned)CHG_TARGETS) continue;
@@ -142,12 +185,12 @@ __global__ void __launch_bounds__(1024) vnp_chamfer_scatter_kernel(int n, const 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = g * (q[(size_t)j * 3 + c] - rp[c]);          // the same fp32 value the point's own term uses
-            atomicAdd(&acc[t * 3 + c], -(double)v);
+            atomicAdd(&acc[t * 3 + c], (unsigned long long)(long long)rintf(-v * scale));          // two's complement: wrap-around addition is exact
         }
     }
     __syncthreads();
-    const int lim = min(CHG_TARGETS, nr - t0) * 3;
-    for (int i = threadIdx.x; i < lim; i += 1024) out[(size_t)t0 * 3 + i] += (float)acc[i];
+    const double down = ldexp(1.0, -sh);
+    for (int i = threadIdx.x; i < lim; i += 1024) out[(size_t)t0 * 3 + i] += (float)((double)(long long)acc[i] * down);
 }
 
 // own terms of both directions: g1[j] = 2 gd1[j] (x1[j] - x2[idx1[j]]),  g2[j] = 2 gd2[j] (x2[j] - x1[idx2[j]])   (plain stores)

@@ -571,15 +571,23 @@ __global__ void vnp_gather_points_kernel(const float* __restrict__ x, int ldx, c
     for (int t = 0; t < 3; ++t) out[(i * 3 + t) * ldo + c] = x[(s + t) * ldx + c];
 }
 
-// gx[src[i]] += g[i]  (atomics; gx zeroed by the caller side of the C entry point)
-__global__ void vnp_scatter_add_points_kernel(const float* __restrict__ g, int ldg, const int* __restrict__ src, int W,
-                                              float* __restrict__ gx, int ldgx)
+// gx[s] = sum of g[i] over the i with src[i] == s, as a GATHER over the reverse adjacency (start, rev from vnp_edge_reverse: the i of a
+// source ascending): summed in list order in double, one plain store per element, zeros for a source nobody points at — no atomics, no
+// zero fill, the same bits on every run (rounds 1-3: float atomics in arrival order).       grid (ceil(W/256), Pin)
+__global__ void vnp_gather_sum_rev_kernel(const float* __restrict__ g, int ldg, const int* __restrict__ start, const int* __restrict__ rev,
+                                          int W, float* __restrict__ gx, int ldgx)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= W) return;
-    const size_t i = blockIdx.y, s = (size_t)src[i] * 3;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) atomicAdd(&gx[(s + t) * ldgx + c], g[(i * 3 + t) * ldg + c]);
+    const size_t s = blockIdx.y;
+    const int b0 = start[s], b1 = start[s + 1];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int e = b0; e < b1; ++e) {
+        const float* r = g + (size_t)rev[e] * 3 * ldg + c;
+        a0 += (double)r[0]; a1 += (double)r[ldg]; a2 += (double)r[2 * (size_t)ldg];
+    }
+    float* w = gx + s * 3 * ldgx + c;
+    w[0] = (float)a0; w[ldgx] = (float)a1; w[2 * (size_t)ldgx] = (float)a2;
 }
 
 // Edge tensor of a kNN graph with the EdgeConv weights already applied (see ops.EdgeGatherAddFn):
@@ -606,18 +614,23 @@ extern "C" int vnp_gather_points(hipStream_t st, const float* x, int ldx, const 
     return vnp_last_error();
 }
 
-// gx [Pin*3][ldgx] = 0; then gx[src[i]] += g[i] for i < Pout
+extern "C" int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long long Pu, int* start, int* rev, int* ws);
+
+// gx [Pin*3][ldgx]: gx[s] = sum of g[i] over the i < Pout with src[i] == s (every row of gx is written).
+// ws: 2 * (Pin + 1) + 2 * Pout ints (the reverse adjacency of src and its scratch).
 extern "C" int vnp_scatter_add_points(hipStream_t st, const float* g, int ldg, const int* src, long long Pout, int W,
-                                      float* gx, int ldgx, long long Pin)
+                                      float* gx, int ldgx, long long Pin, int* ws)
 {
-    if (!g || !src || !gx || Pout <= 0 || W <= 0 || Pin <= 0) return VNP_EINVAL;
-    hipError_t e = ldgx == W ? hipMemsetAsync(gx, 0, (size_t)Pin * 3 * W * 4, st)
-                             : hipMemset2DAsync(gx, (size_t)ldgx * 4, 0, (size_t)W * 4, (size_t)Pin * 3, st);
-    if (e != hipSuccess) return (int)e;
-    for (long long p0 = 0; p0 < Pout; p0 += 65535) {
-        const int n = (int)((Pout - p0) < 65535 ? (Pout - p0) : 65535);
-        hipLaunchKernelGGL(vnp_scatter_add_points_kernel, dim3(vnp_cdiv(W, 256), n), dim3(256), 0, st,
-                           g + (size_t)p0 * 3 * ldg, ldg, src + p0, W, gx, ldgx);
+    if (!g || !src || !gx || !ws || Pout <= 0 || W <= 0 || Pin <= 0) return VNP_EINVAL;
+    int* start = ws;
+    int* rev = ws + (Pin + 1);
+    int* scratch = rev + Pout;
+    int rc = vnp_edge_reverse(st, src, Pout, 1, Pin, start, rev, scratch);
+    if (rc) return rc;
+    for (long long p0 = 0; p0 < Pin; p0 += 65535) {
+        const int n = (int)((Pin - p0) < 65535 ? (Pin - p0) : 65535);
+        hipLaunchKernelGGL(vnp_gather_sum_rev_kernel, dim3(vnp_cdiv(W, 256), n), dim3(256), 0, st, g, ldg, (const int*)start + p0,
+                           (const int*)rev, W, gx + (size_t)p0 * 3 * ldgx, ldgx);
     }
     return vnp_last_error();
 }

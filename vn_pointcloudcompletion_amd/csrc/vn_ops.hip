@@ -810,7 +810,7 @@ struct VnpFoldArgs {
     float2* partial;                      // MODE 0: (mean, M2); MODE 2: (S1, S2)   [nchunk][C]
     const float* sums; float inv_count;   // MODE 3: reduced sums [C][2] (nullptr in eval mode)
     float* part5;                         // MODE 3: [nchunk][5][2C]
-    float* gcoarse;                       // MODE 3: [B*Mc][3], zero-filled, atomically accumulated
+    float* gcoarse;                       // MODE 3: [ceil(C / 64)][B*Mc][3]: one partial per 64-column block, summed by the caller (no atomics)
     // GRP (vnp_group_fold_fused): bias rows per COARSE point (group) instead of per sample, seed_batched = 2: seed points per coarse
     // point; coarse == nullptr: no coarse term
     float* gbias_cp;                      // MODE 3, GRP: dL/dbias per coarse point [B*Mc*3][2C]
@@ -1013,11 +1013,13 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
             gc0 += r0 * wcf + h0 * wcd; gc1 += r1 * wcf + h1 * wcd; gc2 += r2 * wcf + h2 * wcd;
         }
         if (MODE == 3 && !GRP) {
-            // dcoarse[cp][t] = sum over columns (this wave's 64, then the other column tiles through atomics)
+            // dcoarse[cp][t] = sum over columns: this wave's 64 here (a fixed butterfly), the column blocks' partials by the caller
+            // (vnp_reduce_rows) — plain stores, the same bits on every run (rounds 1-3: float atomics across the column blocks)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { gc0 += __shfl_xor(gc0, o); gc1 += __shfl_xor(gc1, o); gc2 += __shfl_xor(gc2, o); }
             if (cx == 0) {
-                atomicAdd(&a.gcoarse[cp * 3], gc0); atomicAdd(&a.gcoarse[cp * 3 + 1], gc1); atomicAdd(&a.gcoarse[cp * 3 + 2], gc2);
+                float* w = a.gcoarse + ((size_t)blockIdx.x * a.ncoarse + cp) * 3;
+                w[0] = gc0; w[1] = gc1; w[2] = gc2;
             }
         }
     }
@@ -1057,7 +1059,7 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
 #undef FDIV
 
 // mode 0: statistics partials; 1: forward; 2: backward sums; 3: backward gradients (see ops.FoldBnLeakyFn).
-// partial: [nchunk][C][2]; part5: [nchunk][5][2C] with nchunk = B*Mc / coarse_per_chunk; gcoarse [B*Mc][3] is zero-filled here in mode 3.
+// partial: [nchunk][C][2]; part5: [nchunk][5][2C] with nchunk = B*Mc / coarse_per_chunk; gcoarse [ceil(C / 64)][B*Mc][3]: per-column-block partials of dL/dcoarse (mode 3), to be summed over the first axis.
 extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int ldb, const float* wseed, const float* wcoarse,
                               const float* seed, int seed_batched, const float* coarse, int B, int Mc, int S, int C,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float negative_slope,
@@ -1092,8 +1094,6 @@ extern "C" int vnp_fold_fused(hipStream_t st, int mode, const float* bias, int l
         if (S % 2 == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<2, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((vnp_fold_fused_kernel<2>), grid, block, 0, st, a);
     } else {
-        hipError_t e = hipMemsetAsync(gcoarse, 0, (size_t)B * Mc * 3 * 4, st);
-        if (e != hipSuccess) return (int)e;
         if (S % 2 == 0) hipLaunchKernelGGL((vnp_fold_fused_kernel<3, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((vnp_fold_fused_kernel<3>), grid, block, 0, st, a);
     }
@@ -1252,11 +1252,6 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             const float kk = pn > 0.f ? EDIV(gn, pn) : 0.f;
             const float f0 = s * g0 + kk * x0, f1 = s * g1 + kk * x1, f2 = s * g2 + kk * x2;   // dL/dp of this edge
             o0 += f0; o1 += f1; o2 += f2; h0 += e0; h1 += e1; h2 += e2;
-            if (live && a.gu) {                     // scatter form (gu given): float atomics; the default is vnp_edge_fused_gather below
-                float* wu = a.gu + urow * a.ldgu + c;
-                atomicAdd(wu, f0); atomicAdd(wu + a.ldgu, f1); atomicAdd(wu + 2 * a.ldgu, f2);
-                atomicAdd(wu + C, e0); atomicAdd(wu + a.ldgu + C, e1); atomicAdd(wu + 2 * a.ldgu + C, e2);
-            }
         }
         if (MODE == 1 && live) {
             float* w = a.out + (size_t)q * 3 * a.ldo + c;
@@ -1372,8 +1367,8 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
 #undef EDIV
 #undef ESQRT
 
-// ---- reverse adjacency of a neighbour table: count -> exclusive scan -> fill (integer atomics: the ORDER inside a source's list is
-// unspecified, its CONTENT is not)
+// ---- reverse adjacency of a neighbour table: count -> exclusive scan -> fill (integer atomics: arrival order) -> sort of every
+// source's list, so that the lists — and every sum taken over them in list order — are the same on every run
 __global__ void vnp_edge_rev_hist_kernel(const int* __restrict__ nbr, long long total, int* __restrict__ deg)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) atomicAdd(&deg[nbr[i]], 1);
@@ -1420,6 +1415,73 @@ __global__ void vnp_edge_rev_fill_kernel(const int* __restrict__ nbr, long long 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int sidx = nbr[i];
         rev[start[sidx] + atomicAdd(&cursor[sidx], 1)] = (int)(i / k);
+    }
+}
+
+// Ascending sort of data[0 .. L) by one workgroup: the bitonic network in its all-ascending form (first stage of every merge mirrors the
+// block, i ^ (2 j - 1); the others i ^ j; the smaller value always goes to the smaller index), so positions >= L behave as +infinity
+// without being stored.  `data` is LDS or global memory (a workgroup's own global accesses are ordered by __syncthreads).
+__device__ void vnp_block_sort_asc(int* data, int L)
+{
+    int n2 = 1;
+    while (n2 < L) n2 <<= 1;
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool first = j == (k >> 1);
+            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+                const int p = first ? (i ^ (k - 1)) : (i ^ j);
+                if (p > i && p < L) {                             // (i < p < L: both real; p >= L is +infinity and stays where it is)
+                    const int a = data[i], c = data[p];
+                    if (c < a) { data[i] = c; data[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Every source point's list `in[start[s] .. start[s + 1])` (query ids, in arrival order) -> ascending in `out`.  A workgroup takes four
+// sources.  Lists of up to 64 entries (a kNN graph's in-degree is ~k) are sorted by one wave each, by counting: an entry's position is the
+// number of entries that are smaller, or equal and earlier (equal ids — a query that lists the same neighbour twice — are
+// interchangeable): one load, <= 64 shuffle-compare steps, one store per lane.  Longer lists (hubs: feature-space graphs) are sorted by
+// the whole workgroup, in LDS up to VNP_REV_LDS entries, in place in the unsorted buffer beyond.
+#define VNP_REV_LDS 4096
+__global__ void __launch_bounds__(256) vnp_edge_rev_sort_kernel(const int* __restrict__ start, int* __restrict__ in, int* __restrict__ out,
+                                                                long long Pu)
+{
+    __shared__ int buf[VNP_REV_LDS];
+    const int lane = threadIdx.x & 63;
+    {
+        const long long s = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (s < Pu) {
+            const int b0 = start[s], L = start[s + 1] - b0;
+            if (L > 0 && L <= 64) {
+                const int v = lane < L ? in[b0 + lane] : 0x7fffffff;
+                int rank = 0;
+                for (int j = 0; j < L; ++j) {
+                    const int u = __shfl(v, j);
+                    rank += (u < v || (u == v && j < lane)) ? 1 : 0;
+                }
+                if (lane < L) out[b0 + rank] = v;
+            }
+        }
+    }
+    for (int q = 0; q < 4; ++q) {                               // workgroup-uniform: the long lists among the four
+        const long long s = (long long)blockIdx.x * 4 + q;
+        if (s >= Pu) break;
+        const int b0 = start[s], L = start[s + 1] - b0;
+        if (L <= 64) continue;
+        if (L <= VNP_REV_LDS) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < L; i += 256) buf[i] = in[b0 + i];
+            __syncthreads();
+            vnp_block_sort_asc(buf, L);
+            for (int i = threadIdx.x; i < L; i += 256) out[b0 + i] = buf[i];
+        } else {
+            __syncthreads();
+            vnp_block_sort_asc(in + b0, L);
+            for (int i = threadIdx.x; i < L; i += 256) out[b0 + i] = in[b0 + i];
+        }
     }
 }
 
@@ -1756,8 +1818,8 @@ extern "C" int vnp_edge_block_queries(void) { return VNP_EDGE_QB; }
 
 // Fused EdgeConv passes (see vnp_edge_fused_kernel).  u [Pu*3, ldu >= 2C], v [Pq*3, ldv >= 2C], nbr [Pq][k] ids < Pu.
 // mode 0: partial [ceil(Pq/64)][C][2].  mode 1: out [Pq*3, ldo].  mode 2: go, partial.  mode 3: go, sums ([C][2] or NULL), count =
-// number of edges, gv [Pq*3, ldgv >= 2C], and gu [Pu*3, ldgu >= 2C] (zeroed here, filled with float atomics) or NULL (then gu comes from
-// vnp_edge_fused_gather).
+// number of edges, gv [Pq*3, ldgv >= 2C]; gu / ldgu / Pu must be NULL / 0 / 0 (the scatter form with float atomics is gone: the source
+// points' gradient comes from vnp_edge_fused_gather, a gather over the reverse adjacency).
 extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
                               long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
@@ -1768,7 +1830,8 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
     if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
     if (mode == 1 && !out) return VNP_EINVAL;
     if (mode >= 2 && !go) return VNP_EINVAL;
-    if (mode == 3 && (!gv || (gu && Pu <= 0))) return VNP_EINVAL;
+    if (mode == 3 && (!gv || gu)) return VNP_EINVAL;
+    (void)Pu; (void)ldgu;
     const long long nblk = (Pq + VNP_EDGE_QB - 1) / VNP_EDGE_QB;
     if (nblk > 65535LL * 32768LL) return VNP_EINVAL;
     VnpEdgeArgs a;
@@ -1776,12 +1839,7 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
     a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
     a.partial = (float2*)partial; a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo;
     a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f;
-    a.gu = gu; a.ldgu = ldgu; a.gv = gv; a.ldgv = ldgv;
-    if (mode == 3 && gu) {
-        hipError_t e = ldgu == 2 * C ? hipMemsetAsync(gu, 0, (size_t)Pu * 3 * ldgu * 4, st)
-                                     : hipMemset2DAsync(gu, (size_t)ldgu * 4, 0, (size_t)2 * C * 4, (size_t)Pu * 3, st);
-        if (e != hipSuccess) return (int)e;
-    }
+    a.gu = nullptr; a.ldgu = 0; a.gv = gv; a.ldgv = ldgv;
     // gridDim.y <= 65535: slices of query blocks
     for (long long b0 = 0; b0 < nblk; b0 += 65535) {
         const int nb = (int)((nblk - b0) < 65535 ? (nblk - b0) : 65535);
@@ -1805,16 +1863,21 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
 
 // Reverse adjacency of nbr [Pq][k] (ids < Pu): start [Pu + 1] = exclusive prefix of the in-degrees, rev [Pq * k] = query ids grouped by
 // source point (order inside a group unspecified).  ws: (Pu + 1) ints.  Pq * k and Pu below 2^31.
+// start [Pu + 1], rev [Pq * k]: for every source point the ids of the queries that list it, ASCENDING (deterministic).
+// ws: (Pu + 1) + Pq * k ints (the fill pass's cursors and its unsorted lists).
 extern "C" int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long long Pu, int* start, int* rev, int* ws)
 {
     if (!nbr || !start || !rev || !ws || Pq <= 0 || k <= 0 || Pu <= 0 || Pq * k > 2147483647LL || Pu > 2147483646LL) return VNP_EINVAL;
     const long long total = Pq * k;
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)(Pu + 1) * 4, st);
     if (e != hipSuccess) return (int)e;
+    int* unsorted = ws + (Pu + 1);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(vnp_edge_rev_hist_kernel, dim3(blocks), dim3(256), 0, st, nbr, total, ws);
     hipLaunchKernelGGL(vnp_edge_rev_scan_kernel, dim3(1), dim3(1024), 0, st, ws, Pu, start);
-    hipLaunchKernelGGL(vnp_edge_rev_fill_kernel, dim3(blocks), dim3(256), 0, st, nbr, total, k, (const int*)start, ws, rev);
+    hipLaunchKernelGGL(vnp_edge_rev_fill_kernel, dim3(blocks), dim3(256), 0, st, nbr, total, k, (const int*)start, ws, unsorted);
+    if ((Pu + 3) / 4 > 2147483647LL) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_edge_rev_sort_kernel, dim3((unsigned)((Pu + 3) / 4)), dim3(256), 0, st, (const int*)start, unsorted, rev, Pu);
     return vnp_last_error();
 }
 

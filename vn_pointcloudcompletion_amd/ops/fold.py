@@ -127,15 +127,17 @@ class FoldBnLeakyFn(Function):
         call("vnp_fold_fused", 2, *args, *bn, None, 0, ptr(go), _ld(go), ptr(part), None, 0, None, None, cpc)
         Ssum, planar = reduce_pairs(part, nch, C)
         part5 = torch.empty((nch, 5, 2 * C), device=dev, dtype=torch.float32)
-        gcoarse = torch.empty((B, Mc, 3), device=dev, dtype=torch.float32)
+        ncb = (C + 63) // 64
+        gc_part = torch.empty((ncb, B * Mc * 3), device=dev, dtype=torch.float32)       # dL/dcoarse: one partial per 64-column block
         call("vnp_fold_fused", 3, *args, *bn, None, 0, ptr(go), _ld(go), None, ptr(Ssum) if training else None, P,
-             ptr(part5), ptr(gcoarse), cpc)
+             ptr(part5), ptr(gc_part), cpc)
+        gcoarse = reduce_rows(gc_part, 1, ncb, B * Mc * 3).view(B, Mc, 3) if ctx.needs_input_grad[4] else None
         W = 2 * C
         per_sample = reduce_rows(part5, B, Mc // cpc, 5 * W)                           # [B][5W]: a chunk lies inside one sample
         gbias = per_sample[:, :3 * W].reshape(B * 3, W)
         tot = reduce_rows(per_sample, 1, B, 5 * W)
         gws, gwc = tot[0, 3 * W:4 * W], tot[0, 4 * W:]
-        return (gbias, gws, gwc, None, gcoarse if ctx.needs_input_grad[4] else None, planar[1], planar[0], None, None, None, None)
+        return (gbias, gws, gwc, None, gcoarse, planar[1], planar[0], None, None, None, None)
 
 
 

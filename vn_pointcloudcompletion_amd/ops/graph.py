@@ -84,7 +84,8 @@ class GatherPointsFn(Function):
         P_in, W = ctx.cfg
         g = _rows(g)
         gx = torch.empty((P_in * 3, W), device=g.device, dtype=torch.float32)
-        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(src), src.numel(), W, ptr(gx), W, P_in)
+        ws = torch.empty(2 * (P_in + 1) + 2 * src.numel(), device=g.device, dtype=torch.int32)
+        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(src), src.numel(), W, ptr(gx), W, P_in, ptr(ws))
         return gx, None
 
 
@@ -113,7 +114,8 @@ class EdgeGatherAddFn(Function):
         g = _rows(g)
         dev = g.device
         gu = torch.empty((Pu * 3, W), device=dev, dtype=torch.float32)
-        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(nbr), P * k, W, ptr(gu), W, Pu)
+        ws = torch.empty(2 * (Pu + 1) + 2 * P * k, device=dev, dtype=torch.int32)
+        call("vnp_scatter_add_points", ptr(g), _ld(g), ptr(nbr), P * k, W, ptr(gu), W, Pu, ptr(ws))
         gv = torch.empty((P * 3, W), device=dev, dtype=torch.float32)
         call("vnp_vn_mean_pool_fwd", ptr(g), _ld(g), P, k, W, ptr(gv), W)          # mean over k ...
         gv.mul_(float(k))                                                          # ... times k = sum
@@ -130,7 +132,7 @@ def edge_reverse(nbr, Pu):
     Pq, k = nbr.shape
     start = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
     rev = torch.empty(Pq * k, device=nbr.device, dtype=torch.int32)
-    ws = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
+    ws = torch.empty(Pu + 1 + Pq * k, device=nbr.device, dtype=torch.int32)
     call("vnp_edge_reverse", ptr(nbr), Pq, k, Pu, ptr(start), ptr(rev), ptr(ws))
     nbr._vnp_rev = (start, rev)
     return start, rev
