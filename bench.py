@@ -554,6 +554,13 @@ def main():
         out = {"metric": METRIC, "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
+               "dtype_note": ("fp32 operands and fp32 results.  GEMM mode 'split' (default): every operand element is split EXACTLY into three bf16 "
+                              "terms and six bf16 MFMA products are accumulated in fp32 — error against fp64 at or below an fp32-input MFMA's "
+                              "(tests/test_gpu_gemm.py::test_split_is_fp32_grade); three documented edge cases (Inf operand -> NaN where an fp32 "
+                              "product gives Inf, |x| > 3.39e38 likewise, fp32 denormals lose their low planes), exercised at layer level by "
+                              "tests/test_gpu_layers.py::test_split_arithmetic_edge_cases_through_a_layer.  The fp32-input MFMA mode "
+                              "(VNP_GEMM_MODE=fp32) is reported beside it as fp32_mfma_mode; it has no fused statistics / pool epilogues")
+                             if gemm_mode == "split" else "fp32-input MFMA kernels (v_mfma_f32_32x32x2_f32)",
                "config": {"workload": f"vn_pointnet+vn_foldingnet train step (fwd+2xCD-L1+bwd+allreduce+Adam), B={B}/GPU, "
                                       f"{N}->{Mc}->{Md} pts, fp32 (GEMM mode: {gemm_mode})", "global_batch": B * world,
                           "parallelism": f"dp{world}", "allreduce": allreduce["mode"]},
@@ -569,8 +576,8 @@ def main():
             legs = [("roofline_other", lambda: roofline_other(B, N, Mc, Md) + bench_extras.roofline_other_configs()),
                     ("chamfer_op", chamfer_op_bench)]
             if not args.no_configs:
-                # the other BASELINE configurations at full batch and resolution: 3 untimed + 5 timed steps each
-                legs.append(("configs", lambda: bench_extras.other_configs(steps=5, warmup=3)))
+                # the other BASELINE configurations at full batch and resolution: 5 untimed + 5 timed steps each
+                legs.append(("configs", lambda: bench_extras.other_configs(steps=5, warmup=5)))
             for key, fn in legs:
                 try:
                     out[key] = fn()

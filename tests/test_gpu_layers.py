@@ -776,3 +776,55 @@ def test_colsum_short_and_long_groups(lib_built, nb, npts, W, weighted):
     call("vnp_colsum", ptr(x), npts * W, W, nb, npts, W, ptr(w) if weighted else None, ptr(part))
     ref = (x.double() * (w.double()[..., None] if weighted else 1.0)).sum(1)
     assert relerr(part.sum(1), ref) < 2e-6
+
+
+def test_split_arithmetic_edge_cases_through_a_layer(lib_built):
+    """The three documented edge cases of the default GEMM arithmetic (fp32 operands split exactly into three bf16 terms)
+    at NETWORK level, through one VNLinearLeakyReLU (GEMM -> BatchNorm over norms -> leaky projection), against the same layer in
+    VNP_GEMM_MODE=fp32 (fp32-input MFMA) and against float64:
+      * an Inf operand element: the split forms Inf - Inf in its remainder planes and yields NaN where an fp32 product yields Inf; either
+        way the output rows that touch the element are non-finite in BOTH modes and every other row agrees — the failure is loud and local;
+      * fp32 DENORMAL operand elements lose their low planes (bf16 has no more exponent range than fp32): their contribution is below
+        2^-126 * |w| and the outputs agree with float64 to fp32 rounding;
+      * finite elements above 3.39e38 (the largest bf16) round to Inf in the first plane: as Inf in the split mode, whatever fp32 gives."""
+    from vn_pointcloudcompletion_amd import _lib, ops
+    from vn_pointcloudcompletion_amd.vn_layers import VNLinearLeakyReLU
+    g = torch.Generator().manual_seed(31)
+    P, Cin, Cout = 512, 64, 96
+    x0 = torch.randn(P * 3, Cin, generator=g)
+    torch.manual_seed(7)
+    layer = VNLinearLeakyReLU(Cin, Cout, dim=4).cuda().eval()           # eval: BatchNorm on running statistics, rows independent
+    with torch.no_grad():
+        layer.batchnorm.bn.running_mean.uniform_(0.5, 1.5); layer.batchnorm.bn.running_var.uniform_(0.5, 1.5)
+
+    def run(x, mode):
+        keep = _lib.get_gemm_mode()
+        _lib.set_gemm_mode(mode)
+        try:
+            with torch.no_grad():
+                return layer.forward_rows(x.cuda()).cpu()
+        finally:
+            _lib.set_gemm_mode(keep)
+
+    # denormals: a whole channel of them, and a few scattered
+    xd = x0.clone()
+    xd[:, 3] = 1e-40
+    xd[5, 7] = -3e-42
+    ys, yf = run(xd, "split"), run(xd, "fp32")
+    assert torch.isfinite(ys).all() and torch.isfinite(yf).all()
+    xz = xd.clone(); xz[:, 3] = 0.0; xz[5, 7] = 0.0                    # what the low planes' loss amounts to at most: those elements as zeros
+    yz = run(xz, "split")
+    assert relerr(ys, yf) < 2e-5 and relerr(ys, yz) < 1e-6
+    # Inf and an above-bf16-range element: rows 30 .. 32 (point 10) and 60 .. 62 (point 20)
+    for bad in (float("inf"), 3.4e38):
+        xi = x0.clone()
+        xi[31, 5] = bad
+        xi[61, 9] = -bad
+        ys, yf = run(xi, "split"), run(xi, "fp32")
+        hit = torch.zeros(P * 3, dtype=torch.bool)
+        hit[30:33] = True; hit[60:63] = True                            # the leaky projection mixes the three rows of a point
+        assert not torch.isfinite(ys[hit]).all(), bad                  # the split mode: NaN on the rows of the two points
+        if bad == float("inf"):
+            assert not torch.isfinite(yf[hit]).all()                   # (3.4e38 is a finite fp32: the fp32-input mode may stay finite there)
+        assert torch.isfinite(ys[~hit]).all() and torch.isfinite(yf[~hit]).all()
+        assert relerr(ys[~hit], yf[~hit]) < 2e-5

@@ -3,8 +3,8 @@
 // matchcostgrad1 :333-355).
 //
 // The reference runs ONE 512-thread block per sample through all 10 annealing levels x 3 passes (32 blocks busy at
-// most).  Here every pass is its own launch over (point tiles x samples), so B = 16 samples of 1024 points fill 64+
-// workgroups and the 30 dependent passes cost a few microseconds each; the arithmetic (level schedule -4^j, j = 7..-1,
+// most).  Here every pass is its own launch over (tiles of 64 points x samples), four threads per point, so B = 16 samples of 1024 points
+// fill 256 workgroups and the 30 dependent passes cost a few microseconds each; the arithmetic (level schedule -4^j, j = 7..-1,
 // then 0; integer n/m multipliers; the 1e-9 guards; fmax/fmin clamps; __expf; l/k summation order) is the reference's.
 // match is [B][m][n] (match[b][l][k]), temp is [B][(n+m)*2] = remainL[n] | remainR[m] | ratioL[n] | ratioR[m].
 #include "vnp_common.h"
@@ -25,30 +25,57 @@ __global__ void emd_init_kernel(int n, int m, float* __restrict__ temp, float mu
     if (j < m) t[n + j] = multiR;
 }
 
+// The three reductions of a level — pass (a): sum over l per k, pass (b): sum over k per l, the drain of pass (c): sum over l per k — share
+// one skeleton: a workgroup takes EMD_ROWS "row" points and ALL "column" points of its sample; the column cloud (with its per-point weight)
+// is staged in LDS tile by tile, thread (row r, part q) sums the q-th quarter of every tile, and the EMD_PARTS partial sums of a row meet in
+// LDS in a fixed order.  (Rounds 1-3: one thread per row walking all 1024 columns — 64 workgroups for B = 16, 1024 points, 30 us per pass; with
+// 64 rows x 4 parts a pass is 256 workgroups of 256-step loops.)  The sums differ from the one-thread order by fp32 re-association only.
+#define EMD_ROWS 64
+#define EMD_PARTS 4
+// returns (valid for q == 0 threads) sum_j exp(level * |row - col_j|^2) * w_j over all ncol column points; `scale` multiplies every term
+// BEFORE the sum (pass (c): w = exp(..) * ratioL[k] * ratioR[l], emd_kernel.cu:139-141)
+__device__ __forceinline__ float emd_row_sum(const float* __restrict__ pc, const float* __restrict__ wc, int ncol, float x, float y, float z,
+                                             float level, float scale, bool scaled, float4* buf, float (*red)[EMD_ROWS])
+{
+#pragma clang fp contract(off)
+    const int r = threadIdx.x & (EMD_ROWS - 1), q = threadIdx.x / EMD_ROWS;
+    float s = 0.f;
+    for (int c0 = 0; c0 < ncol; c0 += EMD_TILE) {
+        const int cend = min(ncol, c0 + EMD_TILE) - c0;
+        __syncthreads();
+        for (int c = threadIdx.x; c < cend; c += EMD_T)
+            buf[c] = make_float4(pc[(c0 + c) * 3], pc[(c0 + c) * 3 + 1], pc[(c0 + c) * 3 + 2], wc[c0 + c]);
+        __syncthreads();
+        const int per = (cend + EMD_PARTS - 1) / EMD_PARTS;
+        const int j0 = q * per, j1 = min(cend, j0 + per);
+        for (int j = j0; j < j1; ++j) {
+            const float4 p = buf[j];                              // (same address across the 64 lanes of a wave: LDS broadcast)
+            const float e = __expf(level * emd_d2(x, y, z, p.x, p.y, p.z));
+            s += scaled ? e * scale * p.w : e * p.w;
+        }
+    }
+    red[q][r] = s;
+    __syncthreads();
+    float t = red[0][r];
+#pragma unroll
+    for (int i = 1; i < EMD_PARTS; ++i) t += red[i][r];
+    return t;
+}
+
 // pass (a): ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level*d) * remainR[l])          emd_kernel.cu:51-84
 __global__ void __launch_bounds__(EMD_T) emd_pass_a_kernel(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                           float* __restrict__ temp, float level)
 {
     __shared__ float4 buf[EMD_TILE];
-    const int b = blockIdx.y, k = blockIdx.x * EMD_T + threadIdx.x;
+    __shared__ float red[EMD_PARTS][EMD_ROWS];
+    const int b = blockIdx.y, k = blockIdx.x * EMD_ROWS + (threadIdx.x & (EMD_ROWS - 1));
     float* t = temp + (size_t)b * (n + m) * 2;
     const float* remainL = t; const float* remainR = t + n; float* ratioL = t + n + m;
     const float* p1 = xyz1 + (size_t)b * n * 3; const float* p2 = xyz2 + (size_t)b * m * 3;
     float x1 = 0, y1 = 0, z1 = 0;
     if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
-    float suml = 1e-9f;
-    for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
-        const int lend = min(m, l0 + EMD_TILE) - l0;
-        __syncthreads();
-        for (int l = threadIdx.x; l < lend; l += EMD_T)
-            buf[l] = make_float4(p2[(l0 + l) * 3], p2[(l0 + l) * 3 + 1], p2[(l0 + l) * 3 + 2], remainR[l0 + l]);
-        __syncthreads();
-        for (int l = 0; l < lend; ++l) {
-            const float4 q = buf[l];
-            suml += __expf(level * emd_d2(x1, y1, z1, q.x, q.y, q.z)) * q.w;
-        }
-    }
-    if (k < n) ratioL[k] = remainL[k] / suml;
+    const float suml = 1e-9f + emd_row_sum(p2, remainR, m, x1, y1, z1, level, 1.f, false, buf, red);
+    if (threadIdx.x < EMD_ROWS && k < n) ratioL[k] = remainL[k] / suml;
 }
 
 // pass (b): per l: sumr = remainR[l] * sum_k exp(level*d)*ratioL[k]; ratioR, remainR update     emd_kernel.cu:86-119
@@ -56,25 +83,15 @@ __global__ void __launch_bounds__(EMD_T) emd_pass_b_kernel(int n, int m, const f
                                                           float* __restrict__ temp, float level)
 {
     __shared__ float4 buf[EMD_TILE];
-    const int b = blockIdx.y, l = blockIdx.x * EMD_T + threadIdx.x;
+    __shared__ float red[EMD_PARTS][EMD_ROWS];
+    const int b = blockIdx.y, l = blockIdx.x * EMD_ROWS + (threadIdx.x & (EMD_ROWS - 1));
     float* t = temp + (size_t)b * (n + m) * 2;
     float* remainR = t + n; const float* ratioL = t + n + m; float* ratioR = t + n + m + n;
     const float* p1 = xyz1 + (size_t)b * n * 3; const float* p2 = xyz2 + (size_t)b * m * 3;
     float x2 = 0, y2 = 0, z2 = 0;
     if (l < m) { x2 = p2[l * 3]; y2 = p2[l * 3 + 1]; z2 = p2[l * 3 + 2]; }
-    float sumr = 0;
-    for (int k0 = 0; k0 < n; k0 += EMD_TILE) {
-        const int kend = min(n, k0 + EMD_TILE) - k0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < kend; k += EMD_T)
-            buf[k] = make_float4(p1[(k0 + k) * 3], p1[(k0 + k) * 3 + 1], p1[(k0 + k) * 3 + 2], ratioL[k0 + k]);
-        __syncthreads();
-        for (int k = 0; k < kend; ++k) {
-            const float4 q = buf[k];
-            sumr += __expf(level * emd_d2(q.x, q.y, q.z, x2, y2, z2)) * q.w;
-        }
-    }
-    if (l < m) {
+    float sumr = emd_row_sum(p1, ratioL, n, x2, y2, z2, level, 1.f, false, buf, red);
+    if (threadIdx.x < EMD_ROWS && l < m) {
         const float r = remainR[l];
         sumr *= r;
         const float consumption = fminf(r / (sumr + 1e-9f), 1.0f);
@@ -111,28 +128,16 @@ __global__ void __launch_bounds__(EMD_T) emd_pass_c_match_kernel(int n, int m, c
 __global__ void __launch_bounds__(EMD_T) emd_pass_c_sum_kernel(int n, int m, const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                               float* __restrict__ temp, float level)
 {
-#pragma clang fp contract(off)
     __shared__ float4 buf[EMD_TILE];
-    const int b = blockIdx.y, k = blockIdx.x * EMD_T + threadIdx.x;
+    __shared__ float red[EMD_PARTS][EMD_ROWS];
+    const int b = blockIdx.y, k = blockIdx.x * EMD_ROWS + (threadIdx.x & (EMD_ROWS - 1));
     float* t = temp + (size_t)b * (n + m) * 2;
     float* remainL = t; const float* ratioL = t + n + m; const float* ratioR = t + n + m + n;
     const float* p1 = xyz1 + (size_t)b * n * 3; const float* p2 = xyz2 + (size_t)b * m * 3;
     float x1 = 0, y1 = 0, z1 = 0, rl = 0;
     if (k < n) { x1 = p1[k * 3]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratioL[k]; }
-    float suml = 0;
-    for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
-        const int lend = min(m, l0 + EMD_TILE) - l0;
-        __syncthreads();
-        for (int l = threadIdx.x; l < lend; l += EMD_T)
-            buf[l] = make_float4(p2[(l0 + l) * 3], p2[(l0 + l) * 3 + 1], p2[(l0 + l) * 3 + 2], ratioR[l0 + l]);
-        __syncthreads();
-        for (int l = 0; l < lend; ++l) {
-            const float4 q = buf[l];
-            const float w = __expf(level * emd_d2(x1, y1, z1, q.x, q.y, q.z)) * rl * q.w;
-            suml += w;
-        }
-    }
-    if (k < n) remainL[k] = fmaxf(0.0f, remainL[k] - suml);
+    const float suml = emd_row_sum(p2, ratioR, m, x1, y1, z1, level, rl, true, buf, red);      // the weights of emd_pass_c_match_kernel, term for term
+    if (threadIdx.x < EMD_ROWS && k < n) remainL[k] = fmaxf(0.0f, remainL[k] - suml);
 }
 
 // partial[chunk][b] = sum over the chunk's l and all k of match[l][k]*d(k,l)        emd_kernel.cu:200-243
@@ -228,11 +233,11 @@ extern "C" int vnp_emd_approxmatch(hipStream_t st, int B, int n, int m, const fl
     hipLaunchKernelGGL(emd_init_kernel, dim3(vnp_cdiv(n > m ? n : m, 256), B), dim3(256), 0, st, n, m, temp, multiL, multiR);
     for (int j = 7; j >= -2; --j) {
         const float level = j == -2 ? 0.f : -powf(4.0f, (float)j);
-        hipLaunchKernelGGL(emd_pass_a_kernel, dim3(vnp_cdiv(n, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
-        hipLaunchKernelGGL(emd_pass_b_kernel, dim3(vnp_cdiv(m, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
+        hipLaunchKernelGGL(emd_pass_a_kernel, dim3(vnp_cdiv(n, EMD_ROWS), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
+        hipLaunchKernelGGL(emd_pass_b_kernel, dim3(vnp_cdiv(m, EMD_ROWS), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
         hipLaunchKernelGGL(emd_pass_c_match_kernel, dim3(vnp_cdiv(n, EMD_T), vnp_cdiv(m, EMD_LCH), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2,
                            (const float*)temp, match, level);
-        hipLaunchKernelGGL(emd_pass_c_sum_kernel, dim3(vnp_cdiv(n, EMD_T), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
+        hipLaunchKernelGGL(emd_pass_c_sum_kernel, dim3(vnp_cdiv(n, EMD_ROWS), B), dim3(EMD_T), 0, st, n, m, xyz1, xyz2, temp, level);
     }
     return vnp_last_error();
 }
