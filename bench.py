@@ -53,7 +53,8 @@ def parse_args():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-input-MFMA comparison steps (clean profiles)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_other / chamfer_op / configs (clean profiles)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 3, 4, 5 leg (`configs`)")
-    ap.add_argument("--deadline", type=float, default=float(os.environ.get("VNP_BENCH_DEADLINE_S", "900")),
+    ap.add_argument("--shapes", action="store_true", help="print the kernel time of every matrix product of the timed steps, by shape (stderr)")
+    ap.add_argument("--deadline", type=float, default=900.0,
                     help="self-launched ranks (--gpus N without a launcher): wall-clock limit in seconds after which the launcher "
                          "terminates every rank and exits non-zero (a rank stuck in the rendezvous would otherwise hold the others)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -74,8 +75,7 @@ def launch_ranks(n, deadline_s):
         port = s.getsockname()[1]
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   VNP_BENCH_CHILD="1")
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -450,7 +450,7 @@ def main():
         for v, f, ns, shp, kind, t in mfma:
             a = agg.setdefault(v, [0.0, 0.0, 0])
             a[0] += f; a[1] += t; a[2] += 1
-        if os.environ.get("VNP_BENCH_SHAPES"):
+        if args.shapes:
             per = {}
             for v, f, ns, shp, kind, t in recs:
                 if t is None:

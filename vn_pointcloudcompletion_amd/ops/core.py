@@ -98,8 +98,12 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
             bm = 192 if op_a == 0 else 128
             tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
             nk = (K + 31) // 32
-            if tiles < 256 and nk >= 8:
+            if tiles < 64 and nk >= 8:
                 nsplit = max(1, min(nk // 4, 512 // tiles))       # 512 = the persistent grid (2 workgroups x 256 CUs): one item each
+            elif tiles < 256 and nk >= 16:
+                # a quarter of the chip is busy already: split less (one item per CU, slices of >= 8 K-tiles) — measured on MI355X
+                # (scripts/experiments/nsplit_sweep.py): 12288 x 128 x 384 31 -> 22 us unsplit, 12288 x 128 x 1152 (NN) 46 -> 40 us at 4
+                nsplit = max(1, min(nk // 8, 256 // tiles))
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit, M, N), device=A.device, dtype=torch.float32)
