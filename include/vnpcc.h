@@ -345,6 +345,33 @@ int vnp_bn1d_act(hipStream_t st, int mode, const float* x, int ldx, long long P,
                  const float* gamma, const float* beta, int act, float slope, float* y, int ldy, const float* gy, int ldgy,
                  float* partial, const float* sums, long long count);
 
+/* EdgeConv block of the non-equivariant DGCNN_fps (/root/reference/models/dgcnn.py:101-124: Conv2d(1x1) on cat(x_k[nbr] - x_q, x_q) ->
+ * GroupNorm(G) -> LeakyReLU(slope) -> max over the k neighbours) with the convolution applied per point first (u [Pk][C] = W1 x_k,
+ * v [Pq][C] = (W2 - W1) x_q; e(q, j) = u[nbr[q][j]] + v[q]) and the edge tensor never written.  B samples of nq consecutive queries;
+ * nbr [B*nq][k] global row ids of u; G divides C; k <= 255.
+ *   mode 0: partial [B * ceil(nq / 64)][C][2] = Welford (mean, M2) per (block of 64 queries, channel) -> vnp_edge_gn_finalize -> mean, rstd [B][G]
+ *   mode 1: out [Pq][ldo] = max_j leaky(gn(e)), amax [Pq][C] = the j attaining it
+ *   mode 2: partial [B * ceil(nq / 64)][C][4] = (dbeta, dgamma, s1, s2) column sums per block; the caller reduces them per sample -> sums [B][C][4]
+ *   mode 3: gv [Pq][ldgv] = dL/dv;  vnp_edge_gn_gather: gu [Pk][ldgu] = dL/du as a gather over the reverse adjacency (vnp_edge_reverse):
+ *           no atomics, the same bits on every run. */
+int vnp_edge_gn_max(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr, int B, int nq, int k,
+                    int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                    float* out, int ldo, unsigned char* amax, const float* go, int ldgo, float* partial, const float* sums,
+                    float* gv, int ldgv);
+int vnp_edge_gn_finalize(hipStream_t st, const float* partial, int B, int nq, int k, int C, int G, float eps, float* mean, float* rstd);
+int vnp_edge_gn_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr, const int* start,
+                       const int* rev, long long Pk, int B, int nq, int k, int C, int G, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, float slope, const unsigned char* amax, const float* go, int ldgo,
+                       const float* sums, float* gu, int ldgu);
+/* y = act(x + bias) on rows [P][C] (bias [C] or NULL; act 0 none / 1 ReLU / 2 LeakyReLU(slope)); with gy / gx: gx = gy act'(x + bias)
+ * (nn.Linear / Conv1d biases and the ReLU of the baselines' heads: models/dgcnn.py:48-54, models/pcn.py:281-289) */
+int vnp_bias_act(hipStream_t st, const float* x, int ldx, const float* bias, long long P, int C, int act, float slope,
+                 float* y, int ldy, const float* gy, int ldgy, float* gx, int ldgx);
+/* out [B][C] = max over the n rows of each sample of x [B*n][ldx] (torch.max(dim) of models/dgcnn.py:157), amax [B][C] the first row
+ * attaining it; backward: gx [B*n][C] = go at that row, 0 elsewhere (every element written) */
+int vnp_rows_max(hipStream_t st, const float* x, int ldx, int B, int n, int C, float* out, int* amax);
+int vnp_rows_max_bwd(hipStream_t st, const float* go, const int* amax, int B, int n, int C, float* gx);
+
 /* VNLinearLeakyReLU on a map whose VN vectors are all parallel to ONE unit direction u per point (the layer behind VN_PointNet's
  * single-channel first layer, models/pcn.py:165-173 + models/vn_layers.py:46-74), on per-POINT operands:
  *   p[(n,t)][c] = u[n][t] v[n][c] + bias[g(n)*3+t][c],   d[(n,t)][c] = u[n][t] v[n][C+c] + bias[g(n)*3+t][C+c],   g(n) = n / points_per_group

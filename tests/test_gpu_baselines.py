@@ -172,3 +172,65 @@ def test_batchnorm1d_act_kernels_equal_torch(lib_built, P, C, act, slope):
             assert relerr(bn.weight.grad, ref.weight.grad) < 2e-5 and relerr(bn.bias.grad, ref.bias.grad) < 2e-5
             assert relerr(bn.running_mean, ref.running_mean) < 2e-6 and relerr(bn.running_var, ref.running_var) < 2e-6
             assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("B,Nk,Nq,k,C,G", [(2, 300, 300, 16, 32, 4), (3, 640, 128, 16, 128, 4), (1, 70, 70, 5, 24, 3), (2, 200, 100, 8, 64, 4)])
+def test_edge_groupnorm_leaky_max_equals_torch(lib_built, B, Nk, Nq, k, C, G):
+    """vnp_edge_gn_max / vnp_edge_gn_gather (the EdgeConv tail of the non-equivariant DGCNN_fps: GroupNorm(G) + LeakyReLU(0.2) + max over
+    the k neighbours of e(q, j) = u[nbr[q][j]] + v[q], models/dgcnn.py:36-54, 101-124) against the same expression on the materialised
+    [B, C, Nq, k] edge tensor in float64 torch: output, dL/du (gathered over the sorted reverse adjacency), dL/dv, dL/dgamma, dL/dbeta;
+    a block of queries that does not fill 64, C below 64, a neighbour listed twice by one query, and bit-identical repeats."""
+    import torch.nn.functional as F
+    from vn_pointcloudcompletion_amd.baselines import _EdgeGnLeakyMaxFn
+    g = torch.Generator().manual_seed(B * Nk + C)
+    u0, v0 = torch.randn(B * Nk, C, generator=g), torch.randn(B * Nq, C, generator=g)
+    idx = torch.stack([torch.stack([torch.randperm(Nk, generator=g)[:k] for _ in range(Nq)]) for _ in range(B)])      # [B,Nq,k] distinct
+    idx[0, 0, 1] = idx[0, 0, 0]                                                          # one query names a neighbour twice
+    gidx = (idx + torch.arange(B).view(B, 1, 1) * Nk).reshape(B * Nq, k).int()
+    gam0, bet0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    go = torch.randn(B * Nq, C, generator=g)
+
+    def run():
+        u, v = u0.cuda().requires_grad_(True), v0.cuda().requires_grad_(True)
+        gam, bet = gam0.cuda().requires_grad_(True), bet0.cuda().requires_grad_(True)
+        out = _EdgeGnLeakyMaxFn.apply(u, v, gidx.cuda(), gam, bet, B, Nq, G, 1e-5, 0.2)
+        out.backward(go.cuda())
+        return out.detach(), u.grad, v.grad, gam.grad, bet.grad
+    a, b = run(), run()
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    ud, vd = u0.double().requires_grad_(True), v0.double().requires_grad_(True)
+    gd, bd = gam0.double().requires_grad_(True), bet0.double().requires_grad_(True)
+    e = ud[gidx.long().reshape(-1)].view(B, Nq, k, C) + vd.view(B, Nq, 1, C)             # [B,Nq,k,C]
+    y = F.group_norm(e.permute(0, 3, 1, 2), G, gd, bd, 1e-5)                             # [B,C,Nq,k]
+    ref = F.leaky_relu(y, 0.2).max(dim=-1)[0].permute(0, 2, 1).reshape(B * Nq, C)
+    ref.backward(go.double())
+    assert relerr(a[0], ref) < 5e-6
+    for name, mine, want in zip(("gu", "gv", "ggamma", "gbeta"), a[1:], (ud.grad, vd.grad, gd.grad, bd.grad)):
+        assert relerr(mine, want) < 5e-5, (name, relerr(mine, want))
+
+
+def test_bias_act_and_rows_max_equal_torch(lib_built):
+    """vnp_bias_act (bias + ReLU / LeakyReLU on rows, its input and bias gradients) and vnp_rows_max (max over a sample's rows) against torch."""
+    import torch.nn.functional as F
+    from vn_pointcloudcompletion_amd.baselines import _BiasActFn, _RowsMaxFn
+    g = torch.Generator().manual_seed(4)
+    for P, C, act, slope in ((37, 20, 1, 0.0), (3000, 130, 2, 0.2), (5, 1024, 0, 0.0)):
+        x0, b0, go = torch.randn(P, C, generator=g), torch.randn(C, generator=g), torch.randn(P, C, generator=g)
+        x, b = x0.cuda().requires_grad_(True), b0.cuda().requires_grad_(True)
+        y = _BiasActFn.apply(x, b, act, slope)
+        y.backward(go.cuda())
+        xd, bd = x0.double().requires_grad_(True), b0.double().requires_grad_(True)
+        t_ = xd + bd
+        yd = F.relu(t_) if act == 1 else F.leaky_relu(t_, slope) if act == 2 else t_
+        yd.backward(go.double())
+        assert relerr(y, yd) < 1e-6 and relerr(x.grad, xd.grad) < 1e-6 and relerr(b.grad, bd.grad) < 2e-6
+    B, n, C = 3, 128, 1024
+    h0, go = torch.randn(B * n, C, generator=g), torch.randn(B, C, generator=g)
+    h = h0.cuda().requires_grad_(True)
+    m = _RowsMaxFn.apply(h, B, n)
+    m.backward(go.cuda())
+    hd = h0.double().requires_grad_(True)
+    md = hd.view(B, n, C).max(dim=1)[0]
+    md.backward(go.double())
+    assert torch.equal(m.detach().cpu().double(), md.detach()) and torch.equal(h.grad.cpu().double(), hd.grad)

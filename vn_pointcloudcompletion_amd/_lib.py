@@ -146,6 +146,12 @@ _SIGNATURES = {
     "vnp_ref_to_rows": [_vp, _i, _i, _i, _vp, _i],
     "vnp_adam_step": [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f],
     "vnp_pack_tensors": [_i, _vp, _vp, _vp, _vp],
+    "vnp_edge_gn_max": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i],
+    "vnp_edge_gn_finalize": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
+    "vnp_edge_gn_gather": [_vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i],
+    "vnp_bias_act": [_vp, _i, _vp, _ll, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i],
+    "vnp_rows_max": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "vnp_rows_max_bwd": [_vp, _vp, _i, _i, _i, _vp],
 }
 _NO_STREAM = {"vnp_gemm_profile_next": [_vp, _vp, _vp], "vnp_gemm_profile_cancel": [], "vnp_chunk_points": [], "vnp_chunk_points_pc": [_ll, _i], "vnp_gemm_set_mode": [_i], "vnp_gemm_get_mode": [], "vnp_edge_block_queries": [], "vnp_chamfer_pruned_ws_bytes": [_i, _i, _i], "vnp_chamfer_pruned_ws_wave_counts": [_i, _i, _i],
               "vnp_linear_pool_ws_bytes": [_ll, _i, _i], "vnp_linear_pool_screened_ws_bytes": [_ll, _i, _i, _i],

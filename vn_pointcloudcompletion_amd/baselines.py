@@ -9,10 +9,11 @@ so the same seed gives the same weights and reference checkpoints load).
 
 These are baselines outside the measured hot path.  Everything with real arithmetic in it runs on libvnpcc — every
 1x1 convolution / linear layer is ``vnp_gemm`` (point-major rows ``[B*N, C]``), neighbour search is ``vnp_knn``, sampling is
-``vnp_fps``, the loss is the HIP Chamfer, BatchNorm1d with the ReLU / LeakyReLU behind it is ``vnp_bn1d_act`` (round 3) — and there is
-no CPU path (CPU tensors raise).  What is left in ATen on the device: the EdgeConv's GroupNorm(4) + LeakyReLU + max over the k
-neighbours (its backward is dense over all edges through the group statistics: a kernel family of its own, like the VN EdgeConv's), the
-coarse head's ReLU and the global max; as in the VN networks, broadcast input channels are
+``vnp_fps``, the loss is the HIP Chamfer, BatchNorm1d with the ReLU / LeakyReLU behind it is ``vnp_bn1d_act`` (round 3), the EdgeConv's
+GroupNorm(4) + LeakyReLU + max over the k neighbours is ``vnp_edge_gn_max`` (round 4: four passes that recompute the edge values from the
+per-point terms, the neighbour term's gradient gathered over the sorted reverse adjacency — no edge tensor, no atomics), biases and the
+coarse head's ReLU are ``vnp_bias_act``, the global max is ``vnp_rows_max`` — and there is no CPU path (CPU tensors raise).  What is left
+in ATen on the device is index plumbing and the K = 2 seed term of the decoder's first layer.  As in the VN networks, broadcast input channels are
 never materialised: the decoder's first layer is a per-sample bias plus a rank-5 per-point term instead of a GEMM over a
 ``[B, 6149, 16384]`` tensor, and EdgeConv is ``W1 x_k[idx] + (W2 - W1) x_q`` (two per-point GEMMs and a gather) instead of a
 GEMM over the k-times larger edge tensor.
@@ -21,15 +22,136 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, ops
 
 
-def _linear(rows, weight, bias=None):
-    """rows [P, Cin] x weight [Cout, Cin]^T (+ bias) on vnp_gemm, with autograd."""
+class _BiasActFn(torch.autograd.Function):
+    """y = act(x + bias) on rows [P, C] (vnp_bias_act): nn.Linear / Conv1d biases and the ReLU behind them; act 0 none, 1 ReLU, 2 LeakyReLU."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act, slope):
+        from ._lib import call, ptr
+        from .ops import _ld, _rows
+        x = _rows(x)
+        P, C = x.shape
+        y = torch.empty((P, C), device=x.device, dtype=torch.float32)
+        call("vnp_bias_act", ptr(x), _ld(x), ptr(bias), P, C, act, float(slope), ptr(y), C, None, 0, None, 0)
+        ctx.save_for_backward(x, bias)
+        ctx.cfg = (act, float(slope))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from ._lib import call, ptr
+        from .ops import _ld, _rows, reduce_rows
+        x, bias = ctx.saved_tensors
+        act, slope = ctx.cfg
+        gy = _rows(gy)
+        P, C = x.shape
+        if act == 0:
+            gx = gy
+        else:
+            gx = torch.empty((P, C), device=x.device, dtype=torch.float32)
+            call("vnp_bias_act", ptr(x), _ld(x), ptr(bias), P, C, act, slope, None, 0, ptr(gy), _ld(gy), ptr(gx), C)
+        gb = None
+        if bias is not None and ctx.needs_input_grad[1]:
+            from .ops.core import _nchunk
+            g = gx.contiguous()
+            nch = _nchunk(P)
+            part = torch.empty((nch, C), device=x.device, dtype=torch.float32)
+            call("vnp_colsum", ptr(g), 0, C, 1, P, C, None, ptr(part))
+            gb = reduce_rows(part, 1, nch, C)[0]
+        return gx, gb, None, None
+
+
+def _linear(rows, weight, bias=None, act=0, slope=0.0):
+    """act(rows [P, Cin] x weight [Cout, Cin]^T + bias) — the product on vnp_gemm, bias and activation on vnp_bias_act — with autograd."""
     y = ops.VNLinearFn.apply(rows, weight, None, 0)
-    return y if bias is None else y + bias
+    return y if (bias is None and act == 0) else _BiasActFn.apply(y, bias, act, slope)
+
+
+class _RowsMaxFn(torch.autograd.Function):
+    """[B*n, C] rows -> [B, C]: max over the n rows of each sample (torch.max(dim), models/dgcnn.py:157) on vnp_rows_max."""
+
+    @staticmethod
+    def forward(ctx, x, B, n):
+        from ._lib import call, ptr
+        from .ops import _ld, _rows
+        x = _rows(x)
+        C = x.shape[1]
+        out = torch.empty((B, C), device=x.device, dtype=torch.float32)
+        amax = torch.empty((B, C), device=x.device, dtype=torch.int32)
+        call("vnp_rows_max", ptr(x), _ld(x), B, n, C, ptr(out), ptr(amax))
+        ctx.save_for_backward(amax)
+        ctx.cfg = (B, n, C)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        from ._lib import call, ptr
+        (amax,) = ctx.saved_tensors
+        B, n, C = ctx.cfg
+        go = go.contiguous()
+        gx = torch.empty((B * n, C), device=go.device, dtype=torch.float32)
+        call("vnp_rows_max_bwd", ptr(go), ptr(amax), B, n, C, ptr(gx))
+        return gx, None, None
+
+
+class _EdgeGnLeakyMaxFn(torch.autograd.Function):
+    """GroupNorm(G) + LeakyReLU + max over the k neighbours of the edge values e(q, j) = u[nbr[q][j]] + v[q] (vnp_edge_gn_max): the tail of
+    DGCNN_fps' EdgeConv blocks (models/dgcnn.py:36-54, 101-124) without the [B, C, Nq, k] edge tensor.  u [Pk, C], v [B*nq, C] rows,
+    nbr [B*nq, k] int32 global row ids of u.  Returns [B*nq, C]."""
+
+    @staticmethod
+    def forward(ctx, u, v, nbr, gamma, beta, B, nq, G, eps, slope):
+        from ._lib import call, ptr
+        from .ops import _ld, _rows
+        u, v = _rows(u), _rows(v)
+        nbr = nbr.contiguous()
+        C, k = u.shape[1], nbr.shape[1]
+        dev = u.device
+        nblk = B * ((nq + 63) // 64)
+        part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
+        common = (ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), B, nq, k, C, G)
+        call("vnp_edge_gn_max", 0, *common, None, None, None, None, float(slope), None, 0, None, None, 0, ptr(part), None, None, 0)
+        mean = torch.empty((B, G), device=dev, dtype=torch.float32)
+        rstd = torch.empty((B, G), device=dev, dtype=torch.float32)
+        call("vnp_edge_gn_finalize", ptr(part), B, nq, k, C, G, float(eps), ptr(mean), ptr(rstd))
+        out = torch.empty((B * nq, C), device=dev, dtype=torch.float32)
+        amax = torch.empty((B * nq, C), device=dev, dtype=torch.uint8)
+        call("vnp_edge_gn_max", 1, *common, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), float(slope), ptr(out), C, ptr(amax), None, 0, None,
+             None, None, 0)
+        ctx.save_for_backward(u, v, nbr, gamma, beta, mean, rstd, amax)
+        ctx.cfg = (B, nq, G, float(slope))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        from ._lib import call, ptr
+        from .ops import _ld, _rows, edge_reverse, reduce_rows
+        u, v, nbr, gamma, beta, mean, rstd, amax = ctx.saved_tensors
+        B, nq, G, slope = ctx.cfg
+        go = _rows(go)
+        C, k, Pk = u.shape[1], nbr.shape[1], u.shape[0]
+        dev = u.device
+        nblk_s = (nq + 63) // 64
+        common = (ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), B, nq, k, C, G)
+        gn = (ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), slope)
+        part = torch.empty((B * nblk_s, C, 4), device=dev, dtype=torch.float32)
+        call("vnp_edge_gn_max", 2, *common, *gn, None, 0, ptr(amax), ptr(go), _ld(go), ptr(part), None, None, 0)
+        sums = reduce_rows(part.view(B, nblk_s, 4 * C), B, nblk_s, 4 * C)                 # [B, C * 4]: per sample (the group terms)
+        tot = reduce_rows(sums, 1, B, 4 * C)[0].view(C, 4)                                # over the batch: dL/dbeta, dL/dgamma
+        gv = torch.empty((B * nq, C), device=dev, dtype=torch.float32)
+        call("vnp_edge_gn_max", 3, *common, *gn, None, 0, ptr(amax), ptr(go), _ld(go), None, ptr(sums), ptr(gv), C)
+        start, rev = edge_reverse(nbr, Pk)
+        gu = torch.empty((Pk, C), device=dev, dtype=torch.float32)
+        call("vnp_edge_gn_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), ptr(start), ptr(rev), Pk, B, nq, k, C, G, *gn, ptr(amax),
+             ptr(go), _ld(go), ptr(sums), ptr(gu), C)
+        return gu, gv, None, tot[:, 1].contiguous(), tot[:, 0].contiguous(), None, None, None, None, None
 
 
 class _BatchNorm1dActFn(torch.autograd.Function):
@@ -185,15 +307,12 @@ class DGCNN_fps(nn.Module):
         W = conv.weight[:, :, 0, 0]
         Cout = W.shape[0]
         with torch.no_grad():
-            idx = ops.knn_indices(coor_k, coor_q, self.k).long()                       # [B,Nq,k], sorted by (distance, index)
-            gidx = (idx + torch.arange(B, device=idx.device).view(B, 1, 1) * Nk).reshape(-1)
+            idx = ops.knn_indices(coor_k, coor_q, self.k)                              # [B,Nq,k] int32, sorted by (distance, index)
+            gidx = (idx + (torch.arange(B, device=idx.device, dtype=torch.int32) * Nk).view(B, 1, 1)).reshape(B * Nq, self.k)
         u = _linear(x_k.reshape(B * Nk, C), W[:, :C])                                   # neighbour term  W1 x_k
         v = _linear(x_q.reshape(B * Nq, C), W[:, C:] - W[:, :C])                        # centre term  (W2 - W1) x_q
-        e = (u[gidx].view(B, Nq, self.k, Cout) + v.view(B, Nq, 1, Cout)).view(B, Nq * self.k, gn.num_groups, Cout // gn.num_groups)
-        mean = e.mean(dim=(1, 3), keepdim=True)
-        var = e.var(dim=(1, 3), unbiased=False, keepdim=True)
-        y = ((e - mean) * torch.rsqrt(var + gn.eps)).view(B, Nq, self.k, Cout) * gn.weight + gn.bias
-        return F.leaky_relu(y, 0.2).max(dim=2)[0]
+        out = _EdgeGnLeakyMaxFn.apply(u, v, gidx, gn.weight, gn.bias, B, Nq, gn.num_groups, gn.eps, 0.2)
+        return out.view(B, Nq, Cout)
 
     def forward(self, x):
         B, N, _ = x.shape
@@ -209,10 +328,10 @@ class DGCNN_fps(nn.Module):
         n4 = f.shape[1]
         c0, bn, c3 = self.increase_dim[0], self.increase_dim[1], self.increase_dim[3]
         h = _bn_rows(bn, _linear(f.reshape(B * n4, -1), c0.weight[:, :, 0], c0.bias), act=2, slope=0.2)
-        h = _linear(h, c3.weight[:, :, 0], c3.bias).view(B, n4, -1)
-        feature_global = h.max(dim=1)[0]                                                 # [B,1024]
+        h = _linear(h, c3.weight[:, :, 0], c3.bias)                                      # [B*n4, 1024]
+        feature_global = _RowsMaxFn.apply(h, B, n4)                                      # [B,1024]
         l0, l2 = self.coarse_pred[0], self.coarse_pred[2]
-        coarse = _linear(torch.relu(_linear(feature_global, l0.weight, l0.bias)), l2.weight, l2.bias).reshape(-1, self.num_coarse, 3)
+        coarse = _linear(_linear(feature_global, l0.weight, l0.bias, act=1), l2.weight, l2.bias).reshape(-1, self.num_coarse, 3)
         if self.num_coarse == 224:
             idx = ops.fps_indices(x.contiguous().float(), 224).long()
             inp_sparse = torch.gather(x, 1, idx[..., None].expand(-1, -1, 3))
