@@ -3,7 +3,7 @@
 #   bench (config 2): kernel trace + stats; FETCH_SIZE and WRITE_SIZE in separate PMC passes; one SQ/GRBM pass (MFMA busy, wave
 #   states, active cycles -> in-kernel clock).  configs 3, 4, 5 (scripts/bench_configs.py): kernel stats + FETCH / WRITE passes.
 # PMC passes are never combined with other trace domains; the program follows `--` directly (python3, no shell / env hop).
-# Summaries for profiles/ are produced afterwards by scripts/summarize_profile.py (--steps = timed + warm-up steps of the run: 13 for the
+# Summaries for profiles/ are produced afterwards by scripts/summarize_profile.py (--steps = timed + warm-up steps of the run: 14 for the
 # bench passes below, 3 + 5 for the config stats passes).
 set -e
 tag=${1:-r02}
