@@ -276,6 +276,10 @@ int vnp_knn_matrix(hipStream_t st, int B, int D, const float* ref, int Nr, const
 #define VNP_FPS_SKIP_NEAR_ORIGIN 1
 int vnp_fps(hipStream_t st, int B, int N, const float* xyz, int M, int* idx);
 int vnp_fps_ex(hipStream_t st, int B, int N, const float* xyz, int M, int* idx, int flags);
+/* what follows every furthest_point_sample in the reference (gather_operation on the coordinates, models/dgcnn.py:210-218, and the
+ * `idx + arange(B) * N` that turns local picks into row ids): out [B][M][3] = xyz[b][idx[b][i]], gid [B*M] = b * N + idx[b][i] (gid may
+ * be NULL), one launch. */
+int vnp_gather_coords(hipStream_t st, int B, int N, const float* xyz, const int* idx, int M, float* out, int* gid);
 /* rows layout: out point i <- x point src[i] (gather_operation); and its adjoint gx[s] = sum over the i with src[i] == s of g[i]:
  * a gather over the reverse adjacency of src (vnp_edge_reverse), summed in ascending i in double — no atomics, every row of gx written,
  * the same bits on every run.  ws: 2 * (Pin + 1) + 2 * Pout ints. */

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "vnp_fps": [_i, _i, _vp, _i, _vp],
     "vnp_fps_ex": [_i, _i, _vp, _i, _vp, _i],
     "vnp_gather_points": [_vp, _i, _vp, _ll, _i, _vp, _i],
+    "vnp_gather_coords": [_i, _i, _vp, _vp, _i, _vp, _vp],
     "vnp_scatter_add_points": [_vp, _i, _vp, _ll, _i, _vp, _i, _ll, _vp],
     "vnp_vn_bn_finalize_chunked": [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _f, _f],
     "vnp_edge_fused": [_i, _vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _ll, _vp, _i, _ll,

@@ -602,6 +602,28 @@ __global__ void vnp_edge_gather_add_kernel(const float* __restrict__ u, int ldu,
     for (int t = 0; t < 3; ++t) out[(e * 3 + t) * ldo + c] = u[(s * 3 + t) * ldu + c] + v[(p * 3 + t) * ldv + c];
 }
 
+// Sampled coordinates and global point ids of an FPS pick in one launch (instead of arange / mul / add / expand / gather):
+//   out[b][i][:] = xyz[b][idx[b][i]][:],  gid[b * M + i] = b * N + idx[b][i]  (gid may be null).   grid ceil(B*M / 256)
+__global__ void __launch_bounds__(256) vnp_gather_coords_kernel(const float* __restrict__ xyz, int N, const int* __restrict__ idx, int M, long long total,
+                                                                float* __restrict__ out, int* __restrict__ gid)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long b = e / M;
+    const long long s = b * N + idx[e];
+    const float* src = xyz + s * 3;
+    out[e * 3 + 0] = src[0]; out[e * 3 + 1] = src[1]; out[e * 3 + 2] = src[2];
+    if (gid) gid[e] = (int)s;
+}
+
+extern "C" int vnp_gather_coords(hipStream_t st, int B, int N, const float* xyz, const int* idx, int M, float* out, int* gid)
+{
+    if (!xyz || !idx || !out || B <= 0 || N <= 0 || M <= 0 || (long long)B * N > 2147483647LL) return VNP_EINVAL;
+    const long long total = (long long)B * M;
+    hipLaunchKernelGGL(vnp_gather_coords_kernel, dim3((unsigned)vnp_cdiv(total, 256)), dim3(256), 0, st, xyz, N, idx, M, total, out, gid);
+    return vnp_last_error();
+}
+
 // out [Pout*3][ldo] : point i copies point src[i] (global point ids) of x
 extern "C" int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo)
 {

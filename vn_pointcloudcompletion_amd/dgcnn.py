@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .pcn import fps, rows_to_global
+from .pcn import rows_to_global
 from .vn_layers import VNLinear, VNLinearLeakyReLU, VNMaxPool, mean_pool
 
 
@@ -39,22 +39,39 @@ def edge_conv_rows(layer: VNLinearLeakyReLU, x_rows, nbr, k):
     return ops.VNMeanPoolFn.apply(f, x_rows.shape[0] // 3, k)
 
 
+_BASES = {}
+
+
+def batch_base(B, N, device):
+    """int32 [B] = b * N (first global row id of cloud b), made once per (B, N, device) instead of an arange and a multiply per call."""
+    key = (B, N, device)
+    t = _BASES.get(key)
+    if t is None:
+        if len(_BASES) > 64:
+            _BASES.clear()
+        t = _BASES[key] = torch.arange(B, device=device, dtype=torch.int32) * N
+    return t
+
+
 def knn_graph(coords, k):
     """coords [B,N,3] -> global neighbour ids [B*N, k] int32 (no gradient, dgcnn.py:235-241)."""
     B, N, _ = coords.shape
     with torch.no_grad():
         idx = ops.knn_indices(coords, coords, k)                           # [B,N,k] local
-        base = (torch.arange(B, device=coords.device, dtype=torch.int32) * N).view(B, 1, 1)
-        return (idx + base).reshape(B * N, k)
+        return (idx + batch_base(B, N, coords.device).view(B, 1, 1)).reshape(B * N, k)
 
 
-def fps_downsample_rows(coords, f_rows, m):
-    """dgcnn.py:201-222: FPS on the coordinates, gather coordinates and features.  coords [B,N,3], f_rows [B*N*3, C]."""
+def fps_downsample_rows(coords, f_rows, m, picked=None):
+    """dgcnn.py:201-222: FPS on the coordinates, gather coordinates and features.  coords [B,N,3], f_rows [B*N*3, C].
+    ``picked``: (idx, coordinates, global ids) of this level from an ops.FpsPlan started earlier."""
     B, N, _ = coords.shape
-    with torch.no_grad():
-        idx = ops.fps_indices(coords, m)                                   # [B,m]
-        gid = (idx + (torch.arange(B, device=coords.device, dtype=torch.int32) * N).view(B, 1)).reshape(-1)
-    new_coords = torch.gather(coords, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    if picked is None:
+        with torch.no_grad():
+            idx = ops.fps_indices(coords, m)                               # [B,m]
+            gid = (idx + batch_base(B, N, coords.device).view(B, 1)).reshape(-1)
+        new_coords = torch.gather(coords, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    else:
+        _, new_coords, gid = picked
     return new_coords, ops.GatherPointsFn.apply(f_rows, gid)
 
 
@@ -77,13 +94,15 @@ class VN_DGCNN_fps(nn.Module):
         B, N, _ = x.shape
         k = self.k
         coords = x.contiguous().float()
+        # all samplings (512 of the input, 128 of those, the 224 extra coarse points) start now, on a side stream (ops.FpsPlan)
+        plan = ops.FpsPlan(coords, (512, 128), (224,) if self.num_coarse == 224 else ())
         f = coords.reshape(B * N * 3, 1)
         f = edge_conv_rows(self.conv1[0], f, knn_graph(coords, k), k)                  # dynamic graph == coordinates here
-        coor_q, f_q = fps_downsample_rows(coords, f, 512)
+        coor_q, f_q = fps_downsample_rows(coords, f, 512, plan.level(0))
         nbr = knn_graph(coor_q, k)
         f = edge_conv_rows(self.conv4, f_q, nbr, k)
         f = edge_conv_rows(self.conv5, f, nbr, k)
-        coor_q, f_q = fps_downsample_rows(coor_q, f, 128)
+        coor_q, f_q = fps_downsample_rows(coor_q, f, 128, plan.level(1))
         f = edge_conv_rows(self.conv6, f_q, knn_graph(coor_q, k), k)                   # [B*128*3, 512]
         g = self.pool5.forward_rows(f, B, 128)                                         # [B*3, 512]
         h = self.conv7[0].forward_rows(g)
@@ -91,7 +110,8 @@ class VN_DGCNN_fps(nn.Module):
         coarse = h.reshape(B, 3, self.num_coarse).permute(0, 2, 1).contiguous()
         global_feature = rows_to_global(g, B)
         if self.num_coarse == 224:
-            inp_sparse = fps(coords, 224)
+            inp_sparse = plan.level(2)[1]
             coarse_cat = torch.cat([coarse, inp_sparse], dim=1).contiguous()
             return (coarse, coarse_cat), global_feature
+        plan.close()
         return coarse, global_feature

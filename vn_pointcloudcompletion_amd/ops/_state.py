@@ -51,6 +51,7 @@ class _Switches:
     DGRAD_NT_ROWS = 49152           # activations of at least this many rows: input gradient in NT form on the wide tile
     WGRAD_SLICE_TILES = 64          # K-tiles (of 32 rows) per split-K slice of a weight gradient that is multiplied on
     WGRAD_SLAB_BYTES = 128 << 20    # ... as long as the slabs stay under this
+    FPS_AHEAD = True                # an encoder's furthest-point samplings on a side HIP stream beside its kNN / EdgeConv launches (FpsPlan)
 
 
 SW = _Switches()

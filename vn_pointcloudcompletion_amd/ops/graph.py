@@ -62,6 +62,71 @@ def fps_indices(xyz, m, skip_near_origin=None):
     return idx
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    s = _SIDE_STREAMS.get(device.index)
+    if s is None:
+        s = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return s
+
+
+class FpsPlan:
+    """Every furthest-point sampling of an encoder pass (models/dgcnn.py:201-222, 291-314; dgcnn_group.py:141-160; models/pcn.py:6-9)
+    depends on the INPUT COORDINATES alone: level i+1 samples the points level i picked, the 224 extra points of a `num_coarse == 448`
+    head sample the input.  A sampling is M dependent rounds of one workgroup per cloud — latency, 32 of 256 CUs busy — so the whole
+    chain is launched on a side HIP stream as soon as the coordinates exist and runs beside the kNN searches and EdgeConv layers of the
+    main stream; a consumer waits for the event of the level it needs (``level``).  All buffers are allocated on the main stream before
+    the side stream starts and are held by the plan until ``close`` has made the main stream wait for the last event, so the caching
+    allocator cannot hand one of them out while a sampling still reads or writes it.  ``SW.FPS_AHEAD = False``: the same launches in the
+    same order on the main stream.  Each level also yields its coordinates and the global row ids of its picks (vnp_gather_coords)."""
+
+    def __init__(self, coords, chain, extra=()):
+        _lib.require_gpu(coords)
+        coords = coords.contiguous().float()
+        B, N, _ = coords.shape
+        dev = coords.device
+        skip = 1 if SW.FPS_SKIP_NEAR_ORIGIN else 0
+        specs = [(True, int(m)) for m in chain] + [(False, int(m)) for m in extra]
+        self._items, self._events, self._keep = [], [], [coords]
+        for _, m in specs:
+            self._items.append((torch.empty((B, m), device=dev, dtype=torch.int32), torch.empty((B, m, 3), device=dev, dtype=torch.float32),
+                                torch.empty(B * m, device=dev, dtype=torch.int32)))
+        self._main = torch.cuda.current_stream(dev)
+        ahead = SW.FPS_AHEAD and HK.trace is None          # a traced pass reads its picks on the host while it runs: keep it on one stream
+        self._side = _side_stream(dev) if ahead else None
+        if self._side is not None:
+            self._side.wait_stream(self._main)
+        cur, n = coords, N
+        with torch.cuda.stream(self._side if self._side is not None else self._main):
+            for (chained, m), (idx, xyz_m, gid) in zip(specs, self._items):
+                src, ns = (cur, n) if chained else (coords, N)
+                call("vnp_fps_ex", B, ns, ptr(src), m, ptr(idx), skip)
+                call("vnp_gather_coords", B, ns, ptr(src), ptr(idx), m, ptr(xyz_m), ptr(gid))
+                if self._side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    self._events.append(ev)
+                if chained:
+                    cur, n = xyz_m, m
+        self._waited = -1
+
+    def level(self, i):
+        """(idx [B, m] int32 local picks, coordinates [B, m, 3], global row ids [B*m] int32) of item i, ready on the current stream."""
+        if self._side is not None and i > self._waited:
+            torch.cuda.current_stream().wait_event(self._events[i])
+            self._waited = i
+        idx, xyz_m, gid = self._items[i]
+        trace("fps", idx, key="fps_idx")
+        return idx, xyz_m, gid
+
+    def close(self):
+        if self._side is not None and self._events and self._waited < len(self._events) - 1:
+            torch.cuda.current_stream().wait_event(self._events[-1])
+            self._waited = len(self._events) - 1
+
+
 class GatherPointsFn(Function):
     """rows layout: out point i <- x point src[i] (global point ids, int32 [Pout]).  gather_operation of pointnet2_ops
     (models/dgcnn.py:214-218) on VN features; backward = scatter-add."""

@@ -12,8 +12,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .dgcnn import edge_conv_rows, fps_downsample_rows, knn_graph
-from .pcn import fps, rows_to_global
+from .dgcnn import batch_base, edge_conv_rows, fps_downsample_rows, knn_graph
+from .pcn import rows_to_global
 from .vn_layers import (VNLayerNorm, VNLeakyReLU, VNLinear, VNLinearAndLeakyReLU, VNLinearLeakyReLU, VNMaxPool, mean_pool)
 
 
@@ -23,8 +23,7 @@ def feature_knn_graph(f_rows, B, N, k):
     with torch.no_grad():
         feats = f_rows.detach().reshape(B, N, -1)
         idx = ops.knn_indices(feats, feats, k)
-        base = (torch.arange(B, device=f_rows.device, dtype=torch.int32) * N).view(B, 1, 1)
-        return (idx + base).reshape(B * N, k)
+        return (idx + batch_base(B, N, f_rows.device).view(B, 1, 1)).reshape(B * N, k)
 
 
 class VN_DGCNN_Grouper(nn.Module):
@@ -39,16 +38,22 @@ class VN_DGCNN_Grouper(nn.Module):
         self.conv6 = VNLinearLeakyReLU(128, 128)
         self.pool1 = self.pool2 = self.pool3 = self.pool4 = mean_pool
 
-    def forward_rows(self, coords):
-        """coords [B,N,3] -> (proxy coordinates [B,128,3], proxy features rows [B*128*3, 128])."""
+    def forward_rows(self, coords, plan=None):
+        """coords [B,N,3] -> (proxy coordinates [B,128,3], proxy features rows [B*128*3, 128]).  ``plan``: an ops.FpsPlan whose first two
+        levels are this grouper's samplings (512 of the input, 128 of those)."""
         B, N, _ = coords.shape
         k = self.K
+        own = plan is None
+        if own:
+            plan = ops.FpsPlan(coords, (512, 128))
         f = coords.reshape(B * N * 3, 1)
         f = edge_conv_rows(self.conv1[0], f, knn_graph(coords, k), k)           # features == coordinates: D = 3
-        coor_q, f_q = fps_downsample_rows(coords, f, 512)
+        coor_q, f_q = fps_downsample_rows(coords, f, 512, plan.level(0))
         f = edge_conv_rows(self.conv4, f_q, feature_knn_graph(f_q, B, 512, k), k)
         f = edge_conv_rows(self.conv5, f, feature_knn_graph(f, B, 512, k), k)
-        coor_q, f_q = fps_downsample_rows(coor_q, f, 128)
+        coor_q, f_q = fps_downsample_rows(coor_q, f, 128, plan.level(1))
+        if own:
+            plan.close()
         f = edge_conv_rows(self.conv6, f_q, feature_knn_graph(f_q, B, 128, k), k)
         return coor_q, f
 
@@ -230,13 +235,15 @@ class VN_PCTransformer(nn.Module):
         """inpc [B,N,3] -> (coarse [B, 1024+224, 3], global_feature [B,1024,3,1])."""
         B = inpc.shape[0]
         inpc = inpc.contiguous().float()
-        coor, f = self.grouper.forward_rows(inpc)                               # [B,128,3], [B*128*3, 128]
+        # the grouper's two samplings and the 224 extra coarse points (vn_pointr.py:720) start now, on a side stream (ops.FpsPlan)
+        plan = ops.FpsPlan(inpc, (512, 128), (224,))
+        coor, f = self.grouper.forward_rows(inpc, plan)                         # [B,128,3], [B*128*3, 128]
         nc = coor.shape[1]
         x, pos = self.embed_rows(inpc, coor, f)
         nbr = knn_graph(coor, 8)                                                # get_knn_index(coor), k = 8 (vn_pointr.py:10,17-29)
         for i, blk in enumerate(self.encoder):
             x = blk.forward_rows(x + pos, B, nc, nbr if i < self.knn_layer else None)
         coarse, global_feature = self.head_rows(x, B, nc)
-        inp_sparse = fps(inpc, 224)
+        inp_sparse = plan.level(2)[1]
         coarse = torch.cat([coarse, inp_sparse], dim=1).contiguous()
         return coarse, global_feature
