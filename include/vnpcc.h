@@ -95,6 +95,11 @@ int vnp_gemm(hipStream_t st, int op_a, int op_b, int M, int N, int K,
              const float* A, int lda, const float* B, int ldb, float* C, int ldc,
              const float* bias, int ldbias, int rows_per_group,
              int accumulate, int nsplit, float* ws);
+/* C = op(A) op(B) + R: vnp_gemm (no bias) with a residual connection taken in the epilogue — models/pointr/vn_pointr.py:401-410,
+ * models/transformer.py:60-65 add a block's attention / MLP branch to its input right after the branch's last VNLinear.  R [M][N] with
+ * row stride ldr >= N; R may be C.  With split-K the slab reduction adds R. */
+int vnp_gemm_add(hipStream_t st, int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* R, int ldr, int nsplit, float* ws);
 /* vnp_gemm given the operands' absolute maxima (opt-in fast path): amax_a / amax_b (both or neither) are device words holding the bit
  * pattern of max |A| and max |B| over the WHOLE operand (vnp_absmax; any upper bound within a few binades works, an element ABOVE the
  * word overflows to Inf / NaN).  Aligned shapes with K >= 64 then run on two fp16 planes of the power-of-two scaled operands and three
@@ -132,9 +137,23 @@ int vnp_vn_layernorm_fwd(hipStream_t st, const float* x, int ldx, long long P, i
 /* part [ceil(P/4)][2][C] partial (dgamma | dbeta) sums, reduce over the first axis with vnp_reduce_rows */
 int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, const float* x, int ldx, long long P, int C,
                          const float* gamma, const float* beta, const float* stats, float* gx, int ldgx, float* part);
+/* VNLayerNorm of s = x + a1 (+ a2, may be NULL), with s written to sum_out [P*3][lds] (the residual stream a transformer block carries:
+ * x + pos, models/pointr/vn_pointr.py:700, and vn_x + x_2 of the block before, :410); sum_out must not alias an input.
+ * _bwd_add: the backward of VNLayerNorm plus gres, the gradient that reaches the same tensor through the block's skip connection. */
+int vnp_vn_add_layernorm_fwd(hipStream_t st, const float* x, int ldx, const float* a1, int lda1, const float* a2, int lda2,
+                             long long P, int C, const float* gamma, const float* beta, float* sum_out, int lds,
+                             float* out, int ldo, float* stats);
+int vnp_vn_layernorm_bwd_add(hipStream_t st, const float* go, int ldgo, const float* x, int ldx, long long P, int C,
+                             const float* gamma, const float* beta, const float* stats, const float* gres, int ldgres,
+                             float* gx, int ldgx, float* part);
 /* rows [B*N*3][ld] <-> heads [B][H][N][(C/H)*3] (transformer.py:91-93: reshape(B,H,C/H,3,N).permute(0,1,4,2,3)) */
 int vnp_rows_to_heads(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, float* heads);
 int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int N, int C, int H, float* rows, int ld);
+/* the same for G matrices side by side in the rows (q | k | v of ONE projection GEMM: rows [B*N*3][G*C], any row stride ld >= G*C):
+ * heads = G tensors [B*H][N][3 C / H], one after the other — the three permutes of an attention (forward), or of its gradient, in one
+ * launch.  G*C <= 5000. */
+int vnp_rows_to_heads_grouped(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, int G, float* heads);
+int vnp_heads_to_rows_grouped(hipStream_t st, const float* heads, int B, int N, int C, int H, int G, float* rows, int ld);
 /* The same permutation into layouts the aligned GEMM kernels can take when the head dimension Dh = 3 C / H (144 in
  * Attention_VN_FoldingNet) is neither a multiple of 32 nor of 128:
  *   _pad: token-major heads [(b, h)][n][ldh], ldh >= Dh, columns [Dh, ldh) zero   (K of q k^T and dout v^T, padded to a multiple of 32)

@@ -361,3 +361,68 @@ def test_attention_decoder_fused_stage_tails_equal_layer_by_layer(lib_built):
     assert [n for n, _ in res[True][2]] == [n for n, _ in res[False][2]]
     for (n, a), (_, b) in zip(res[True][2], res[False][2]):
         assert relerr(a, b) < 1e-4, (n, relerr(a, b))
+
+
+@pytest.mark.parametrize("B,N,C,H", [(2, 37, 384, 4), (1, 128, 384, 4), (3, 5, 12, 2)])
+def test_grouped_head_permutes_equal_three_single_ones(lib_built, B, N, C, H):
+    """vnp_rows_to_heads_grouped / vnp_heads_to_rows_grouped (q | k | v side by side in the rows -> three head tensors and back, one
+    launch each) against three vnp_rows_to_heads / vnp_heads_to_rows calls on the column thirds: the same floats in the same places,
+    also with a row stride wider than the matrix."""
+    from vn_pointcloudcompletion_amd import ops
+    from vn_pointcloudcompletion_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(C + N)
+    wide = torch.randn(B * N * 3, 3 * C + 8, generator=g).cuda()
+    qkv = wide[:, :3 * C]
+    heads = torch.empty((3, B * H, N, (C // H) * 3), device="cuda")
+    call("vnp_rows_to_heads_grouped", ptr(qkv), qkv.stride(0), B, N, C, H, 3, ptr(heads))
+    for i in range(3):
+        assert torch.equal(heads[i], ops._to_heads(qkv[:, i * C:(i + 1) * C], B, N, H))
+    back = torch.full_like(wide, 7.0)
+    call("vnp_heads_to_rows_grouped", ptr(heads), B, N, C, H, 3, ptr(back), back.stride(0))
+    assert torch.equal(back[:, :3 * C], qkv) and bool((back[:, 3 * C:] == 7.0).all())
+
+
+@pytest.mark.parametrize("M,N,K,nsplit", [(12288, 128, 384, 1), (12288, 128, 384, 4), (96, 256, 2048, 16), (100, 130, 70, 1), (384, 128, 12288, 32)])
+def test_gemm_with_a_residual_in_the_epilogue(lib_built, M, N, K, nsplit):
+    """vnp_gemm_add (C = A B^T + R, the skip connection of a transformer block taken in the epilogue of the VNLinear that ends the
+    branch, models/pointr/vn_pointr.py:401-410) against vnp_gemm followed by an addition: the same bits (one fp32 addition of the same two
+    numbers either way), aligned and ragged shapes, with split-K (the slab reduction adds R), R with a wider row stride, and R = C."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    op_a = 1 if K > 4 * M else 0
+    A = (torch.randn(K, M, generator=g) if op_a else torch.randn(M, K, generator=g)).cuda()
+    Bm = (torch.randn(K, N, generator=g) if op_a else torch.randn(N, K, generator=g)).cuda()
+    Rw = torch.randn(M, N + 4, generator=g).cuda()
+    R = Rw[:, :N]
+    want = ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit) + R
+    got = ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit, resid=R)
+    assert torch.equal(got, want)
+    inplace = R.contiguous()
+    ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit, resid=inplace, out=inplace)
+    assert torch.equal(inplace, want)
+
+
+@pytest.mark.parametrize("P,C,na", [(4096, 128, 2), (37, 384, 1), (5, 12, 0), (300, 128, 2)])
+def test_add_layernorm_equals_the_adds_and_the_layernorm(lib_built, P, C, na):
+    """ops.AddLayerNormFn (s = x + a1 + a2, y = VNLayerNorm(s), and in the backward the skip connection's gradient added inside the
+    LayerNorm's pass) against ATen additions around ops.VNLayerNormFn: s, y and every gradient bit for bit."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(P + C)
+    leaves = [torch.randn(P * 3, C, generator=g).cuda() for _ in range(1 + na)]
+    gam0, bet0 = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    gs, gy = torch.randn(P * 3, C, generator=g).cuda(), torch.randn(P * 3, C, generator=g).cuda()
+
+    def run(fused):
+        xs = [v.clone().requires_grad_(True) for v in leaves]
+        gam, bet = gam0.clone().requires_grad_(True), bet0.clone().requires_grad_(True)
+        if fused:
+            s, y = ops.AddLayerNormFn.apply(xs[0], xs[1] if na > 0 else None, xs[2] if na > 1 else None, gam, bet)
+        else:
+            s = xs[0]
+            for v in xs[1:]:
+                s = s + v
+            y = ops.VNLayerNormFn.apply(s, gam, bet)
+        torch.autograd.backward([s, y], [gs, gy])
+        return [s.detach(), y.detach()] + [v.grad for v in xs] + [gam.grad, bet.grad]
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)

@@ -322,3 +322,35 @@ def test_knn_coords_kernel_equals_matrix_path(lib_built, Nr, Nq, k):
     # exact ties (samples 1 and 2) resolve to the lowest indices: among equal distances no unselected index lies below a selected one
     same = d64[2, 0]                                               # sample 2: every reference at the same distance
     assert torch.equal(idx[2, 0].cpu(), torch.arange(k, dtype=torch.int32)) and float(same.max() - same.min()) == 0.0
+
+
+@pytest.mark.parametrize("ahead", [True, False])
+def test_fps_plan_equals_the_samplings_one_after_the_other(lib_built, ahead):
+    """ops.FpsPlan (the encoder's furthest-point samplings, chained 512 -> 128 plus 224 extra picks of the input, launched on a side
+    stream beside other work) against ops.fps_indices + gathers on the main stream: the same picks, coordinates and global row ids, with
+    main-stream work queued before (the plan must wait for it: the coordinates are written by that work) and after."""
+    from vn_pointcloudcompletion_amd import ops
+    B, N = 5, 2048
+    g = torch.Generator().manual_seed(11)
+    base = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    with ops.switches(FPS_AHEAD=ahead):
+        busy = torch.randn(4096, 4096, device="cuda")
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                       # main-stream work the side stream has to queue behind
+        coords = base * 1.0 + 0.0                           # produced on the main stream just before the plan starts
+        plan = ops.FpsPlan(coords, (512, 128), (224,))
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                       # and work that runs beside the samplings
+        got = [plan.level(i) for i in range(3)]
+        plan.close()
+    torch.cuda.synchronize()
+    i512 = ops.fps_indices(base, 512)
+    c512 = torch.gather(base, 1, i512.long().unsqueeze(-1).expand(-1, -1, 3))
+    i128 = ops.fps_indices(c512, 128)
+    c128 = torch.gather(c512, 1, i128.long().unsqueeze(-1).expand(-1, -1, 3))
+    i224 = ops.fps_indices(base, 224)
+    c224 = torch.gather(base, 1, i224.long().unsqueeze(-1).expand(-1, -1, 3))
+    off = torch.arange(B, device="cuda", dtype=torch.int32).view(B, 1)
+    for (idx, xyz, gid), (ri, rc, n_src) in zip(got, ((i512, c512, N), (i128, c128, 512), (i224, c224, N))):
+        assert torch.equal(idx, ri) and torch.equal(xyz, rc)
+        assert torch.equal(gid, (ri + off * n_src).reshape(-1))

@@ -81,13 +81,18 @@ _SIGNATURES = {
     "vnp_gemm": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "vnp_gemm_vn_stats": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "vnp_gemm_vn_stats_ex": [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "vnp_gemm_add": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "vnp_gemm_ex": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "vnp_absmax": [_vp, _ll, _ll, _i, _vp],
     "vnp_gemm_batched": [_i, _i, _i, _i, _i, _vp, _i, _ll, _vp, _i, _ll, _vp, _i, _ll, _i, _i],
     "vnp_vn_layernorm_fwd": [_vp, _i, _ll, _i, _vp, _vp, _vp, _i, _vp],
     "vnp_vn_layernorm_bwd": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "vnp_vn_add_layernorm_fwd": [_vp, _i, _vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "vnp_vn_layernorm_bwd_add": [_vp, _i, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "vnp_rows_to_heads": [_vp, _i, _i, _i, _i, _i, _vp],
     "vnp_heads_to_rows": [_vp, _i, _i, _i, _i, _vp, _i],
+    "vnp_rows_to_heads_grouped": [_vp, _i, _i, _i, _i, _i, _i, _vp],
+    "vnp_heads_to_rows_grouped": [_vp, _i, _i, _i, _i, _i, _vp, _i],
     "vnp_rows_to_heads_pad": [_vp, _i, _i, _i, _i, _i, _vp, _i],
     "vnp_rows_to_heads_fm": [_vp, _i, _i, _i, _i, _i, _vp, _i],
     "vnp_heads_fm_to_rows": [_vp, _i, _i, _i, _i, _i, _vp, _i],

@@ -65,8 +65,11 @@ class Attention_VN_FoldingNet(nn.Module):
         # pcn.py:467: [bs,384,3,1].expand(N).reshape(bs,1152,N).transpose -> tokens with feature index c*3+t
         tok = g.reshape(bs, 3, 384).permute(0, 2, 1).reshape(bs, 1, 1152).expand(-1, N, -1) + centers
         rows = tokens_to_rows(tok, 384)                                                              # [bs*N*3, 384]
-        for blk in self.transformer:
-            rows = blk.forward_rows(rows, bs, N)
+        carry = None
+        for blk in self.transformer:                                     # a block's output stays the pair (skip stream, MLP branch) until
+            rows, carry = blk.forward_rows_split(rows, bs, N, carry=carry)   # the next LayerNorm pass (or the add below) sums it
+        if carry is not None:
+            rows = rows + carry
         # rows now hold feature_global.reshape(bs,N,-1,3).permute(0,2,3,1) == per-centre features [bs*N, 384, 3]
         dev = coarse.device
         if self.folding_seed.device != dev:

@@ -15,14 +15,31 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // One wave per point (4 points per block).  stats[pt] = (mean, rstd) of the C norms of that point.
+// a1 / a2 (optional): the normalised tensor is s = x + a1 (+ a2) — a block's input plus its position embedding plus the previous block's
+// MLP branch — and s is written to sum_out (the residual stream) by the lanes that then read it back for the norms.
 __global__ void __launch_bounds__(256) vnp_ln_fwd_kernel(const float* __restrict__ x, int ldx, long long P, int C,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ out, int ldo, float2* __restrict__ stats)
+                                                        float* __restrict__ out, int ldo, float2* __restrict__ stats,
+                                                        const float* __restrict__ a1, int lda1, const float* __restrict__ a2, int lda2,
+                                                        float* sum_out, int lds)
 {
     const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pt >= P) return;
     const float* r = x + (size_t)pt * 3 * ldx;
+    if (a1) {
+        float* so = sum_out + (size_t)pt * 3 * lds;
+        const float* p1 = a1 + (size_t)pt * 3 * lda1;
+        const float* p2 = a2 ? a2 + (size_t)pt * 3 * lda2 : nullptr;
+        for (int c = lane; c < C; c += 64)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                float v = r[t * ldx + c] + p1[t * lda1 + c];
+                if (p2) v += p2[t * lda2 + c];
+                so[t * lds + c] = v;
+            }
+        r = so; ldx = lds;                 // each lane re-reads only what it wrote itself
+    }
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += sqrtf(r[c] * r[c] + r[ldx + c] * r[ldx + c] + r[2 * ldx + c] * r[2 * ldx + c]) + VNP_EPS;
     const float mean = wave_sum(s) / (float)C;
@@ -46,7 +63,7 @@ __global__ void __launch_bounds__(256) vnp_ln_fwd_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict__ go, int ldgo, const float* __restrict__ x, int ldx,
                                                         long long P, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float2* __restrict__ stats, float* __restrict__ gx, int ldgx,
-                                                        float* __restrict__ part)
+                                                        float* __restrict__ part, const float* __restrict__ gres, int ldgres)
 {
     extern __shared__ float sm[];                 // [4 waves][2][C]
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -69,6 +86,8 @@ __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict
         }
         a = wave_sum(a) / (float)C; b = wave_sum(b) / (float)C;
         float* o = gx + (size_t)pt * 3 * ldgx;
+        // gres (optional): the gradient arriving on the residual path of the same tensor, added here instead of by a separate launch
+        const float* gr = gres ? gres + (size_t)pt * 3 * ldgres : nullptr;
         for (int c = lane; c < C; c += 64) {
             const float x0 = r[c], x1 = r[ldx + c], x2 = r[2 * ldx + c];
             const float pn = sqrtf(x0 * x0 + x1 * x1 + x2 * x2), n = pn + VNP_EPS;
@@ -79,7 +98,9 @@ __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict
             const float gnl = gs / n;
             const float gn = rstd * (gamma[c] * gnl - a - xh * b) - gs * nl / (n * n);
             const float sc = nl / n, kk = pn > 0.f ? gn / pn : 0.f;
-            o[c] = sc * g0 + kk * x0; o[ldgx + c] = sc * g1 + kk * x1; o[2 * ldgx + c] = sc * g2 + kk * x2;
+            float o0 = sc * g0 + kk * x0, o1 = sc * g1 + kk * x1, o2 = sc * g2 + kk * x2;
+            if (gr) { o0 += gr[c]; o1 += gr[ldgres + c]; o2 += gr[2 * ldgres + c]; }
+            o[c] = o0; o[ldgx + c] = o1; o[2 * ldgx + c] = o2;
         }
     }
     __syncthreads();
@@ -96,7 +117,7 @@ __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict
 // through the fabric — profiles/r03_cfg5_summary.json: 57 MB written for 19 MB read.)
 template <bool TO_HEADS>
 __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int B, int N, int C, int H, int PN,
-                                                              int ldh)
+                                                              int ldh, int hg, long long gstride)
 {
     extern __shared__ __attribute__((aligned(16))) float tile[];      // [PN][3][C] in the rows' order
     const int ch = C / H, Dh = ch * 3, per = 3 * C;
@@ -137,12 +158,15 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
         for (int p = wave; p < cnt; p += 4) {
             const long long tok = tok0 + p;
             const int b = (int)(tok / N), n = (int)(tok - (long long)b * N);
-            const size_t g0 = ((size_t)b * H * N + n) * ldh;                  // slice of head 0; head h: + h N ldh
+            // heads in groups of hg (q | k | v side by side in the rows: one head tensor [B * hg][N][ldh] per group, gstride floats apart;
+            // hg = H: one group): head h = gi hg + hl lives at gi gstride + ((b hg + hl) N + n) ldh
+            const size_t g0 = ((size_t)b * hg * N + n) * ldh;
+            auto head_off = [&](int hh) { const int gi = hh / hg; return (size_t)gi * gstride + (size_t)(hh - gi * hg) * N * ldh; };
             const float* tp = tile + p * per;
             int h = lane / ch, cl = lane - h * ch;
 #pragma unroll 2
             for (int c = lane; c < C; c += 64) {
-                const size_t g = g0 + (size_t)h * N * ldh + cl * 3;
+                const size_t g = g0 + head_off(h) + cl * 3;
                 if (load) {
                     const float v0 = src[g], v1 = src[g + 1], v2 = src[g + 2];
                     tile[p * per + c] = v0; tile[p * per + C + c] = v1; tile[p * per + 2 * C + c] = v2;
@@ -153,7 +177,7 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
                 while (cl >= ch) { cl -= ch; ++h; }
             }
             if (!load && pad > 0)
-                for (int i = lane; i < H * pad; i += 64) { const int hh = i / pad, r = i - hh * pad; dst[g0 + (size_t)hh * N * ldh + Dh + r] = 0.f; }
+                for (int i = lane; i < H * pad; i += 64) { const int hh = i / pad, r = i - hh * pad; dst[g0 + head_off(hh) + Dh + r] = 0.f; }
         }
     };
     if (TO_HEADS) { rows_side(true); __syncthreads(); heads_side(false); }
@@ -329,7 +353,20 @@ extern "C" int vnp_vn_layernorm_fwd(hipStream_t st, const float* x, int ldx, lon
                                     float* out, int ldo, float* stats)
 {
     if (!x || !gamma || !beta || !out || P <= 0 || C <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_ln_fwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), 0, st, x, ldx, P, C, gamma, beta, out, ldo, (float2*)stats);
+    hipLaunchKernelGGL(vnp_ln_fwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), 0, st, x, ldx, P, C, gamma, beta, out, ldo, (float2*)stats,
+                       (const float*)nullptr, 0, (const float*)nullptr, 0, (float*)nullptr, 0);
+    return vnp_last_error();
+}
+
+// s = x + a1 (+ a2, may be NULL) -> sum_out (the residual stream), out = VNLayerNorm(s): the adds of a transformer block's input
+// (x + pos, models/pointr/vn_pointr.py:700; vn_x + x_2 of the previous block, :410) inside the pass that normalises it
+extern "C" int vnp_vn_add_layernorm_fwd(hipStream_t st, const float* x, int ldx, const float* a1, int lda1, const float* a2, int lda2,
+                                        long long P, int C, const float* gamma, const float* beta, float* sum_out, int lds,
+                                        float* out, int ldo, float* stats)
+{
+    if (!x || !a1 || !sum_out || !gamma || !beta || !out || P <= 0 || C <= 0 || sum_out == x || sum_out == a1 || sum_out == a2) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_ln_fwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), 0, st, x, ldx, P, C, gamma, beta, out, ldo, (float2*)stats,
+                       a1, lda1, a2, lda2, sum_out, lds);
     return vnp_last_error();
 }
 
@@ -339,7 +376,19 @@ extern "C" int vnp_vn_layernorm_bwd(hipStream_t st, const float* go, int ldgo, c
 {
     if (!go || !x || !gamma || !beta || !stats || !gx || !part || P <= 0 || C <= 0 || C > 4096) return VNP_EINVAL;
     hipLaunchKernelGGL(vnp_ln_bwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), (size_t)8 * C * 4, st, go, ldgo, x, ldx, P, C, gamma, beta,
-                       (const float2*)stats, gx, ldgx, part);
+                       (const float2*)stats, gx, ldgx, part, (const float*)nullptr, 0);
+    return vnp_last_error();
+}
+
+// gx = (backward of VNLayerNorm) + gres: the normalised tensor also feeds the block's skip connection, whose gradient gres [P*3][C]
+// arrives separately; adding it here replaces the launch autograd would spend on the sum
+extern "C" int vnp_vn_layernorm_bwd_add(hipStream_t st, const float* go, int ldgo, const float* x, int ldx, long long P, int C,
+                                        const float* gamma, const float* beta, const float* stats, const float* gres, int ldgres,
+                                        float* gx, int ldgx, float* part)
+{
+    if (!go || !x || !gamma || !beta || !stats || !gres || !gx || !part || P <= 0 || C <= 0 || C > 4096) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_ln_bwd_kernel, dim3(vnp_cdiv(P, 4)), dim3(256), (size_t)8 * C * 4, st, go, ldgo, x, ldx, P, C, gamma, beta,
+                       (const float2*)stats, gx, ldgx, part, gres, ldgres);
     return vnp_last_error();
 }
 
@@ -351,7 +400,7 @@ extern "C" int vnp_rows_to_heads_pad(hipStream_t st, const float* rows, int ld, 
     const long long blocks = ((long long)B * N + pn - 1) / pn;
     if (blocks > 2147483647LL) return VNP_EINVAL;
     hipLaunchKernelGGL((vnp_head_permute_kernel<true>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * C * sizeof(float), st,
-                       rows, heads, ld, B, N, C, H, pn, ldh);
+                       rows, heads, ld, B, N, C, H, pn, ldh, H, 0LL);
     return vnp_last_error();
 }
 
@@ -368,8 +417,35 @@ extern "C" int vnp_heads_to_rows(hipStream_t st, const float* heads, int B, int 
     const long long blocks = ((long long)B * N + pn - 1) / pn;
     if (blocks > 2147483647LL) return VNP_EINVAL;
     hipLaunchKernelGGL((vnp_head_permute_kernel<false>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * C * sizeof(float), st,
-                       heads, rows, ld, B, N, C, H, pn, 3 * (C / H));
+                       heads, rows, ld, B, N, C, H, pn, 3 * (C / H), H, 0LL);
     return vnp_last_error();
+}
+
+// G matrices side by side in the rows (q | k | v of one projection GEMM: rows [B*N*3][G*C], any row stride) <-> G head tensors
+// heads[g] = [B*H][N][3 C / H], contiguous one after the other: the three (or G) permutes of an attention in one launch
+static int vnp_heads_grouped(hipStream_t st, bool to_heads, const float* src, float* dst, int ld, int B, int N, int C, int H, int G)
+{
+    if (!src || !dst || B <= 0 || N <= 0 || C <= 0 || H <= 0 || G <= 0 || C % H || ld < G * C || (long long)G * C > 5000) return VNP_EINVAL;
+    const int Ct = G * C, Ht = G * H;
+    const int pn = vnp_head_permute_pn(Ct);
+    const long long blocks = ((long long)B * N + pn - 1) / pn;
+    if (blocks > 2147483647LL) return VNP_EINVAL;
+    const long long gstride = (long long)B * H * N * 3 * (C / H);
+    if (to_heads) hipLaunchKernelGGL((vnp_head_permute_kernel<true>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * Ct * sizeof(float), st,
+                                     src, dst, ld, B, N, Ct, Ht, pn, 3 * (C / H), H, gstride);
+    else          hipLaunchKernelGGL((vnp_head_permute_kernel<false>), dim3((unsigned)blocks), dim3(256), (size_t)pn * 3 * Ct * sizeof(float), st,
+                                     src, dst, ld, B, N, Ct, Ht, pn, 3 * (C / H), H, gstride);
+    return vnp_last_error();
+}
+
+extern "C" int vnp_rows_to_heads_grouped(hipStream_t st, const float* rows, int ld, int B, int N, int C, int H, int G, float* heads)
+{
+    return vnp_heads_grouped(st, true, rows, heads, ld, B, N, C, H, G);
+}
+
+extern "C" int vnp_heads_to_rows_grouped(hipStream_t st, const float* heads, int B, int N, int C, int H, int G, float* rows, int ld)
+{
+    return vnp_heads_grouped(st, false, heads, rows, ld, B, N, C, H, G);
 }
 
 // feature-major heads hf [(b, h)][fr][N], fr >= 3 C / H (rows beyond the head dimension are written as zeros) <-> rows [(b, n, t)][C]

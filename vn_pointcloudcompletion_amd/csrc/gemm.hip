@@ -92,7 +92,7 @@ static int vnp_num_cus()
 // rounding of its K-slices only, which average out over the slabs, instead of another sqrt(nsplit) 2^-24 of the running total —
 // it matters where the gradient is multiplied on into a cancelling product (ops.WeightProductFn).
 __global__ void __launch_bounds__(256) vnp_reduce_slabs_kernel(const float* __restrict__ ws, int nsplit, long long slab, float* __restrict__ C,
-                                                               int M, int N, int ldc, int accumulate)
+                                                               int M, int N, int ldc, int accumulate, const float* __restrict__ resid, int ldr)
 {
     __shared__ double part[4][64];
     const long long total = (long long)M * N;
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) vnp_reduce_slabs_kernel(const float* __re
             const float s = (float)((part[0][ox] + part[1][ox]) + (part[2][ox] + part[3][ox]));
             const int r = (int)(i / N), c = (int)(i % N);
             float* dst = C + (size_t)r * ldc + c;
-            *dst = accumulate ? *dst + s : s;
+            *dst = accumulate ? (resid ? resid[(size_t)r * ldr + c] : *dst) + s : s;
         }
         __syncthreads();
     }
@@ -274,14 +274,15 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
                          const float* bias, int ldbias, int rows_per_group,
                          int accumulate, int nsplit, float* ws,
                          int nbatch, long long bsa, long long bsb, long long bsc,
-                         const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr)
+                         const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr, const float* resid = nullptr, int ldr = 0)
 {
     if (M <= 0 || N <= 0 || K < 0 || !A || !B || !C) return VNP_EINVAL;
+    if (resid && (!accumulate || nbatch > 1 || ldr < N)) return VNP_EINVAL;
     if (bias && rows_per_group <= 0) return VNP_EINVAL;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 1 && !ws) return VNP_EINVAL;
     if (nbatch < 1 || (nbatch > 1 && nsplit > 1)) return VNP_EINVAL;
-    if (nbatch == 1 && K >= 1) {
+    if (nbatch == 1 && K >= 1 && !resid) {
         // outer product: A [M,1] (op_a = 0) x b [N]
         if (K == 1 && op_a == 0 && M <= 2147483647 / 2) {
             const long long bstr = op_b == 0 ? ldb : 1;
@@ -320,7 +321,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             if (rc2) return rc2;
             int blocks = vnp_cdiv(cols, 64);
             hipLaunchKernelGGL(vnp_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)slab, ns, (long long)cols, C,
-                               M, N, ldc, accumulate);
+                               M, N, ldc, accumulate, (const float*)nullptr, 0);
             return vnp_last_error();
             }                                                  // without split-K scratch the MFMA path below handles it
         }
@@ -341,6 +342,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         p.C = ws; p.ldc = N; p.slab = (long long)M * N; p.accumulate = 0;
     } else {
         p.C = C; p.ldc = ldc; p.slab = 0; p.accumulate = accumulate;
+        p.resid = resid; p.ldr = ldr;
     }
     p.nsplit = nsplit; p.nbatch = nbatch;
     p.xcd_split = (nsplit > 1 && nsplit % 8 == 0 && nbatch == 1 && vnp_gemm_get_mode() == 0) ? 1 : 0;
@@ -406,7 +408,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         const long long total = (long long)M * N;
         int blocks = (int)((total + 63) / 64 > 16384 ? 16384 : (total + 63) / 64);
         hipLaunchKernelGGL(vnp_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream,
-                           (const float*)ws, nsplit, (long long)M * N, C, M, N, ldc, accumulate);
+                           (const float*)ws, nsplit, (long long)M * N, C, M, N, ldc, accumulate, resid, ldr);
         rc = vnp_last_error();
     }
     return rc;
@@ -1050,6 +1052,16 @@ extern "C" int vnp_gemm_ex(hipStream_t stream, int op_a, int op_b, int M, int N,
     if ((amax_a == nullptr) != (amax_b == nullptr)) return VNP_EINVAL;
     return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias, ldbias, rows_per_group,
                          accumulate, nsplit, ws, 1, 0, 0, 0, amax_a, amax_b);
+}
+
+// C = op(A) op(B) + R: a residual connection taken in the epilogue (R [M][N], row stride ldr; R may be C itself).  The matrix kernels
+// only (no K = 1 / N = 1 / M = 1 streaming forms: those shapes run on the bounds-checked matrix kernel here).
+extern "C" int vnp_gemm_add(hipStream_t stream, int op_a, int op_b, int M, int N, int K,
+                            const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                            const float* R, int ldr, int nsplit, float* ws)
+{
+    if (!R) return VNP_EINVAL;
+    return vnp_gemm_impl(stream, op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, 0, 1, nsplit, ws, 1, 0, 0, 0, nullptr, nullptr, R, ldr);
 }
 
 // nbatch independent products C_i = op(A_i) op(B_i) with element strides bsa / bsb / bsc (attention: one per (sample, head))

@@ -9,6 +9,8 @@ struct VnpGemmArgs {
     int lda, ldb, ldc, ldbias;
     int rows_per_group;
     int accumulate;                      // C += result instead of C = result
+    const float* resid; int ldr;         // with accumulate: the addend is resid[row][col] (row stride ldr) instead of C's old value — a
+                                         // residual connection taken in the epilogue (one batch; split-K: applied by the slab reduction)
     int tiles_per_split;                 // K-tiles handled by one blockIdx.y
     long long slab;                      // elements between the output slabs of consecutive splits
     int nsplit, nbatch;                  // work items = tiles x nsplit x nbatch, walked persistently
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_kernel(const VnpGemmArgs p)
                         if (!full && col >= p.N) continue;
                         float v = acc[i][j][e];
                         if (brow) v += brow[col];
-                        if (p.accumulate) v += drow[col];
+                        if (p.accumulate) v += (p.resid ? p.resid + (size_t)row * p.ldr : (const float*)drow)[col];
                         drow[col] = v;
                     }
                 }

@@ -473,7 +473,7 @@ __device__ __forceinline__ void vnp_split_epilogue(const VnpGemmArgs& p, vnp_f4 
                     if (!full && col >= p.N) continue;
                     float v = acc[i][j][e];
                     if (brow) v += brow[col];
-                    if (p.accumulate) v += drow[col];
+                    if (p.accumulate) v += (p.resid ? p.resid + (size_t)row * p.ldr : (const float*)drow)[col];
                     if ((VAR & 16) && v != 12345.678f) continue;          // diagnostic build: what the output stores cost
                     // activation-sized outputs are streamed (non-temporal: they do not fit any cache and would only evict the
                     // A / B panels); split-K slabs are re-read at once by the slab reduction and stay cached

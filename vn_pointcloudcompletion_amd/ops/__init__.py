@@ -9,7 +9,7 @@ Modules: ``core`` (GEMM wrapper, reductions, BatchNorm / leaky passes, layout Fu
 ``chamfer``, ``graph``, ``attention``; ``_state`` holds the switches (``SW``) and the test / bench hooks (``hooks(...)``).
 """
 from ._state import HK, POOL_PATH_COUNTS, SW, hooks, switches, trace
-from .attention import (VNAttentionFn, VNAttentionPackedFn, VNLayerNormFn, _attn_dims, _attn_token_major, _from_heads, _heads_fm,
+from .attention import (AddLayerNormFn, VNAttentionFn, VNAttentionPackedFn, VNLayerNormFn, _attn_dims, _attn_token_major, _from_heads, _heads_fm,
                         _heads_tm, _rows_from_fm, _to_heads, gemm_batched)
 from .chamfer import ChamferFn
 from .core import (BN_EPS, BN_MOMENTUM, FromRowsFn, SplitColsFn, ToRowsFn, WeightProductFn, _bn_leaky_backward, _bn_leaky_forward, _dgrad,

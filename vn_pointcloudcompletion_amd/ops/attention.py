@@ -164,7 +164,12 @@ class VNAttentionPackedFn(Function):
         ctx.cfg = (B, N, C, H, float(scale))
         ctx.token_major = _attn_token_major(B, N, C, H)
         if ctx.token_major:
-            qh, kh, vh = (_to_heads(qkv[:, i * C:(i + 1) * C], B, N, H) for i in range(3))
+            if 3 * C <= 5000:                                             # q | k | v -> three head tensors in one launch
+                qkvh = torch.empty((3, B * H, N, (C // H) * 3), device=qkv.device, dtype=torch.float32)
+                call("vnp_rows_to_heads_grouped", ptr(qkv), _ld(qkv), B, N, C, H, 3, ptr(qkvh))
+                qh, kh, vh = qkvh[0], qkvh[1], qkvh[2]
+            else:
+                qh, kh, vh = (_to_heads(qkv[:, i * C:(i + 1) * C], B, N, H) for i in range(3))
             P = gemm_batched(qh, kh)                                      # [B*H, N, N] scores
             call("vnp_softmax_fwd", ptr(P), B * H * N, N, float(scale))
             oh = gemm_batched(P, vh, op_b=1)                               # [B*H, N, Dh]
@@ -183,6 +188,14 @@ class VNAttentionPackedFn(Function):
             qh, kh, vh, P = ctx.saved_tensors
             goh = _to_heads(_rows(go), B, N, H)
             dP = gemm_batched(goh, vh)                                     # [B*H, N, N]
+            if 3 * C <= 5000:                                             # dq | dk | dv land in one [3, B*H, N, Dh] buffer: one permute back
+                dh = torch.empty((3, B * H, N, (C // H) * 3), device=go.device, dtype=torch.float32)
+                dvh = gemm_batched(P, goh, op_a=1, op_b=1, out=dh[2])      # P^T goh
+                call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
+                gemm_batched(dP, kh, op_b=1, out=dh[0])
+                gemm_batched(dP, qh, op_a=1, op_b=1, out=dh[1])
+                call("vnp_heads_to_rows_grouped", ptr(dh), B, N, C, H, 3, ptr(g), _ld(g))
+                return g, None, None, None, None
             dvh = gemm_batched(P, goh, op_a=1, op_b=1)                     # P^T goh
             call("vnp_softmax_bwd", ptr(P), ptr(dP), B * H * N, N, scale)  # dP <- dS
             dqh = gemm_batched(dP, kh, op_b=1)
@@ -225,3 +238,57 @@ class VNLayerNormFn(Function):
         gb = reduce_rows(part, 1, nblk_pad, 2 * C)[0]
         return gx, gb[:C].contiguous(), gb[C:].contiguous()
 
+
+class AddLayerNormFn(Function):
+    """(s, y) with s = x + a1 (+ a2) and y = VNLayerNorm(s) — the head of a transformer block: its input is the previous block's
+    residual stream plus that block's MLP branch plus the position embedding (models/pointr/vn_pointr.py:700, 401-410), it is
+    normalised for the attention AND carried on as the skip connection.  One pass forward (vnp_vn_add_layernorm_fwd) instead of two adds
+    and a LayerNorm; backward, the gradient of the skip connection (the cotangent of s) is added inside the LayerNorm's backward pass
+    (vnp_vn_layernorm_bwd_add) instead of by autograd's accumulation, and goes to x, a1 and a2 unchanged.  ``a1 = a2 = None``: s IS x
+    (returned as it came): only the backward fusion."""
+
+    @staticmethod
+    def forward(ctx, x, a1, a2, gamma, beta):
+        x = _rows(x)
+        R, C = x.shape
+        P = R // 3
+        out = torch.empty((R, C), device=x.device, dtype=torch.float32)
+        stats = torch.empty((P, 2), device=x.device, dtype=torch.float32)
+        if a1 is None and a2 is not None:
+            a1, a2 = a2, None
+        if a1 is None:
+            s = x
+            call("vnp_vn_layernorm_fwd", ptr(x), _ld(x), P, C, ptr(gamma), ptr(beta), ptr(out), C, ptr(stats))
+        else:
+            a1 = _rows(a1)
+            a2 = _rows(a2) if a2 is not None else None
+            if a1.shape != x.shape or (a2 is not None and a2.shape != x.shape):
+                raise _lib.VnpError("AddLayerNormFn: addends must have the shape of x")
+            s = torch.empty((R, C), device=x.device, dtype=torch.float32)
+            call("vnp_vn_add_layernorm_fwd", ptr(x), _ld(x), ptr(a1), _ld(a1), ptr(a2), _ld(a2) if a2 is not None else 0, P, C,
+                 ptr(gamma), ptr(beta), ptr(s), C, ptr(out), C, ptr(stats))
+        ctx.save_for_backward(s, gamma, beta, stats)
+        return s, out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gs, go):
+        s, gamma, beta, stats = ctx.saved_tensors
+        R, C = s.shape
+        P = R // 3
+        if go is None:                                   # the normalised output was not used: only the skip connection carries a gradient
+            return gs, gs, gs, None, None
+        go = _rows(go)
+        nblk = (P + 3) // 4
+        nblk_pad = (nblk + 255) // 256 * 256 if nblk > 1024 else nblk
+        gx = torch.empty((R, C), device=s.device, dtype=torch.float32)
+        part = (torch.zeros if nblk_pad != nblk else torch.empty)((nblk_pad, 2 * C), device=s.device, dtype=torch.float32)
+        if gs is None:
+            call("vnp_vn_layernorm_bwd", ptr(go), _ld(go), ptr(s), _ld(s), P, C, ptr(gamma), ptr(beta), ptr(stats), ptr(gx), C, ptr(part))
+        else:
+            gs = _rows(gs)
+            call("vnp_vn_layernorm_bwd_add", ptr(go), _ld(go), ptr(s), _ld(s), P, C, ptr(gamma), ptr(beta), ptr(stats), ptr(gs), _ld(gs),
+                 ptr(gx), C, ptr(part))
+        gb = reduce_rows(part, 1, nblk_pad, 2 * C)[0]
+        need = ctx.needs_input_grad
+        return (gx if need[0] else None), (gx if need[1] else None), (gx if need[2] else None), gb[:C], gb[C:]

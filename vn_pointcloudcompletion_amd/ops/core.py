@@ -78,9 +78,10 @@ def _fp16x2_shape(op_a, M, N, K, A, B, nsplit):
             and _lib.get_gemm_mode() == "split" and _ld(A) % 4 == 0 and _ld(B) % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
 
 
-def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumulate=False, nsplit=None, amax_a=None, amax_b=None):
-    """C = op(A) op(B) (+ per-sample bias).  See vnp_gemm / vnp_gemm_ex in include/vnpcc.h.  ``amax_a`` / ``amax_b``: the operands'
-    ``amax_word`` when the caller already holds it (an operand used by two GEMMs)."""
+def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumulate=False, nsplit=None, amax_a=None, amax_b=None, resid=None):
+    """C = op(A) op(B) (+ per-sample bias | + resid).  See vnp_gemm / vnp_gemm_ex / vnp_gemm_add in include/vnpcc.h.  ``amax_a`` /
+    ``amax_b``: the operands' ``amax_word`` when the caller already holds it (an operand used by two GEMMs).  ``resid`` [M, N]: a
+    residual connection added in the epilogue."""
     A, B = _rows(A), _rows(B)
     M, K = (A.shape[0], A.shape[1]) if op_a == 0 else (A.shape[1], A.shape[0])
     N, Kb = (B.shape[0], B.shape[1]) if op_b == 0 else (B.shape[1], B.shape[0])
@@ -92,6 +93,10 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
         raise _lib.VnpError("gemm: bad output tensor")
     if bias is not None:
         bias = _rows(bias)
+    if resid is not None:
+        resid = _rows(resid)
+        if bias is not None or accumulate or resid.shape != (M, N):
+            raise _lib.VnpError("gemm: resid needs an [M, N] addend and excludes bias / accumulate")
     if nsplit is None:
         nsplit = 1
         if bias is None:
@@ -107,7 +112,7 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
     ws = None
     if nsplit > 1:
         ws = torch.empty((nsplit, M, N), device=A.device, dtype=torch.float32)
-    h2 = _fp16x2_shape(op_a, M, N, K, A, B, nsplit)
+    h2 = resid is None and _fp16x2_shape(op_a, M, N, K, A, B, nsplit)
     if h2:
         amax_a = amax_a if amax_a is not None else amax_word(A)
         amax_b = amax_b if amax_b is not None else amax_word(B)
@@ -117,6 +122,8 @@ def gemm(A, B, *, op_a=0, op_b=0, out=None, bias=None, rows_per_group=0, accumul
         trace("gemm_fp16x2")
         call("vnp_gemm_ex", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
              ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws), ptr(amax_a), ptr(amax_b))
+    elif resid is not None:
+        call("vnp_gemm_add", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out), ptr(resid), _ld(resid), nsplit, ptr(ws))
     else:
         call("vnp_gemm", op_a, op_b, M, N, K, ptr(A), _ld(A), ptr(B), _ld(B), ptr(out), _ld(out),
              ptr(bias), _ld(bias) if bias is not None else 0, rows_per_group, 1 if accumulate else 0, nsplit, ptr(ws))

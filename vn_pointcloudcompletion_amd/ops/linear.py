@@ -14,12 +14,14 @@ from .core import (BN_EPS, BN_MOMENTUM, _bn_leaky_backward, _bn_leaky_forward, _
 
 
 class VNLinearFn(Function):
-    """y = x W^T (+ per-sample bias)  —  VNLinear, models/vn_layers.py:12-22."""
+    """y = x W^T (+ per-sample bias | + residual)  —  VNLinear, models/vn_layers.py:12-22.  ``residual`` [R, Cout]: the tensor the
+    layer's output is added to right after it (a transformer block's skip connection, models/pointr/vn_pointr.py:401-410), added in the
+    GEMM's epilogue; its gradient is the output gradient itself."""
 
     @staticmethod
-    def forward(ctx, x, W, bias=None, rows_per_group=0):
+    def forward(ctx, x, W, bias=None, rows_per_group=0, residual=None):
         x = _rows(x)
-        y = gemm(x, W, bias=bias, rows_per_group=rows_per_group)
+        y = gemm(x, W, bias=bias, rows_per_group=rows_per_group, resid=residual)
         ctx.save_for_backward(x, W)
         ctx.rpg = rows_per_group
         ctx.has_bias = bias is not None
@@ -35,7 +37,7 @@ class VNLinearFn(Function):
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _per_sample_colsum(gy.contiguous(), ctx.rpg)
-        return gx, gW, gb, None
+        return gx, gW, gb, None, (gy if len(ctx.needs_input_grad) > 4 and ctx.needs_input_grad[4] else None)
 
 
 class VNLinearLeakyFn(Function):

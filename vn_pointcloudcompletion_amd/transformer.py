@@ -48,12 +48,13 @@ class Attention(nn.Module):
         if attn_drop or proj_drop:
             raise NotImplementedError("dropout > 0 is not used on the PCNNet paths (rates are 0 in models/pcn.py:408-412)")
 
-    def forward_rows(self, rows, B, N):
-        # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result
+    def forward_rows(self, rows, B, N, residual=None):
+        # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result;
+        # ``residual``: the block's skip connection, added in the output projection's epilogue
         Wqkv = torch.cat([self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight], dim=0)
         qkv = ops.VNLinearFn.apply(rows, Wqkv, None, 0)
         x = ops.VNAttentionPackedFn.apply(qkv, B, N, self.num_heads, self.scale)
-        return self.proj_vn.forward_rows(x)
+        return self.proj_vn.forward_rows(x, residual=residual)
 
     def forward(self, vn_x):
         from .vn_layers import from_rows, to_rows
@@ -78,17 +79,24 @@ class VN_Block(nn.Module):
         self.conv4 = VNLinearLeakyReLU(dim * 2, dim, dim=4)
         self.pool1 = mean_pool
 
-    def forward_rows(self, vn_x, B, N, knn_index=None, k=8):
-        norm_x = self.norm1.forward_rows(vn_x)
-        x_1 = self.attn.forward_rows(norm_x, B, N)
-        if knn_index is not None:
+    def forward_rows_split(self, vn_x, B, N, knn_index=None, k=8, carry=None):
+        """The block on the input vn_x (+ carry) as the pair (skip stream, MLP branch) whose SUM is its output (see the VN-PoinTr block,
+        vn_pointr.VN_Block.forward_rows_split): the adds ride in the LayerNorm passes and the GEMM epilogues."""
+        s, norm_x = self.norm1.forward_rows_carry(vn_x, carry)
+        if knn_index is None:
+            vn_x = self.attn.forward_rows(norm_x, B, N, residual=s)
+        else:
+            x_1 = self.attn.forward_rows(norm_x, B, N)
             f = graph_feature_rows(norm_x, knn_index, B, N, k)              # [(B*N*k)*3, 2C]
             f = self.conv1.forward_rows(f)
             f = ops.VNMeanPoolFn.apply(f, B * N, k)
-            x_1 = self.conv2.forward_rows(torch.cat([x_1, f], dim=1))
-        vn_x = vn_x + x_1
-        x_2 = self.conv4.forward_rows(self.conv3.forward_rows(self.norm2.forward_rows(vn_x)))
-        return vn_x + x_2
+            vn_x = self.conv2.forward_rows(torch.cat([x_1, f], dim=1), residual=s)
+        vn_x, n2 = self.norm2.forward_rows_carry(vn_x)
+        return vn_x, self.conv4.forward_rows(self.conv3.forward_rows(n2))
+
+    def forward_rows(self, vn_x, B, N, knn_index=None, k=8):
+        a, b = self.forward_rows_split(vn_x, B, N, knn_index, k)
+        return a + b
 
     def forward(self, x, knn_index=None):
         B, N, _ = x.shape

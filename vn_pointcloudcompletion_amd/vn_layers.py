@@ -45,8 +45,9 @@ class VNLinear(nn.Module):
         super().__init__()
         self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
 
-    def forward_rows(self, rows, bias=None, rows_per_group=0):
-        return ops.VNLinearFn.apply(rows, self.map_to_feat.weight, bias, rows_per_group)
+    def forward_rows(self, rows, bias=None, rows_per_group=0, residual=None):
+        """``residual``: a tensor of the output's shape added to it in the GEMM's epilogue (a block's skip connection)."""
+        return ops.VNLinearFn.apply(rows, self.map_to_feat.weight, bias, rows_per_group, residual)
 
     def forward(self, x):
         rows, meta = to_rows(x)
@@ -143,6 +144,11 @@ class VNLayerNorm(nn.Module):
 
     def forward_rows(self, rows):
         return ops.VNLayerNormFn.apply(rows, self.layer_norm.weight, self.layer_norm.bias)
+
+    def forward_rows_carry(self, rows, a1=None, a2=None):
+        """(s, LayerNorm(s)) with s = rows + a1 + a2: for a tensor that is normalised AND carried on as a skip connection — feed the
+        RETURNED s to the skip connection (ops.AddLayerNormFn: the adds ride in the LayerNorm pass, forward and backward)."""
+        return ops.AddLayerNormFn.apply(rows, a1, a2, self.layer_norm.weight, self.layer_norm.bias)
 
     def forward(self, x):
         rows, meta = to_rows(x)

@@ -81,11 +81,12 @@ class Attention(nn.Module):
         self.proj_vnv = VNLinear(128, 384)
         self.proj_vn = VNLinear(384, 128)
 
-    def forward_rows(self, rows, B, N):
-        # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result
+    def forward_rows(self, rows, B, N, residual=None):
+        # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result;
+        # ``residual``: the block's skip connection, added in the output projection's epilogue
         Wqkv = torch.cat([self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight], dim=0)
         qkv = ops.VNLinearFn.apply(rows, Wqkv, None, 0)
-        return self.proj_vn.forward_rows(ops.VNAttentionPackedFn.apply(qkv, B, N, self.num_heads, self.scale))
+        return self.proj_vn.forward_rows(ops.VNAttentionPackedFn.apply(qkv, B, N, self.num_heads, self.scale), residual=residual)
 
 
 class CrossAttention(nn.Module):
@@ -122,15 +123,23 @@ class VN_Block(nn.Module):
         self.conv4 = VNLinearLeakyReLU(256, 128, dim=4)
         self.pool1 = mean_pool
 
-    def forward_rows(self, vn_x, B, N, nbr=None, k=8):
-        norm_x = self.norm1.forward_rows(vn_x)
-        x_1 = self.attn.forward_rows(norm_x, B, N)
-        if nbr is not None:
+    def forward_rows_split(self, vn_x, B, N, nbr=None, k=8, pos=None, carry=None):
+        """The block on the input vn_x (+ pos + carry), returned as the pair (skip stream, MLP branch) whose SUM is the block's output:
+        the caller hands the pair to the next block as (vn_x, carry), whose first LayerNorm pass adds it up together with the position
+        embedding (ops.AddLayerNormFn); both skip connections are added in the epilogue of the VNLinear that ends their branch."""
+        s, norm_x = self.norm1.forward_rows_carry(vn_x, pos, carry)
+        if nbr is None:
+            vn_x = self.attn.forward_rows(norm_x, B, N, residual=s)
+        else:
+            x_1 = self.attn.forward_rows(norm_x, B, N)
             knn_f = edge_conv_rows(self.conv1, norm_x, nbr, k)                      # graph feature + conv1 + mean pool
-            x_1 = self.conv2.forward_rows(torch.cat([x_1, knn_f], dim=1))
-        vn_x = vn_x + x_1
-        x_2 = self.conv4.forward_rows(self.conv3.forward_rows(self.norm2.forward_rows(vn_x)))
-        return vn_x + x_2
+            vn_x = self.conv2.forward_rows(torch.cat([x_1, knn_f], dim=1), residual=s)
+        vn_x, n2 = self.norm2.forward_rows_carry(vn_x)
+        return vn_x, self.conv4.forward_rows(self.conv3.forward_rows(n2))
+
+    def forward_rows(self, vn_x, B, N, nbr=None, k=8):
+        a, b = self.forward_rows_split(vn_x, B, N, nbr, k)
+        return a + b
 
 
 class VN_DecoderBlock(nn.Module):
@@ -241,8 +250,11 @@ class VN_PCTransformer(nn.Module):
         nc = coor.shape[1]
         x, pos = self.embed_rows(inpc, coor, f)
         nbr = knn_graph(coor, 8)                                                # get_knn_index(coor), k = 8 (vn_pointr.py:10,17-29)
-        for i, blk in enumerate(self.encoder):
-            x = blk.forward_rows(x + pos, B, nc, nbr if i < self.knn_layer else None)
+        carry = None
+        for i, blk in enumerate(self.encoder):                                  # x = blk(x + pos), vn_pointr.py:700-702
+            x, carry = blk.forward_rows_split(x, B, nc, nbr if i < self.knn_layer else None, pos=pos, carry=carry)
+        if carry is not None:
+            x = x + carry
         coarse, global_feature = self.head_rows(x, B, nc)
         inp_sparse = plan.level(2)[1]
         coarse = torch.cat([coarse, inp_sparse], dim=1).contiguous()
