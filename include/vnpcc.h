@@ -50,6 +50,13 @@ long long vnp_chamfer_pruned_ws_bytes(int B, int n, int m);
 long long vnp_chamfer_pruned_ws_wave_counts(int B, int n, int m);
 int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float* xyz1, int m, const float* xyz2,
                            float* dist1, int* idx1, float* dist2, int* idx2, void* ws);
+/* cd_loss_L1 (metrics/loss.py:20-31) on the outputs of vnp_chamfer_fwd: out[3] = {(m1 + m2) / 2, m1, m2} with m = mean sqrt(dist) over ALL
+ * n1 = B*n / n2 = B*m elements (double sums in a fixed order; part: 512 doubles of scratch), and its gradient with respect to the two
+ * distance arrays, gdist = ((g / 2) / n) / (2 sqrt(dist)) for the device scalar g — the input vnp_chamfer_bwd takes.  Replaces the
+ * sqrt / mean / add / div chain of ATen kernels (4 per array forward, 5 backward) by 2 + 1 launches. */
+int vnp_cd_l1_loss(hipStream_t st, const float* dist1, long long n1, const float* dist2, long long n2, double* part, float* out);
+int vnp_cd_l1_grad(hipStream_t st, const float* g, const float* dist1, long long n1, const float* dist2, long long n2,
+                   float* gdist1, float* gdist2);
 /* One side of the density-aware Chamfer distance, calc_dcd (/root/reference/metrics/loss.py:77-118; the reference loops over the batch
  * with torch.bincount): hits [B, T] = histogram of the arg-min indices idx [B, N] (scratch, zeroed by the call; integer atomics, so the
  * result does not depend on their order), loss [B] = mean_i (1 - exp(-alpha dist_i) * frac / (hits[idx_i]^lambda + 1e-6)) in the

@@ -269,3 +269,30 @@ def test_pruned_is_the_path_dense_clouds_take(lib_built):
     d1, d2, i1, i2 = _fwd(a.clone().requires_grad_(True), b)
     brute, _ = _both_paths(a, b)
     _assert_same_bits(brute, (d1.detach(), d2.detach(), i1, i2))
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 100, 200), (3, 1024, 4096), (2, 4096, 4096), (1, 5, 3)])
+def test_fused_chamfer_l1_loss_equals_the_operator_followed_by_the_formula(lib_built, B, n, m):
+    """loss.cd_loss_L1 as ONE Function (ops.ChamferL1LossFn: search, vnp_cd_l1_loss, and backward vnp_cd_l1_grad -> vnp_chamfer_bwd) against
+    the reference's formula (metrics/loss.py:28-31) written with ATen operators on ChamferDistance's outputs: the loss within 2e-7 relative
+    (double sums here, torch's float tree there), the gradients of both clouds bit for bit (the distance gradients are the same three
+    IEEE operations in the same order), with a cotangent other than 1, brute-force and pruned searches."""
+    from vn_pointcloudcompletion_amd import loss as L
+    g = torch.Generator().manual_seed(n + m)
+    a0, b0 = (torch.rand(B, n, 3, generator=g) - 0.5).cuda(), (torch.rand(B, m, 3, generator=g) - 0.5).cuda()
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    fused = L.cd_loss_L1(a, b)
+    (fused * 0.7).backward()
+    a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    d1, d2 = L.CD(a2, b2)
+    plain = (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2.0
+    (plain * 0.7).backward()
+    assert fused.dim() == 0 and abs(fused.item() - plain.item()) <= 2e-7 * abs(plain.item())
+    assert torch.equal(a.grad, a2.grad) and torch.equal(b.grad, b2.grad)
+    # only one of the operator's two distance outputs used: the other's gradient arrives as None (no zero-filled stand-ins any more)
+    a3, b3 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    L.CD(a3, b3)[0].sum().backward()
+    a4, b4 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    d1, d2 = L.CD(a4, b4)
+    (d1.sum() + 0.0 * d2.sum()).backward()
+    assert torch.equal(a3.grad, a4.grad) and torch.equal(b3.grad, b4.grad)

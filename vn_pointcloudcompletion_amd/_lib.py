@@ -75,6 +75,8 @@ _SIGNATURES = {
     "vnp_chamfer_bwd": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_chamfer_fwd_pruned": [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "vnp_dcd_side": [_i, _i, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp],
+    "vnp_cd_l1_loss": [_vp, _ll, _vp, _ll, _vp, _vp],
+    "vnp_cd_l1_grad": [_vp, _vp, _ll, _vp, _ll, _vp, _vp],
     "vnp_emd_approxmatch": [_i, _i, _i, _vp, _vp, _vp, _vp],
     "vnp_emd_matchcost": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "vnp_emd_matchcost_bwd": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -685,6 +685,77 @@ __global__ void __launch_bounds__(1024) vnp_dcd_side_kernel(const float* __restr
     if (tid == 0) loss[b] = (float)(red[0] / (double)N);
 }
 
+// ---- cd_loss_L1 (metrics/loss.py:20-31): (mean sqrt(dist1) + mean sqrt(dist2)) / 2 over ALL B*n / B*m elements, and its gradient with
+// respect to the two distance arrays, as two launches + one instead of four ATen kernels per array forward and five backward.
+// Sums in double in a fixed order (block partials, then one block over the partials): run-to-run identical.
+#define VNP_CDL_BLOCKS 256
+__global__ void __launch_bounds__(256) vnp_cd_l1_partial_kernel(const float* __restrict__ d1, long long n1, const float* __restrict__ d2, long long n2,
+                                                               double* __restrict__ part)
+{
+    __shared__ double red[2][256];
+    double s1 = 0.0, s2 = 0.0;
+    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = first; i < n1; i += stride) s1 += (double)sqrtf(d1[i]);
+    for (long long i = first; i < n2; i += stride) s2 += (double)sqrtf(d2[i]);
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x] = red[0][0]; part[VNP_CDL_BLOCKS + blockIdx.x] = red[1][0]; }
+}
+
+__global__ void __launch_bounds__(256) vnp_cd_l1_final_kernel(const double* __restrict__ part, int nblk, long long n1, long long n2, float* __restrict__ out)
+{
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = (int)threadIdx.x < nblk ? part[threadIdx.x] : 0.0;
+    red[1][threadIdx.x] = (int)threadIdx.x < nblk ? part[VNP_CDL_BLOCKS + threadIdx.x] : 0.0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float m1 = (float)(red[0][0] / (double)n1), m2 = (float)(red[1][0] / (double)n2);
+        out[0] = (m1 + m2) / 2.0f; out[1] = m1; out[2] = m2;
+    }
+}
+
+// gd[i] = ((g / 2) / n) / (2 sqrt(d[i])): the chain of autograd's own formulas for (mean(sqrt(d1)) + mean(sqrt(d2))) / 2 in the same
+// order (division by 2, mean, sqrt), so the same bits; d = 0 gives Inf here and NaN after the Chamfer backward, as in the reference
+__global__ void __launch_bounds__(256) vnp_cd_l1_grad_kernel(const float* __restrict__ g, const float* __restrict__ d1, long long n1,
+                                                            const float* __restrict__ d2, long long n2, float* __restrict__ gd1, float* __restrict__ gd2)
+{
+    const float gh = g[0] / 2.0f;
+    const float g1 = gh / (float)n1, g2 = gh / (float)n2;
+    const long long stride = (long long)gridDim.x * 256, first = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = first; i < n1; i += stride) gd1[i] = g1 / (2.0f * sqrtf(d1[i]));
+    for (long long i = first; i < n2; i += stride) gd2[i] = g2 / (2.0f * sqrtf(d2[i]));
+}
+
+// out[3] = {loss, mean sqrt(dist1), mean sqrt(dist2)}; part: 2 * 256 doubles of scratch
+extern "C" int vnp_cd_l1_loss(hipStream_t st, const float* dist1, long long n1, const float* dist2, long long n2, double* part, float* out)
+{
+    if (!dist1 || !dist2 || !part || !out || n1 <= 0 || n2 <= 0) return VNP_EINVAL;
+    const long long nmax = n1 > n2 ? n1 : n2;
+    const int nblk = (int)(vnp_cdiv(nmax, 1024) < VNP_CDL_BLOCKS ? vnp_cdiv(nmax, 1024) : VNP_CDL_BLOCKS);
+    hipLaunchKernelGGL(vnp_cd_l1_partial_kernel, dim3(nblk), dim3(256), 0, st, dist1, n1, dist2, n2, part);
+    hipLaunchKernelGGL(vnp_cd_l1_final_kernel, dim3(1), dim3(256), 0, st, (const double*)part, nblk, n1, n2, out);
+    return vnp_last_error();
+}
+
+// g: device scalar, the cotangent of the loss
+extern "C" int vnp_cd_l1_grad(hipStream_t st, const float* g, const float* dist1, long long n1, const float* dist2, long long n2,
+                              float* gdist1, float* gdist2)
+{
+    if (!g || !dist1 || !dist2 || !gdist1 || !gdist2 || n1 <= 0 || n2 <= 0) return VNP_EINVAL;
+    const long long nmax = n1 > n2 ? n1 : n2;
+    const int nblk = (int)(vnp_cdiv(nmax, 1024) < 1024 ? vnp_cdiv(nmax, 1024) : 1024);
+    hipLaunchKernelGGL(vnp_cd_l1_grad_kernel, dim3(nblk), dim3(256), 0, st, g, dist1, n1, dist2, n2, gdist1, gdist2);
+    return vnp_last_error();
+}
+
 // One side of calc_dcd.  dist / idx [B, N]: one-sided squared distances and arg-min indices (into T targets) from vnp_chamfer_fwd;
 // hits [B, T] ints: scratch, zeroed here; loss [B]; gfac [B, N] or NULL (no gradient wanted).
 extern "C" int vnp_dcd_side(hipStream_t st, int B, int N, int T, const float* dist, const int* idx, float alpha, float lambda, float frac,

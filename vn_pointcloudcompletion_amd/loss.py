@@ -10,8 +10,8 @@ CD = ChamferDistance()
 
 def cd_loss_L1(pcs1, pcs2):
     """metrics/loss.py:20-31: (mean sqrt(dist1) + mean sqrt(dist2)) / 2 over ALL B*n elements."""
-    dist1, dist2 = CD(pcs1, pcs2)
-    return (torch.mean(torch.sqrt(dist1)) + torch.mean(torch.sqrt(dist2))) / 2.0
+    from .ops import ChamferL1LossFn
+    return ChamferL1LossFn.apply(pcs1, pcs2)            # the search + the sqrt / mean / add / div chain and its backward in one Function
 
 
 def cd_loss_L2(pcs1, pcs2):

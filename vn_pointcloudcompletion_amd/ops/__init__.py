@@ -11,7 +11,7 @@ Modules: ``core`` (GEMM wrapper, reductions, BatchNorm / leaky passes, layout Fu
 from ._state import HK, POOL_PATH_COUNTS, SW, hooks, switches, trace
 from .attention import (AddLayerNormFn, VNAttentionFn, VNAttentionPackedFn, VNLayerNormFn, _attn_dims, _attn_token_major, _from_heads, _heads_fm,
                         _heads_tm, _rows_from_fm, _to_heads, gemm_batched)
-from .chamfer import ChamferFn
+from .chamfer import ChamferFn, ChamferL1LossFn
 from .core import (BN_EPS, BN_MOMENTUM, FromRowsFn, SplitColsFn, ToRowsFn, WeightProductFn, _bn_leaky_backward, _bn_leaky_forward, _dgrad,
                    _ld, _rows, amax_word, drop_amax, gemm,
                    gemm_pd_stats, reduce_pairs, reduce_rows, set_amax, split_cols)

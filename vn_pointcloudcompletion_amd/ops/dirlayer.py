@@ -96,6 +96,7 @@ class DirLinearMaxPoolFn(Function):
         ctx.save_for_backward(h, u, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for the index output
         return out, idx
 
     @staticmethod

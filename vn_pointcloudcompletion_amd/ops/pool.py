@@ -66,6 +66,7 @@ class VNMaxPoolFn(Function):
         ctx.save_for_backward(idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for the index output
         return out, idx
 
     @staticmethod
@@ -136,6 +137,7 @@ class VNMaxPoolTapFn(Function):
         ctx.save_for_backward(idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for the index output
         return x, out, idx                      # x as-is: autograd hands back an alias whose gradient flows through this node
 
     @staticmethod
@@ -143,6 +145,8 @@ class VNMaxPoolTapFn(Function):
     def backward(ctx, gx, gout, _gidx):
         (idx,) = ctx.saved_tensors
         G, gs, C = ctx.cfg
+        if gout is None:                                  # the pooled output was not used: only the pass-through carries a gradient
+            return gx, None, None, None, None, None
         gout = _rows(gout)
         if gx is None or gx.dim() != 2 or gx.stride(1) != 1 or gx.shape != (G * gs * 3, C) or not _grad_is_private(gx):
             dense = torch.empty((G * gs * 3, C), device=gout.device, dtype=torch.float32)
@@ -186,6 +190,7 @@ class VNLinearPoolTapFn(Function):
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for the index output
         return y, out, idx
 
     @staticmethod
@@ -273,6 +278,7 @@ class VNLinearMaxPoolFn(Function):
         ctx.save_for_backward(x, W, idx)
         ctx.cfg = (G, gs, C)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)                  # no zero-filled gradient for the index output
         return out, idx
 
     @staticmethod

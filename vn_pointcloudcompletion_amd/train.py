@@ -78,6 +78,18 @@ def make_scheduler(optimizer, start_epoch=0):
     return scheduler
 
 
+_ONES = {}
+
+
+def _one_like(loss):
+    """The cotangent 1.0 of a 0-dim loss, made once per (device, dtype) instead of a ones_like launch per step."""
+    key = (loss.device, loss.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return t
+
+
 def train_step(config, model, optimizer, p, c, trot=None, loss_weight=1.0):
     """One iteration of the hot loop (train.py:140-173): zero_grad, forward, losses, backward, gradient all-reduce
     (world > 1), Adam.  Returns the three loss tensors (on device, no host sync).  ``loss_weight`` scales the gradient of an
@@ -85,7 +97,7 @@ def train_step(config, model, optimizer, p, c, trot=None, loss_weight=1.0):
     optimizer.zero_grad()
     coarse_pred, dense_pred = model(p, trot)
     loss, loss1, loss2 = compute_losses(config, coarse_pred, dense_pred, c)
-    (loss if loss_weight == 1.0 else loss * loss_weight).backward()
+    (loss if loss_weight == 1.0 else loss * loss_weight).backward(gradient=_one_like(loss))
     D.allreduce_gradients(optimizer)
     optimizer.step()
     return loss.detach(), loss1.detach(), loss2.detach()
