@@ -57,6 +57,8 @@ class Census(TorchDispatchMode):
                     where = f"{fn.split('vn_pointcloudcompletion_amd/')[-1]}:{f.f_lineno} {f.f_code.co_name}"
                     break
                 f = f.f_back
+            if where == "(autograd engine)":      # say what is being accumulated / materialised
+                where += " " + " ".join(str(tuple(a.shape)) for a in args if isinstance(a, torch.Tensor))
             sites[(name, where)] += 1
         return func(*args, **(kwargs or {}))
 

@@ -828,3 +828,36 @@ def test_split_arithmetic_edge_cases_through_a_layer(lib_built):
             assert not torch.isfinite(yf[hit]).all()                   # (3.4e38 is a finite fp32: the fp32-input mode may stay finite there)
         assert torch.isfinite(ys[~hit]).all() and torch.isfinite(yf[~hit]).all()
         assert relerr(ys[~hit], yf[~hit]) < 2e-5
+
+
+def test_pack_pd_cols_and_leaky_dir_equal_their_unfused_forms(lib_built):
+    """ops.PackPdColsFn (column ranges of a layer's two weights as [2C, n] matrices / adjacent halves) against slicing and concatenating
+    with autograd, values and both weight gradients; ops.cat_rows returns a VIEW for the halves; and ops.VNLeakyDirFn (direction map +
+    leaky projection, the two gradient paths of x joined in the epilogue of a product) against VNLinearFn -> VNLeakyFn: the same bits."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C, K = 24, 2050
+    Wf0, Wd0 = torch.randn(C, K, generator=g).cuda(), torch.randn(C, K, generator=g).cuda()
+    cots = [torch.randn(2 * C, 2048, generator=g).cuda(), torch.randn(2 * C, 1, generator=g).cuda(), torch.randn(C, 1, generator=g).cuda(),
+            torch.randn(C, 1, generator=g).cuda()]
+    Wf, Wd = Wf0.clone().requires_grad_(True), Wd0.clone().requires_grad_(True)
+    Wg, ws, hf, hd = ops.pack_pd_cols(Wf, Wd, (2048, 1, 1), (False, False, True))
+    assert ops.cat_rows(hf, hd).data_ptr() == hf.data_ptr() and ops.cat_rows(hf, hd).shape == (2 * C, 1)
+    torch.autograd.backward([Wg, ws, hf, hd], cots)
+    Wf2, Wd2 = Wf0.clone().requires_grad_(True), Wd0.clone().requires_grad_(True)
+    ref = [torch.cat([Wf2[:, :2048], Wd2[:, :2048]]), torch.cat([Wf2[:, 2048:2049], Wd2[:, 2048:2049]]), Wf2[:, 2049:], Wd2[:, 2049:]]
+    torch.autograd.backward(ref, cots)
+    for a, b in zip((Wg, ws, hf, hd), ref):
+        assert torch.equal(a, b)
+    assert torch.equal(Wf.grad, Wf2.grad) and torch.equal(Wd.grad, Wd2.grad)
+
+    for R, Cc in ((96, 256), (3 * 700, 64)):
+        x0, W0, go = torch.randn(R, Cc, generator=g).cuda(), torch.randn(Cc, Cc, generator=g).cuda() * 0.1, torch.randn(R, Cc, generator=g).cuda()
+        x, W = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+        y = ops.VNLeakyDirFn.apply(x, W, 0.2)
+        y.backward(go)
+        x2, W2 = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+        y2 = ops.VNLeakyFn.apply(x2, ops.VNLinearFn.apply(x2, W2, None, 0), 0.2)
+        y2.backward(go)
+        assert torch.equal(y, y2) and torch.equal(W.grad, W2.grad)
+        assert torch.equal(x.grad, x2.grad)

@@ -373,13 +373,66 @@ def split_cols(W, *sizes):
     return SplitColsFn.apply(W, *sizes)
 
 
+def cat_rows(Wf, Wd):
+    """[Wf; Wd] — as a VIEW when the two already sit one after the other in one buffer (the halves PackPdColsFn returns), else one
+    concatenation.  For use inside a Function's forward (no autograd through it)."""
+    if (Wf.dim() == 2 and Wd.dim() == 2 and Wf.shape[1] == Wd.shape[1] and Wf.is_contiguous() and Wd.is_contiguous()
+            and Wf.dtype == Wd.dtype and Wf.device == Wd.device and Wf.untyped_storage().data_ptr() == Wd.untyped_storage().data_ptr()
+            and Wd.storage_offset() == Wf.storage_offset() + Wf.numel()):
+        return torch.as_strided(Wf, (Wf.shape[0] + Wd.shape[0], Wf.shape[1]), (Wf.shape[1], 1), Wf.storage_offset())
+    return torch.cat([Wf, Wd], dim=0)
+
+
+class PackPdColsFn(Function):
+    """Column ranges of a layer's two weights Wf, Wd [C, K], each as ONE [2C, n] matrix [Wf[:, a:b]; Wd[:, a:b]] (rows: feat then dir):
+    a VNLinearLeakyReLU whose input is cat(per-sample channels, per-point channels) (models/pcn.py:172, 375-385) applies the first to the
+    per-sample features in ONE product (the layer's per-sample bias [G*3, 2C], columns feat | dir) and the second to the points.
+    ``halves[i]``: return range i as its two halves [C, n] (adjacent views of one buffer: cat_rows joins them again without a copy) for
+    the Functions that take Wf and Wd separately.  One concatenation per range forward, two backward — against a copy per misaligned
+    slice, two products instead of one, an addition of their input gradients and autograd's zero-padded slice gradients."""
+
+    @staticmethod
+    def forward(ctx, Wf, Wd, sizes, halves):
+        if Wf.dim() != 2 or Wf.shape != Wd.shape or sum(sizes) != Wf.shape[1] or len(halves) != len(sizes):
+            raise _lib.VnpError(f"pack_pd_cols: sizes {sizes} do not cover {tuple(Wf.shape)} / {tuple(Wd.shape)}")
+        C = Wf.shape[0]
+        ctx.cfg = (C, tuple(sizes), tuple(bool(h) for h in halves))
+        outs, a = [], 0
+        for n, hv in zip(sizes, halves):
+            m = torch.cat([Wf[:, a:a + n], Wd[:, a:a + n]], dim=0)
+            outs += [m[:C], m[C:]] if hv else [m]
+            a += n
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        C, sizes, halves = ctx.cfg
+        ref = next(g for g in gs if g is not None)
+        pf, pd, i = [], [], 0
+        for n, hv in zip(sizes, halves):
+            if hv:
+                gf, gd = gs[i], gs[i + 1]
+                i += 2
+            else:
+                gf, gd = (gs[i][:C], gs[i][C:]) if gs[i] is not None else (None, None)
+                i += 1
+            pf.append(gf if gf is not None else ref.new_zeros((C, n)))
+            pd.append(gd if gd is not None else ref.new_zeros((C, n)))
+        return torch.cat(pf, dim=1), torch.cat(pd, dim=1), None, None
+
+
+def pack_pd_cols(Wf, Wd, sizes, halves=None):
+    return PackPdColsFn.apply(Wf, Wd, tuple(sizes), tuple(halves) if halves is not None else (False,) * len(sizes))
+
+
 class WeightProductFn(Function):
     """(Wf W1, Wd W1) for weights Wf, Wd [C, K1] and W1 [K1, K0]: the layer that follows a VNLinear, folded onto that VNLinear's input
     channels (SW.ENC_LINEAR_REASSOCIATE).  One GEMM over [Wf; Wd] forward, two backward; all of them a few hundred MFLOP."""
 
     @staticmethod
     def forward(ctx, Wf, Wd, W1):
-        Wcat = torch.cat([Wf, Wd], dim=0)
+        Wcat = cat_rows(Wf, Wd)
         W1 = _rows(W1)
         prod = gemm(Wcat, W1, op_b=1)                       # [2C, K0]
         ctx.save_for_backward(Wcat, W1)

@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import call, ptr
 from ._state import HK, SW, POOL_PATH_COUNTS, prof_arm, trace
 from .core import (BN_EPS, BN_MOMENTUM, _bn_leaky_backward, _bn_leaky_forward, _bn_statistics, _chunk_pc, _dgrad, _ld, _nchunk,
-                   _per_sample_colsum, _rows, _wgrad, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
+                   _per_sample_colsum, _rows, _wgrad, cat_rows, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
 from .pool import _forced_pool
 
 
@@ -153,7 +153,7 @@ class VNDirLinearLeakyFn(Function):
         dev = h.device
         if bias is not None:
             bias = _rows(bias)
-        Wcat = torch.cat([Wf, Wd], dim=0)
+        Wcat = cat_rows(Wf, Wd)
         v = gemm(h, Wcat, nsplit=1)                                   # [P, 2C]
         chunk, nch = VNDirLinearLeakyFn._chunk(P, C)
         common = (ptr(v), 2 * C, ptr(u), ptr(bias), _ld(bias) if bias is not None else 0, P, C, points_per_group, chunk)

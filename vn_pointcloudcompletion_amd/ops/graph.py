@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import call, ptr
 from ._state import HK, SW, POOL_PATH_COUNTS, prof_arm, trace
 from .core import (BN_EPS, BN_MOMENTUM, _bn_leaky_backward, _bn_leaky_forward, _bn_statistics, _chunk_pc, _dgrad, _ld, _nchunk,
-                   _per_sample_colsum, _rows, _wgrad, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
+                   _per_sample_colsum, _rows, _wgrad, cat_rows, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
 
 
 def knn_indices(ref, query, k, return_dist=False):

@@ -10,7 +10,7 @@ from .. import _lib
 from .._lib import call, ptr
 from ._state import HK, SW, POOL_PATH_COUNTS, prof_arm, trace
 from .core import (BN_EPS, BN_MOMENTUM, _bn_leaky_backward, _bn_leaky_forward, _bn_statistics, _chunk_pc, _dgrad, _ld, _nchunk,
-                   _per_sample_colsum, _rows, _wgrad, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
+                   _per_sample_colsum, _rows, _wgrad, cat_rows, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
 
 
 class VNLinearFn(Function):
@@ -57,7 +57,7 @@ class VNLinearLeakyFn(Function):
             bias = _rows(bias)
         # one GEMM for both halves: [Wf; Wd] is copied into a [2C, Cin] matrix (a few MB at most) so that x is streamed
         # once and the launch has twice the columns
-        Wcat = torch.cat([Wf, Wd], dim=0)
+        Wcat = cat_rows(Wf, Wd)
         part = gemm_pd_stats(x, Wcat, pd, bias, rows_per_group, C, training)
         out, mean, rstd = _bn_leaky_forward(pd[:, :C], pd[:, C:], C, gamma, beta, running_mean, running_var, training, ns, part=part)
         ctx.save_for_backward(x, Wcat, gamma, beta, pd, mean, rstd)
@@ -99,7 +99,7 @@ class VNLinearLeakyOutFn(Function):
         P = R // 3
         C = Wf.shape[0]
         dev = x.device
-        Wcat = torch.cat([Wf, Wd], dim=0)
+        Wcat = cat_rows(Wf, Wd)
         pd = torch.empty((R, 2 * C), device=dev, dtype=torch.float32)
         part = gemm_pd_stats(x, Wcat, pd, None, 0, C, training)                # [R, 2C] (+ the statistics of p from the epilogue)
         p, d = pd[:, :C], pd[:, C:]
@@ -182,3 +182,32 @@ class VNLeakyFn(Function):
         return gpd[:, :C], gpd[:, C:], None
 
 
+
+
+class VNLeakyDirFn(Function):
+    """VNLeakyReLU (models/vn_layers.py:25-43) with its direction map inside: d = x Wd^T, out = leaky(x, d).  x reaches the output twice
+    (directly and through d); its two gradient contributions are joined in the epilogue of the direction map's input-gradient product
+    (vnp_gemm_add) instead of by an addition of autograd's."""
+
+    @staticmethod
+    def forward(ctx, x, Wd, ns):
+        x = _rows(x)
+        C = x.shape[1]
+        if Wd.shape != (C, C):
+            raise _lib.VnpError("VNLeakyDirFn: a [C, C] direction map expected")
+        d = gemm(x, Wd)
+        out, _, _ = _bn_leaky_forward(x, d, C, None, None, None, None, False, ns, use_bn=False)
+        ctx.save_for_backward(x, d, Wd)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, d, Wd = ctx.saved_tensors
+        C = x.shape[1]
+        gpd, _, _ = _bn_leaky_backward(go, x, d, C, None, None, None, None, False, ctx.ns, use_bn=False)
+        gxl, gd = gpd[:, :C], gpd[:, C:]
+        gx = gemm(gd, Wd, op_b=1, resid=gxl) if ctx.needs_input_grad[0] else None        # dL/dx = dL/dx|leaky + gd Wd
+        gW = _wgrad(gd, x) if ctx.needs_input_grad[1] else None
+        return gx, gW, None

@@ -158,12 +158,10 @@ class VN_FoldingNet(nn.Module):
         latent = feature_global.shape[1]
         g_rows = global_to_rows(feature_global.float())
         Wf, Wd = l0.map_to_feat.weight, l0.map_to_dir.weight
-        Wfg, wfs, wfc = ops.split_cols(Wf, latent, 1, 1)                        # per-sample part | seed column | coarse column
-        Wdg, wds, wdc = ops.split_cols(Wd, latent, 1, 1)
-        bias = torch.cat([ops.VNLinearFn.apply(g_rows, Wfg, None, 0),
-                          ops.VNLinearFn.apply(g_rows, Wdg, None, 0)], dim=1)        # [B*3, 512]
-        wseed = torch.cat([wfs.squeeze(1), wds.squeeze(1)])
-        wcoarse = torch.cat([wfc.squeeze(1), wdc.squeeze(1)])
+        # per-sample part | seed column | coarse column of both weights, each as one [2C, n] matrix (rows: feat then dir)
+        Wg, wseed, wcoarse = ops.pack_pd_cols(Wf, Wd, (latent, 1, 1))
+        bias = ops.VNLinearFn.apply(g_rows, Wg, None, 0)                        # [B*3, 512] (feat | dir), one product
+        wseed, wcoarse = wseed.squeeze(1), wcoarse.squeeze(1)
         coarse = coarse.contiguous().float()
         bn = l0.batchnorm.bn
         l0.batchnorm._tick()

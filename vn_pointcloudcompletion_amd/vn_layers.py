@@ -64,9 +64,10 @@ class VNLeakyReLU(nn.Module):
         self.negative_slope = negative_slope
 
     def forward_rows(self, rows):
+        if not self.share_nonlinearity:
+            return ops.VNLeakyDirFn.apply(rows, self.map_to_dir.weight, self.negative_slope)
         d = ops.VNLinearFn.apply(rows, self.map_to_dir.weight, None, 0)
-        if self.share_nonlinearity:
-            d = d.expand(-1, rows.shape[1]).contiguous()
+        d = d.expand(-1, rows.shape[1]).contiguous()
         return ops.VNLeakyFn.apply(rows, d, self.negative_slope)
 
     def forward(self, x):
@@ -180,23 +181,26 @@ class VNLinearLeakyReLU(nn.Module):
             Wd = Wd.expand(Wf.shape[0], -1)              # one shared direction (vn_layers.py:56-57): same row for every channel
         bias = None
         if global_rows is not None:
+            # the per-sample channels' columns of both weights as one [2C, cg] matrix: ONE product gives the bias (feat | dir); the
+            # per-point columns come back as the two halves of one buffer (ops.PackPdColsFn)
             cg = global_rows.shape[1]
             cx = Wf.shape[1] - cg
+            fold = (pre_linear is None and rows_per_group % 3 == 0 and rows.dim() == 2 and cx == 1
+                    and ops.group_fold_ok(rows.shape[1], rows_per_group // 3, Wf.shape[0]))
             if global_first:
-                (Wfg, Wf), (Wdg, Wd) = ops.split_cols(Wf, cg, cx), ops.split_cols(Wd, cg, cx)
+                Wg, *Wx = ops.pack_pd_cols(Wf, Wd, (cg, cx), (False, not fold))
             else:
-                (Wf, Wfg), (Wd, Wdg) = ops.split_cols(Wf, cx, cg), ops.split_cols(Wd, cx, cg)
-            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
-                              ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
+                *Wx, Wg = ops.pack_pd_cols(Wf, Wd, (cx, cg), (not fold, False))
+            bias = ops.VNLinearFn.apply(global_rows, Wg, None, 0)
+            if fold:
+                # ONE per-point VN channel beside per-group features (the attention decoder's folding stages): all passes rebuild
+                # p | d = bias[group] + w x[point] in registers instead of streaming a [P*3, 2C] tensor six times
+                return ops.GroupFoldBnLeakyFn.apply(rows, Wx[0].squeeze(1), bias, rows_per_group // 3, bn.weight, bn.bias,
+                                                    bn.running_mean, bn.running_var, self.training, self.negative_slope)
+            Wf, Wd = Wx
         if pre_linear is not None:
             ops.trace("linear_folded_onto_producer")
             Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
-        if (bias is not None and pre_linear is None and rows_per_group % 3 == 0 and rows.dim() == 2
-                and ops.group_fold_ok(rows.shape[1], rows_per_group // 3, Wf.shape[0])):
-            # ONE per-point VN channel beside per-group features (the attention decoder's folding stages): all passes rebuild
-            # p | d = bias[group] + w x[point] in registers instead of streaming a [P*3, 2C] tensor six times
-            return ops.GroupFoldBnLeakyFn.apply(rows, torch.cat([Wf[:, 0], Wd[:, 0]]), bias, rows_per_group // 3, bn.weight, bn.bias,
-                                                bn.running_mean, bn.running_var, self.training, self.negative_slope)
         return ops.VNLinearLeakyFn.apply(rows, Wf, Wd, bn.weight, bn.bias, bn.running_mean, bn.running_var, bias,
                                          rows_per_group, self.training, self.negative_slope, pre_linear is not None)
 
@@ -212,9 +216,8 @@ class VNLinearLeakyReLU(nn.Module):
         if global_rows is not None:
             cg = global_rows.shape[1]
             cx = Wf.shape[1] - cg
-            (Wfg, Wf), (Wdg, Wd) = ops.split_cols(Wf, cg, cx), ops.split_cols(Wd, cg, cx)
-            bias = torch.cat([ops.VNLinearFn.apply(global_rows, Wfg, None, 0),
-                              ops.VNLinearFn.apply(global_rows, Wdg, None, 0)], dim=1)
+            Wg, Wf, Wd = ops.pack_pd_cols(Wf, Wd, (cg, cx), (False, True))
+            bias = ops.VNLinearFn.apply(global_rows, Wg, None, 0)
         if pre_linear is not None:
             ops.trace("linear_folded_onto_producer")
             Wf, Wd = ops.WeightProductFn.apply(Wf, Wd, pre_linear)
