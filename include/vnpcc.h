@@ -332,6 +332,10 @@ int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long l
 int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
                           long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                           float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu);
+/* The per-point weights [Wu; Wv] [4C'][C] of a fused EdgeConv layer from its VNLinearLeakyReLU weights Wf, Wd [C'][2C] (contiguous):
+ * Wu = [Wf[:, :C]; Wd[:, :C]] acts on the neighbour, Wv = [Wf[:, C:] - Wf[:, :C]; Wd[:, C:] - Wd[:, :C]] on the centre
+ * (W cat(f_j - x, x) = W1 f_j + (W2 - W1) x, models/dgcnn.py:250-278).  dir = 0: uv <- (Wf, Wd); dir = 1: the adjoint, (Wf, Wd) <- uv. */
+int vnp_edge_weights(hipStream_t st, int dir, float* Wf, float* Wd, float* uv, int Cp, int C);
 /* out[(p*k+j)*3+t][c] = u[nbr[p*k+j]*3+t][c] + v[p*3+t][c]: edge tensor of vn_get_graph_feature (models/dgcnn.py:250-278)
  * with the layer's weights applied per point first (W [feat-x | x] = W1 feat + (W2-W1) x) */
 int vnp_edge_gather_add(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* nbr,

@@ -47,7 +47,9 @@ def test_training_step_gradients_are_bit_identical_run_to_run(lib_built, enc, la
         if not same:
             diff = (grads[i].view(torch.int32) != grads[0].view(torch.int32))
             names = []
-            for (name, prm), o in zip(net.named_parameters(), fb.offsets):
+            name_of = {id(q): nm for nm, q in net.named_parameters()}
+            for prm, o in zip(fb.params, fb.offsets):               # fb.params: the layout order (ops.pack_hint), offsets ascending
+                name = name_of[id(prm)]
                 if diff[o:o + prm.numel()].any():
                     names.append((name, int(diff[o:o + prm.numel()].sum())))
             raise AssertionError(f"run {i}: {int(diff.sum())} gradient words differ from run 0: {names[:8]}")

@@ -624,6 +624,29 @@ extern "C" int vnp_gather_coords(hipStream_t st, int B, int N, const float* xyz,
     return vnp_last_error();
 }
 
+// [Wu; Wv] [4C'][C] of an EdgeConv layer from its VNLinearLeakyReLU weights Wf, Wd [C'][2C] (input channels: C of feature - x, then C of x;
+// models/dgcnn.py:250-278): W cat(f_j - x, x) = W1 f_j + (W2 - W1) x, so Wu = [Wf1; Wd1] acts on the neighbour and Wv = [Wf2 - Wf1; Wd2 - Wd1]
+// on the centre.  dir = 0: out <- (Wf, Wd); dir = 1: the adjoint, (gWf, gWd) <- g [4C'][C]: d/dW1 = gu - gv, d/dW2 = gv.  One launch each
+// (five ATen launches forward and four backward per layer before).
+__global__ void __launch_bounds__(256) vnp_edge_weights_kernel(float* __restrict__ Wf, float* __restrict__ Wd, float* __restrict__ out, int Cp, int C, int dir)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;             // over [2][Cp][C]: (which weight, output channel, column)
+    if (e >= 2LL * Cp * C) return;
+    const int c = (int)(e % C), o = (int)((e / C) % Cp), w = (int)(e / ((long long)C * Cp));
+    float* W = w ? Wd : Wf;
+    const size_t i1 = (size_t)o * 2 * C + c, i2 = i1 + C;                     // W1 = W[:, :C], W2 = W[:, C:]
+    const size_t iu = ((size_t)w * Cp + o) * C + c, iv = iu + (size_t)2 * Cp * C;
+    if (dir == 0) { const float a = W[i1]; out[iu] = a; out[iv] = W[i2] - a; }
+    else          { const float gv = out[iv]; W[i1] = out[iu] - gv; W[i2] = gv; }
+}
+
+extern "C" int vnp_edge_weights(hipStream_t st, int dir, float* Wf, float* Wd, float* uv, int Cp, int C)
+{
+    if (!Wf || !Wd || !uv || Cp <= 0 || C <= 0 || (dir != 0 && dir != 1)) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_edge_weights_kernel, dim3((unsigned)vnp_cdiv(2LL * Cp * C, 256)), dim3(256), 0, st, Wf, Wd, uv, Cp, C, dir);
+    return vnp_last_error();
+}
+
 // out [Pout*3][ldo] : point i copies point src[i] (global point ids) of x
 extern "C" int vnp_gather_points(hipStream_t st, const float* x, int ldx, const int* src, long long Pout, int W, float* out, int ldo)
 {

@@ -13,7 +13,7 @@ from .attention import (AddLayerNormFn, VNAttentionFn, VNAttentionPackedFn, VNLa
                         _heads_tm, _rows_from_fm, _to_heads, gemm_batched)
 from .chamfer import ChamferFn, ChamferL1LossFn
 from .core import (BN_EPS, BN_MOMENTUM, FromRowsFn, SplitColsFn, ToRowsFn, WeightProductFn, _bn_leaky_backward, _bn_leaky_forward, _dgrad,
-                   _ld, _rows, amax_word, cat_rows, drop_amax, gemm, pack_pd_cols, PackPdColsFn,
+                   _ld, _rows, amax_word, cat_rows, drop_amax, gemm, pack_hint, pack_pd_cols, PackPdColsFn, PackRowsFn,
                    gemm_pd_stats, reduce_pairs, reduce_rows, set_amax, split_cols)
 from .dirlayer import DirContractFn, DirExpandFn, DirLinearMaxPoolFn, VNDirLinearLeakyFn, unit_dirs
 from .fold import FoldBnLeakyFn, FoldFn, GroupFoldBnLeakyFn, LinOutFn, group_fold_ok

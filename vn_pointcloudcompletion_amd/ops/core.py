@@ -373,14 +373,46 @@ def split_cols(W, *sizes):
     return SplitColsFn.apply(W, *sizes)
 
 
-def cat_rows(Wf, Wd):
-    """[Wf; Wd] — as a VIEW when the two already sit one after the other in one buffer (the halves PackPdColsFn returns), else one
-    concatenation.  For use inside a Function's forward (no autograd through it)."""
-    if (Wf.dim() == 2 and Wd.dim() == 2 and Wf.shape[1] == Wd.shape[1] and Wf.is_contiguous() and Wd.is_contiguous()
-            and Wf.dtype == Wd.dtype and Wf.device == Wd.device and Wf.untyped_storage().data_ptr() == Wd.untyped_storage().data_ptr()
-            and Wd.storage_offset() == Wf.storage_offset() + Wf.numel()):
-        return torch.as_strided(Wf, (Wf.shape[0] + Wd.shape[0], Wf.shape[1]), (Wf.shape[1], 1), Wf.storage_offset())
-    return torch.cat([Wf, Wd], dim=0)
+def cat_rows(*ws):
+    """[W0; W1; ...] — as a VIEW when the matrices already sit one after the other in one buffer (the halves PackPdColsFn returns; a
+    layer's weights inside optim.FlatBuffers, which honours ``pack_hint``), else one concatenation.  For use inside a Function's forward
+    (no autograd through it)."""
+    w0 = ws[0]
+    ok = all(w.dim() == 2 and w.shape[1] == w0.shape[1] and w.is_contiguous() and w.dtype == w0.dtype and w.device == w0.device
+             for w in ws)
+    if ok:
+        base, off = w0.untyped_storage().data_ptr(), w0.storage_offset()
+        for w in ws:
+            if w.untyped_storage().data_ptr() != base or w.storage_offset() != off:
+                ok = False
+                break
+            off += w.numel()
+    if ok:
+        return torch.as_strided(w0, (sum(w.shape[0] for w in ws), w0.shape[1]), (w0.shape[1], 1), w0.storage_offset())
+    return torch.cat(list(ws), dim=0)
+
+
+def pack_hint(*params):
+    """Ask optim.FlatBuffers to place these parameters one after the other (in this order) in its flat buffers, so that ``cat_rows`` of
+    them is a view: a layer's [Wf; Wd], an attention's [Wq; Wk; Wv].  Only a hint: without FlatBuffers (or with a parameter frozen or
+    of a size that needs padding) the concatenation is a copy, as before."""
+    for a, b in zip(params[:-1], params[1:]):
+        a._vnp_pack_next = b
+
+
+class PackRowsFn(Function):
+    """[W0; W1; ...] of parameters with autograd (an attention's projection weights for ONE product): a view when they are adjacent
+    (``pack_hint`` + FlatBuffers), else a concatenation; the gradient comes back as the row blocks of one matrix."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.rows = [w.shape[0] for w in ws]
+        return cat_rows(*[w.detach() for w in ws])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return tuple(torch.split(g, ctx.rows, dim=0))
 
 
 class PackPdColsFn(Function):

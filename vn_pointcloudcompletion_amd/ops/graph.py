@@ -310,19 +310,19 @@ class EdgeWeightsFn(Function):
 
     @staticmethod
     def forward(ctx, Wf, Wd):
-        C = Wf.shape[1] // 2
-        W = torch.stack([Wf, Wd])                                # [2, C', 2C]
-        a, b = W[:, :, :C], W[:, :, C:]
-        ctx.C = C
-        return torch.cat([a.reshape(-1, C), (b - a).reshape(-1, C)], dim=0)
+        Cp, C = Wf.shape[0], Wf.shape[1] // 2
+        Wf, Wd = Wf.contiguous(), Wd.contiguous()
+        out = torch.empty((4 * Cp, C), device=Wf.device, dtype=torch.float32)
+        call("vnp_edge_weights", 0, ptr(Wf), ptr(Wd), ptr(out), Cp, C)
+        ctx.cfg = (Cp, C)
+        return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        C = ctx.C
-        half = g.shape[0] // 2
-        gu, gv = g[:half], g[half:]
-        gW = torch.cat([(gu - gv).reshape(2, -1, C), gv.reshape(2, -1, C)], dim=2)      # [2, C', 2C]: d/dW1 = gu - gv, d/dW2 = gv
-        return gW[0], gW[1]
-
-
+        Cp, C = ctx.cfg
+        g = g.contiguous()
+        gWf = torch.empty((Cp, 2 * C), device=g.device, dtype=torch.float32)
+        gWd = torch.empty((Cp, 2 * C), device=g.device, dtype=torch.float32)
+        call("vnp_edge_weights", 1, ptr(gWf), ptr(gWd), ptr(g), Cp, C)
+        return gWf, gWd

@@ -34,7 +34,7 @@ class FlatBuffers:
     """
 
     def __init__(self, params, gathered=None):
-        self.params = [p for p in params if p.requires_grad]
+        self.params = self._layout_order([p for p in params if p.requires_grad])
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
@@ -63,6 +63,27 @@ class FlatBuffers:
         self._numels = [p.numel() for p in self.params]
         for p, v in zip(self.params, self._gviews):
             p.grad = v
+
+    @staticmethod
+    def _layout_order(params):
+        """The order in which the parameters are laid out (``self.params``; offsets ascend along it): the given order, except that a
+        parameter another one names as its pack successor (ops.pack_hint: a layer's map_to_dir after its map_to_feat, an attention's
+        Wk, Wv after Wq) moves up right behind it, so that [Wf; Wd] is one contiguous block of the flat buffer and the layers take it
+        as a view instead of concatenating the two every step.  A chain is cut at a parameter whose size would need padding."""
+        ids = {id(p) for p in params}
+        placed, order = set(), []
+        for p in params:
+            if id(p) in placed:
+                continue
+            q = p
+            while True:
+                order.append(q)
+                placed.add(id(q))
+                nxt = getattr(q, "_vnp_pack_next", None)
+                if nxt is None or id(nxt) not in ids or id(nxt) in placed or q.numel() % _ALIGN or nxt.dtype != q.dtype:
+                    break
+                q = nxt
+        return order
 
     def view(self, flat, i):
         p, o = self.params[i], self.offsets[i]

@@ -44,6 +44,7 @@ class Attention(nn.Module):
         self.proj_vnq = VNLinear(dim, dim)
         self.proj_vnk = VNLinear(dim, dim)
         self.proj_vnv = VNLinear(dim, dim)
+        ops.pack_hint(self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight)
         self.proj_vn = VNLinear(dim, dim)
         if attn_drop or proj_drop:
             raise NotImplementedError("dropout > 0 is not used on the PCNNet paths (rates are 0 in models/pcn.py:408-412)")
@@ -51,7 +52,7 @@ class Attention(nn.Module):
     def forward_rows(self, rows, B, N, residual=None):
         # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result;
         # ``residual``: the block's skip connection, added in the output projection's epilogue
-        Wqkv = torch.cat([self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight], dim=0)
+        Wqkv = ops.PackRowsFn.apply(self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight)
         qkv = ops.VNLinearFn.apply(rows, Wqkv, None, 0)
         x = ops.VNAttentionPackedFn.apply(qkv, B, N, self.num_heads, self.scale)
         return self.proj_vn.forward_rows(x, residual=residual)

@@ -167,6 +167,8 @@ class VNLinearLeakyReLU(nn.Module):
         self.map_to_feat = nn.Linear(in_channels, out_channels, bias=False)
         self.batchnorm = VNBatchNorm(out_channels, dim=dim)
         self.map_to_dir = nn.Linear(in_channels, 1 if share_nonlinearity else out_channels, bias=False)
+        if not share_nonlinearity:
+            ops.pack_hint(self.map_to_feat.weight, self.map_to_dir.weight)      # [Wf; Wd] as one block of the optimizer's flat buffer
 
     def forward_rows(self, rows, global_rows=None, rows_per_group=0, global_first=True, pre_linear=None):
         """``global_rows`` [G*3, Cg]: per-group features standing for Cg of the input channels, i.e. the layer acts on

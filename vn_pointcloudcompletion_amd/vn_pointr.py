@@ -79,12 +79,13 @@ class Attention(nn.Module):
         self.proj_vnq = VNLinear(128, 384)
         self.proj_vnk = VNLinear(128, 384)
         self.proj_vnv = VNLinear(128, 384)
+        ops.pack_hint(self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight)
         self.proj_vn = VNLinear(384, 128)
 
     def forward_rows(self, rows, B, N, residual=None):
         # one projection GEMM over [Wq; Wk; Wv] (the three VNLinear modules keep their state_dict keys), attention on the packed result;
         # ``residual``: the block's skip connection, added in the output projection's epilogue
-        Wqkv = torch.cat([self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight], dim=0)
+        Wqkv = ops.PackRowsFn.apply(self.proj_vnq.map_to_feat.weight, self.proj_vnk.map_to_feat.weight, self.proj_vnv.map_to_feat.weight)
         qkv = ops.VNLinearFn.apply(rows, Wqkv, None, 0)
         return self.proj_vn.forward_rows(ops.VNAttentionPackedFn.apply(qkv, B, N, self.num_heads, self.scale), residual=residual)
 
