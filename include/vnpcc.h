@@ -332,6 +332,18 @@ int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, int k, long l
 int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
                           long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                           float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu);
+/* vnp_edge_fused / vnp_edge_fused_gather for a layer whose input is ONE VN channel — the points themselves: conv1 of VN_DGCNN_fps and of
+ * the VN-PoinTr grouper (models/dgcnn.py:291, models/pointr/utils/dgcnn_group.py:225).  xu [Pu*3], xv [Pq*3]: coordinates; wu, wv [2C]:
+ * the single column of [Wu; Wv] (vnp_edge_weights).  u = x wu^T and v = x wv^T are never formed: an edge reads its neighbour's 12 bytes
+ * instead of 24 C, and the product that formed them is gone.  Same bits as the general form on the formed matrices. */
+int vnp_edge_fused_r1(hipStream_t st, int mode, const float* xu, const float* xv, const float* wu, const float* wv, const int* nbr,
+                      long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
+                      const float* sums, long long count, float* gv, int ldgv);
+int vnp_edge_fused_gather_r1(hipStream_t st, const float* xu, const float* xv, const float* wu, const float* wv, const int* start,
+                             const int* rev, long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, float negative_slope, const float* go, int ldgo, const float* sums, long long count,
+                             float* gu, int ldgu);
 /* The per-point weights [Wu; Wv] [4C'][C] of a fused EdgeConv layer from its VNLinearLeakyReLU weights Wf, Wd [C'][2C] (contiguous):
  * Wu = [Wf[:, :C]; Wd[:, :C]] acts on the neighbour, Wv = [Wf[:, C:] - Wf[:, :C]; Wd[:, C:] - Wd[:, :C]] on the centre
  * (W cat(f_j - x, x) = W1 f_j + (W2 - W1) x, models/dgcnn.py:250-278).  dir = 0: uv <- (Wf, Wd); dir = 1: the adjoint, (Wf, Wd) <- uv. */

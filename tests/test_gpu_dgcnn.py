@@ -354,3 +354,38 @@ def test_fps_plan_equals_the_samplings_one_after_the_other(lib_built, ahead):
     for (idx, xyz, gid), (ri, rc, n_src) in zip(got, ((i512, c512, N), (i128, c128, 512), (i224, c224, N))):
         assert torch.equal(idx, ri) and torch.equal(xyz, rc)
         assert torch.equal(gid, (ri + off * n_src).reshape(-1))
+
+
+@pytest.mark.parametrize("B,N,k,Cp,training", [(2, 300, 16, 32, True), (3, 128, 8, 128, True), (1, 70, 5, 24, False), (2, 2048, 20, 32, True)])
+def test_edge_conv_on_the_cloud_itself_equals_the_general_form(lib_built, B, N, k, Cp, training):
+    """ops.EdgeConvRank1Fn (EdgeConv whose input is ONE VN channel, the coordinates: the per-point matrices u | v = x [Wu; Wv]^T are rebuilt
+    from 12 bytes per point inside the passes, vnp_edge_fused_r1) against the general fused form on the formed matrices
+    (VNLinearFn -> EdgeConvPackedFn): output, running statistics and the gradients of the weights, of gamma / beta and of the cloud, bit for
+    bit (the rebuilt products are rounded once and not contracted with the additions behind them)."""
+    from vn_pointcloudcompletion_amd import ops
+    g = torch.Generator().manual_seed(N + k)
+    xyz = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    idx = ops.knn_indices(xyz, xyz, k)
+    nbr = (idx + (torch.arange(B, device="cuda", dtype=torch.int32) * N).view(B, 1, 1)).reshape(B * N, k)
+    W0 = (torch.randn(4 * Cp, 1, generator=g) * 0.7).cuda()
+    gam0, bet0 = (torch.rand(Cp, generator=g) + 0.5).cuda(), (torch.randn(Cp, generator=g) * 0.2).cuda()
+    go = torch.randn(B * N * 3, Cp, generator=g).cuda()
+
+    def run(rank1):
+        x = xyz.reshape(B * N * 3, 1).clone().requires_grad_(True)
+        W, gam, bet = W0.clone().requires_grad_(True), gam0.clone().requires_grad_(True), bet0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(Cp, device="cuda"), torch.ones(Cp, device="cuda")
+        if rank1:
+            out = ops.EdgeConvRank1Fn.apply(x, W, nbr, gam, bet, rm, rv, training, 0.2)
+        else:
+            out = ops.EdgeConvPackedFn.apply(ops.VNLinearFn.apply(x, W, None, 0), nbr, gam, bet, rm, rv, training, 0.2)
+        out.backward(go)
+        return [out.detach(), rm, rv, W.grad, gam.grad, bet.grad, x.grad]
+    names = ("out", "running_mean", "running_var", "gW", "ggamma", "gbeta", "gx")
+    for nm, a, b in zip(names, run(True), run(False)):
+        if nm in ("gW", "gx"):
+            # the two weight / input gradients are products over the same guv in both forms, but the general form reaches them through
+            # VNLinearFn's own launches: same kernels and shapes, so the same bits as well
+            assert torch.equal(a, b), nm
+        else:
+            assert torch.equal(a, b), nm

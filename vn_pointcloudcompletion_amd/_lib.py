@@ -135,6 +135,8 @@ _SIGNATURES = {
     "vnp_edge_reverse": [_vp, _ll, _i, _ll, _vp, _vp, _vp],
     "vnp_edge_fused_gather": [_vp, _i, _vp, _i, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _ll, _vp, _i],
     "vnp_edge_weights": [_i, _vp, _vp, _vp, _i, _i],
+    "vnp_edge_fused_r1": [_i, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _ll, _vp, _i],
+    "vnp_edge_fused_gather_r1": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _ll, _vp, _i],
     "vnp_edge_gather_add": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_fold_fused": [_i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _ll,
                        _vp, _vp, _i],

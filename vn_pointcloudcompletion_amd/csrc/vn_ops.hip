@@ -1166,10 +1166,16 @@ struct VnpEdgeArgs {
     const float* go; int ldgo;                 // MODE 2 / 3
     const float* sums; float inv_count;        // MODE 3 ([C][2]; nullptr in eval mode)
     float* gu; int ldgu; float* gv; int ldgv;  // MODE 3
+    // R1 kernels (a layer whose input is ONE VN channel — the point itself, conv1 of every encoder, models/dgcnn.py:291): u and v are
+    // the points' coordinates [P*3] (ldu = ldv = 1) and the per-point matrices are rebuilt as x[t] * wu[c], x[t] * wv[c] (wu, wv [2C])
+    const float* wu; const float* wv;
 };
 #define VNP_EDGE_QB 64                         // queries per block
 
-template <int MODE>
+// one rounding of the product and no contraction with the addition behind it: the bits of the stored u = x W^T (a K = 1 product)
+__device__ __forceinline__ float vnp_mul_alone(float a, float b) { float p = a * b; asm volatile("" : "+v"(p)); return p; }
+
+template <int MODE, bool R1 = false>
 __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a)
 {
     // the backward modes use v_rcp_f32 / v_sqrt_f32 (1 ulp each) as the other gradient kernels do; the forward modes keep IEEE division
@@ -1190,10 +1196,20 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
     const float kf = (float)k, kinv = 1.f / kf;
     float wmean = 0.f, wm2 = 0.f, s1 = 0.f, s2 = 0.f;
     int wn = 0;
+    float wup = 0.f, wud = 0.f, wvp = 0.f, wvd = 0.f;
+    if (R1) { wup = a.wu[cc]; wud = a.wu[C + cc]; wvp = a.wv[cc]; wvd = a.wv[C + cc]; }
     for (long long q = q0 + py; q < q1; q += 4) {
-        const float* rv = a.v + (size_t)q * 3 * a.ldv + cc;
-        const float vp0 = rv[0], vp1 = rv[a.ldv], vp2 = rv[2 * a.ldv];
-        const float vd0 = rv[C], vd1 = rv[a.ldv + C], vd2 = rv[2 * a.ldv + C];
+        float vp0, vp1, vp2, vd0, vd1, vd2;
+        if (R1) {
+            const float* xq = a.v + (size_t)q * 3;
+            const float c0 = xq[0], c1 = xq[1], c2 = xq[2];
+            vp0 = vnp_mul_alone(c0, wvp); vp1 = vnp_mul_alone(c1, wvp); vp2 = vnp_mul_alone(c2, wvp);
+            vd0 = vnp_mul_alone(c0, wvd); vd1 = vnp_mul_alone(c1, wvd); vd2 = vnp_mul_alone(c2, wvd);
+        } else {
+            const float* rv = a.v + (size_t)q * 3 * a.ldv + cc;
+            vp0 = rv[0]; vp1 = rv[a.ldv]; vp2 = rv[2 * a.ldv];
+            vd0 = rv[C]; vd1 = rv[a.ldv + C]; vd2 = rv[2 * a.ldv + C];
+        }
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f;
         if (MODE >= 2) {
             const float* rg = a.go + (size_t)q * 3 * a.ldgo + cc;
@@ -1204,8 +1220,12 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
 #pragma unroll 4
         for (int j = 0; j < k; ++j) {
             const size_t urow = (size_t)nb[j] * 3;
-            const float* ru = a.u + urow * a.ldu + cc;
-            const float x0 = ru[0] + vp0, x1 = ru[a.ldu] + vp1, x2 = ru[2 * a.ldu] + vp2;
+            const float* ru = R1 ? a.u + urow : a.u + urow * a.ldu + cc;
+            float x0, x1, x2, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+            if (R1) {
+                t0 = ru[0]; t1 = ru[1]; t2 = ru[2];                                          // the neighbour's coordinates: 12 bytes, not 24 C
+                x0 = vnp_mul_alone(t0, wup) + vp0; x1 = vnp_mul_alone(t1, wup) + vp1; x2 = vnp_mul_alone(t2, wup) + vp2;
+            } else { x0 = ru[0] + vp0; x1 = ru[a.ldu] + vp1; x2 = ru[2 * a.ldu] + vp2; }
             if (MODE == 0) {
                 // statistics pass: hardware sqrt and reciprocal (1 ulp each) — the pass was bound by the IEEE sqrt / division sequences
                 // (~22 of its ~30 instructions per edge and channel); the running statistics move by ~1e-7 relative
@@ -1218,7 +1238,9 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             }
             const float pn = ESQRT(vnp_sq3(x0, x1, x2));
             const float n = pn + VNP_EPS;
-            const float d0 = ru[C] + vd0, d1 = ru[a.ldu + C] + vd1, d2 = ru[2 * a.ldu + C] + vd2;
+            float d0, d1, d2;
+            if (R1) { d0 = vnp_mul_alone(t0, wud) + vd0; d1 = vnp_mul_alone(t1, wud) + vd1; d2 = vnp_mul_alone(t2, wud) + vd2; }
+            else { d0 = ru[C] + vd0; d1 = ru[a.ldu + C] + vd1; d2 = ru[2 * a.ldu + C] + vd2; }
             const float xh = (n - mu) * rs;
             const float nh = xh * ga + be;
             const float s = EDIV(nh, n);
@@ -1291,6 +1313,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
 // A workgroup = 64 channels x 4 edge lanes walks VNP_EDGE_SB consecutive sources; the four lanes share a source's list (edge e, e + 4, ...:
 // a hub of a feature-space graph with hundreds of incoming edges does not serialise on one thread) and meet in LDS in a fixed order.
 #define VNP_EDGE_SB 16
+template <bool R1 = false>
 __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArgs a, const int* __restrict__ rstart, const int* __restrict__ rev,
                                                                long long Pu)
 {
@@ -1306,19 +1329,36 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
     float m1 = 0.f, m2 = 0.f;
     if (a.sums) { m1 = a.sums[2 * cc] * a.inv_count; m2 = a.sums[2 * cc + 1] * a.inv_count; }
     const float kinv = 1.f / (float)a.k;
+    float wup = 0.f, wud = 0.f, wvp = 0.f, wvd = 0.f;
+    if (R1) { wup = a.wu[cc]; wud = a.wu[C + cc]; wvp = a.wv[cc]; wvd = a.wv[C + cc]; }
     for (long long sp = s0; sp < s1; ++sp) {
-        const float* ru = a.u + (size_t)sp * 3 * a.ldu + cc;
-        const float up0 = ru[0], up1 = ru[a.ldu], up2 = ru[2 * a.ldu];
-        const float ud0 = ru[C], ud1 = ru[a.ldu + C], ud2 = ru[2 * a.ldu + C];
+        float up0, up1, up2, ud0, ud1, ud2;
+        if (R1) {
+            const float* xs = a.u + (size_t)sp * 3;
+            const float c0 = xs[0], c1 = xs[1], c2 = xs[2];
+            up0 = vnp_mul_alone(c0, wup); up1 = vnp_mul_alone(c1, wup); up2 = vnp_mul_alone(c2, wup);
+            ud0 = vnp_mul_alone(c0, wud); ud1 = vnp_mul_alone(c1, wud); ud2 = vnp_mul_alone(c2, wud);
+        } else {
+            const float* ru = a.u + (size_t)sp * 3 * a.ldu + cc;
+            up0 = ru[0]; up1 = ru[a.ldu]; up2 = ru[2 * a.ldu];
+            ud0 = ru[C]; ud1 = ru[a.ldu + C]; ud2 = ru[2 * a.ldu + C];
+        }
         double F0 = 0.0, F1 = 0.0, F2 = 0.0, E0 = 0.0, E1 = 0.0, E2 = 0.0;
         const int e1 = rstart[sp + 1];
 #pragma unroll 2
         for (int e = rstart[sp] + py; e < e1; e += 4) {
             const size_t q = (size_t)rev[e];
-            const float* rv = a.v + q * 3 * a.ldv + cc;
+            const float* rv = R1 ? a.v + q * 3 : a.v + q * 3 * a.ldv + cc;
             const float* rg = a.go + q * 3 * a.ldgo + cc;
-            const float x0 = up0 + rv[0], x1 = up1 + rv[a.ldv], x2 = up2 + rv[2 * a.ldv];
-            const float d0 = ud0 + rv[C], d1 = ud1 + rv[a.ldv + C], d2 = ud2 + rv[2 * a.ldv + C];
+            float x0, x1, x2, d0, d1, d2;
+            if (R1) {
+                const float c0 = rv[0], c1 = rv[1], c2 = rv[2];
+                x0 = up0 + vnp_mul_alone(c0, wvp); x1 = up1 + vnp_mul_alone(c1, wvp); x2 = up2 + vnp_mul_alone(c2, wvp);
+                d0 = ud0 + vnp_mul_alone(c0, wvd); d1 = ud1 + vnp_mul_alone(c1, wvd); d2 = ud2 + vnp_mul_alone(c2, wvd);
+            } else {
+                x0 = up0 + rv[0]; x1 = up1 + rv[a.ldv]; x2 = up2 + rv[2 * a.ldv];
+                d0 = ud0 + rv[C]; d1 = ud1 + rv[a.ldv + C]; d2 = ud2 + rv[2 * a.ldv + C];
+            }
             const float ge0 = rg[0] * kinv, ge1 = rg[a.ldgo] * kinv, ge2 = rg[2 * a.ldgo] * kinv;
             const float pn = ESQRT(vnp_sq3(x0, x1, x2));
             const float n = pn + VNP_EPS;
@@ -1820,11 +1860,13 @@ extern "C" int vnp_edge_block_queries(void) { return VNP_EDGE_QB; }
 // mode 0: partial [ceil(Pq/64)][C][2].  mode 1: out [Pq*3, ldo].  mode 2: go, partial.  mode 3: go, sums ([C][2] or NULL), count =
 // number of edges, gv [Pq*3, ldgv >= 2C]; gu / ldgu / Pu must be NULL / 0 / 0 (the scatter form with float atomics is gone: the source
 // points' gradient comes from vnp_edge_fused_gather, a gather over the reverse adjacency).
-extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
+static int vnp_edge_fused_impl(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
                               long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
-                              const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv)
+                              const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv,
+                              const float* wu, const float* wv)
 {
+    const bool r1 = wu != nullptr;
     if (!u || !v || !nbr || Pq <= 0 || k <= 0 || C <= 0 || mode < 0 || mode > 3) return VNP_EINVAL;
     if (mode >= 1 && (!mean || !rstd || !gamma || !beta)) return VNP_EINVAL;
     if ((mode == 0 || mode == 2) && !partial) return VNP_EINVAL;
@@ -1840,6 +1882,7 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
     a.partial = (float2*)partial; a.out = out; a.ldo = ldo; a.go = go; a.ldgo = ldgo;
     a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f;
     a.gu = nullptr; a.ldgu = 0; a.gv = gv; a.ldgv = ldgv;
+    a.wu = wu; a.wv = wv;
     // gridDim.y <= 65535: slices of query blocks
     for (long long b0 = 0; b0 < nblk; b0 += 65535) {
         const int nb = (int)((nblk - b0) < 65535 ? (nblk - b0) : 65535);
@@ -1851,14 +1894,43 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
         if (go) s.go = go + (size_t)qoff * 3 * ldgo;
         if (gv) s.gv = gv + (size_t)qoff * 3 * ldgv;
         const dim3 grid(vnp_cdiv(C, 64), nb), block(256);
-        switch (mode) {
-        case 0: hipLaunchKernelGGL(vnp_edge_fused_kernel<0>, grid, block, 0, st, s); break;
-        case 1: hipLaunchKernelGGL(vnp_edge_fused_kernel<1>, grid, block, 0, st, s); break;
-        case 2: hipLaunchKernelGGL(vnp_edge_fused_kernel<2>, grid, block, 0, st, s); break;
-        default: hipLaunchKernelGGL(vnp_edge_fused_kernel<3>, grid, block, 0, st, s); break;
+        if (r1) switch (mode) {
+        case 0: hipLaunchKernelGGL((vnp_edge_fused_kernel<0, true>), grid, block, 0, st, s); break;
+        case 1: hipLaunchKernelGGL((vnp_edge_fused_kernel<1, true>), grid, block, 0, st, s); break;
+        case 2: hipLaunchKernelGGL((vnp_edge_fused_kernel<2, true>), grid, block, 0, st, s); break;
+        default: hipLaunchKernelGGL((vnp_edge_fused_kernel<3, true>), grid, block, 0, st, s); break;
+        }
+        else switch (mode) {
+        case 0: hipLaunchKernelGGL((vnp_edge_fused_kernel<0, false>), grid, block, 0, st, s); break;
+        case 1: hipLaunchKernelGGL((vnp_edge_fused_kernel<1, false>), grid, block, 0, st, s); break;
+        case 2: hipLaunchKernelGGL((vnp_edge_fused_kernel<2, false>), grid, block, 0, st, s); break;
+        default: hipLaunchKernelGGL((vnp_edge_fused_kernel<3, false>), grid, block, 0, st, s); break;
         }
     }
     return vnp_last_error();
+}
+
+extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu, const float* v, int ldv, const int* nbr,
+                              long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
+                              const float* sums, long long count, float* gu, int ldgu, long long Pu, float* gv, int ldgv)
+{
+    return vnp_edge_fused_impl(st, mode, u, ldu, v, ldv, nbr, Pq, k, C, mean, rstd, gamma, beta, negative_slope, partial, out, ldo, go, ldgo,
+                               sums, count, gu, ldgu, Pu, gv, ldgv, nullptr, nullptr);
+}
+
+// The same passes for a layer whose input is ONE VN channel, the points themselves (conv1 of the encoders: models/dgcnn.py:291,
+// dgcnn_group.py:225): xu [Pu*3], xv [Pq*3] coordinates, wu, wv [2C] the columns of [Wu; Wv] (vnp_edge_weights with one input channel).
+// The per-point matrices u = x wu^T, v = x wv^T are never formed: an edge reads its neighbour's 12 bytes instead of 24 C.
+// Same bits as vnp_edge_fused on the formed matrices.
+extern "C" int vnp_edge_fused_r1(hipStream_t st, int mode, const float* xu, const float* xv, const float* wu, const float* wv, const int* nbr,
+                                 long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
+                                 const float* sums, long long count, float* gv, int ldgv)
+{
+    if (!wu || !wv) return VNP_EINVAL;
+    return vnp_edge_fused_impl(st, mode, xu, 1, xv, 1, nbr, Pq, k, C, mean, rstd, gamma, beta, negative_slope, partial, out, ldo, go, ldgo,
+                               sums, count, nullptr, 0, 0, gv, ldgv, wu, wv);
 }
 
 // Reverse adjacency of nbr [Pq][k] (ids < Pu): start [Pu + 1] = exclusive prefix of the in-degrees, rev [Pq * k] = query ids grouped by
@@ -1883,9 +1955,10 @@ extern "C" int vnp_edge_reverse(hipStream_t st, const int* nbr, long long Pq, in
 
 // gu [Pu*3, ldgu >= 2C] of vnp_edge_fused's mode 3 as a gather over the reverse adjacency (start, rev from vnp_edge_reverse): no atomics,
 // no zero fill, the same per-edge arithmetic; k = neighbours per query (the mean-pool divisor), count = number of edges.
-extern "C" int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
+static int vnp_edge_fused_gather_impl(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
                                      long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                     float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu)
+                                     float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu,
+                                     const float* wu, const float* wv)
 {
     if (!u || !v || !start || !rev || !mean || !rstd || !gamma || !beta || !go || !gu || Pu <= 0 || k <= 0 || C <= 0) return VNP_EINVAL;
     VnpEdgeArgs a{};
@@ -1893,6 +1966,7 @@ extern "C" int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, co
     a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta; a.ns = negative_slope;
     a.go = go; a.ldgo = ldgo; a.sums = sums; a.inv_count = count > 0 ? 1.0f / (float)count : 0.f;
     a.gu = gu; a.ldgu = ldgu;
+    a.wu = wu; a.wv = wv;
     const long long nblk = (Pu + VNP_EDGE_SB - 1) / VNP_EDGE_SB;
     for (long long b0 = 0; b0 < nblk; b0 += 65535) {
         const int nb = (int)((nblk - b0) < 65535 ? (nblk - b0) : 65535);
@@ -1900,7 +1974,26 @@ extern "C" int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, co
         const long long soff = b0 * VNP_EDGE_SB;
         s.u = u + (size_t)soff * 3 * ldu; s.gu = gu + (size_t)soff * 3 * ldgu;
         const long long np = (Pu - soff) < (long long)nb * VNP_EDGE_SB ? (Pu - soff) : (long long)nb * VNP_EDGE_SB;
-        hipLaunchKernelGGL(vnp_edge_gather_u_kernel, dim3(vnp_cdiv(C, 64), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        if (wu) hipLaunchKernelGGL((vnp_edge_gather_u_kernel<true>), dim3(vnp_cdiv(C, 64), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        else    hipLaunchKernelGGL((vnp_edge_gather_u_kernel<false>), dim3(vnp_cdiv(C, 64), nb), dim3(256), 0, st, s, start + soff, rev, np);
     }
     return vnp_last_error();
+}
+
+extern "C" int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* v, int ldv, const int* start, const int* rev,
+                                     long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float negative_slope, const float* go, int ldgo, const float* sums, long long count, float* gu, int ldgu)
+{
+    return vnp_edge_fused_gather_impl(st, u, ldu, v, ldv, start, rev, Pu, k, C, mean, rstd, gamma, beta, negative_slope, go, ldgo, sums, count,
+                                      gu, ldgu, nullptr, nullptr);
+}
+
+extern "C" int vnp_edge_fused_gather_r1(hipStream_t st, const float* xu, const float* xv, const float* wu, const float* wv, const int* start,
+                                        const int* rev, long long Pu, int k, int C, const float* mean, const float* rstd, const float* gamma,
+                                        const float* beta, float negative_slope, const float* go, int ldgo, const float* sums, long long count,
+                                        float* gu, int ldgu)
+{
+    if (!wu || !wv) return VNP_EINVAL;
+    return vnp_edge_fused_gather_impl(st, xu, 1, xv, 1, start, rev, Pu, k, C, mean, rstd, gamma, beta, negative_slope, go, ldgo, sums, count,
+                                      gu, ldgu, wu, wv);
 }

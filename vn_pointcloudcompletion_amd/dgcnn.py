@@ -26,7 +26,12 @@ def edge_conv_rows(layer: VNLinearLeakyReLU, x_rows, nbr, k):
     if ops.SW.EDGE_FUSED:
         # ONE GEMM for u | v (x is read once, forward and backward), edge pre-activations u[nbr] + v recomputed inside each pass: the
         # [P*k*3, 2C'] tensor is never written
-        uv = ops.VNLinearFn.apply(x_rows, ops.EdgeWeightsFn.apply(Wf, Wd), None, 0)        # [P*3, 4C']: u (feat | dir), v (feat | dir)
+        Wuv = ops.EdgeWeightsFn.apply(Wf, Wd)                                              # [4C', C]: [Wu; Wv]
+        if C == 1 and ops.SW.EDGE_RANK1 and nbr.shape[0] * 3 == x_rows.shape[0]:
+            # the layer's input is the cloud itself: u | v = x Wuv^T is rebuilt from 12 bytes per point inside the passes
+            return ops.EdgeConvRank1Fn.apply(x_rows, Wuv, nbr, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
+                                             layer.negative_slope)
+        uv = ops.VNLinearFn.apply(x_rows, Wuv, None, 0)                                    # [P*3, 4C']: u (feat | dir), v (feat | dir)
         return ops.EdgeConvPackedFn.apply(uv, nbr, bn.weight, bn.bias, bn.running_mean, bn.running_var, layer.training,
                                           layer.negative_slope)
     Wu = torch.cat([Wf[:, :C], Wd[:, :C]], dim=0)                           # [2C', C]  (feat | dir)

@@ -34,6 +34,7 @@ class _Switches:
 
     # --- attributes only: fused kernel vs. the general path that serves the shapes it does not take -----------------------------
     EDGE_FUSED = True               # EdgeConv without its edge tensor (vnp_edge_fused) vs gather-add -> BatchNorm / leaky -> mean pool
+    EDGE_RANK1 = True               # ... and, for a one-channel input (the coordinates), without its per-point matrices either (EdgeConvRank1Fn)
     STATS_IN_EPILOGUE = True        # BatchNorm statistics from the GEMM's accumulators vs a vnp_vn_norm_stats pass
     POOL_FUSED_EPILOGUE = True      # VNLinear -> VNMaxPool in the GEMM epilogue vs two GEMMs + pool kernels
     POOL_SCREEN_PASS = "fp16"       # bracketing pass of the screened pool: one fp16 product, or "bf16x3"

@@ -303,6 +303,72 @@ class EdgeConvPackedFn(Function):
         return guv, None, S[1], S[0], None, None, None, None
 
 
+class EdgeConvRank1Fn(Function):
+    """EdgeConvPackedFn for a layer whose input is ONE VN channel, the points themselves (conv1 of VN_DGCNN_fps and of the VN-PoinTr
+    grouper, models/dgcnn.py:291, dgcnn_group.py:225): x [P*3, 1] coordinates in the rows layout, Wuv [4C', 1] = [Wu; Wv] (EdgeWeightsFn).
+    The per-point matrices u | v = x Wuv^T ([P*3, 4C'], 100 MB at 65536 points) are never formed: every pass rebuilds an edge's
+    pre-activations from the neighbour's and the centre's 12 bytes of coordinates (vnp_edge_fused_r1) instead of gathering 24 C' bytes per
+    edge and channel block — the gathers were what bounded the passes.  Same bits as the general form."""
+
+    @staticmethod
+    def forward(ctx, x, Wuv, nbr, gamma, beta, running_mean, running_var, training, ns):
+        x = _rows(x).contiguous()
+        nbr = nbr.contiguous()
+        Wuv = Wuv.contiguous()
+        Pq, k = nbr.shape
+        C = Wuv.shape[0] // 4
+        if x.shape[1] != 1 or Wuv.shape[1] != 1 or x.shape[0] != Pq * 3:
+            raise _lib.VnpError("EdgeConvRank1Fn: one input channel and a graph on the layer's own points expected")
+        dev = x.device
+        wu, wv = Wuv[:2 * C], Wuv[2 * C:]
+        qb = _lib.lib().vnp_edge_block_queries()
+        nblk = (Pq + qb - 1) // qb
+        if training:
+            part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
+            call("vnp_edge_fused_r1", 0, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
+                 ptr(part), None, 0, None, 0, None, 0, None, 0)
+            mean = torch.empty(C, device=dev, dtype=torch.float32)
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
+                 ptr(running_var), BN_MOMENTUM, BN_EPS)
+        else:
+            mean = running_mean
+            rstd = torch.empty(C, device=dev, dtype=torch.float32)
+            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
+        out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
+        call("vnp_edge_fused_r1", 1, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+             float(ns), None, ptr(out), C, None, 0, None, 0, None, 0)
+        trace("edge_conv_rank1")
+        ctx.save_for_backward(x, Wuv, nbr, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), float(ns), nblk)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        x, Wuv, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, ns, nblk = ctx.cfg
+        go = _rows(go)
+        Pq, k = nbr.shape
+        C = Wuv.shape[0] // 4
+        wu, wv = Wuv[:2 * C], Wuv[2 * C:]
+        part = torch.empty((nblk, C, 2), device=go.device, dtype=torch.float32)
+        call("vnp_edge_fused_r1", 2, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0)
+        S, planar = reduce_pairs(part, nblk, C)
+        sums = ptr(S) if training else None
+        guv = torch.empty((Pq * 3, 4 * C), device=go.device, dtype=torch.float32)
+        gu, gv = guv[:, :2 * C], guv[:, 2 * C:]
+        start, rev = edge_reverse(nbr, Pq)
+        call("vnp_edge_fused_r1", 3, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
+             None, None, 0, ptr(go), _ld(go), sums, Pq * k, ptr(gv), _ld(gv))
+        call("vnp_edge_fused_gather_r1", ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(start), ptr(rev), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma),
+             ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
+        gW = _wgrad(guv, x) if ctx.needs_input_grad[1] else None                 # [4C', 1] = guv^T x
+        gx = _dgrad(guv, Wuv) if ctx.needs_input_grad[0] else None               # [P*3, 1] (the input cloud rarely asks for it)
+        return gx, gW, None, planar[1], planar[0], None, None, None, None
+
+
 class EdgeWeightsFn(Function):
     """[Wu; Wv] [4C', C] of an EdgeConv layer from its VNLinearLeakyReLU weights Wf, Wd [C', 2C] (input channels: C of feature - x, then C
     of x): W cat(f_j - x, x) = W1 f_j + (W2 - W1) x, so Wu = [Wf1; Wd1] acts on the neighbour and Wv = [Wf2 - Wf1; Wd2 - Wd1] on the centre.
