@@ -335,7 +335,8 @@ int vnp_edge_fused_gather(hipStream_t st, const float* u, int ldu, const float* 
 /* vnp_edge_fused / vnp_edge_fused_gather for a layer whose input is ONE VN channel — the points themselves: conv1 of VN_DGCNN_fps and of
  * the VN-PoinTr grouper (models/dgcnn.py:291, models/pointr/utils/dgcnn_group.py:225).  xu [Pu*3], xv [Pq*3]: coordinates; wu, wv [2C]:
  * the single column of [Wu; Wv] (vnp_edge_weights).  u = x wu^T and v = x wv^T are never formed: an edge reads its neighbour's 12 bytes
- * instead of 24 C, and the product that formed them is gone.  Same bits as the general form on the formed matrices. */
+ * instead of 24 C, and the product that formed them is gone.  Forward passes: the same bits as the general form on the formed matrices;
+ * backward: the same arithmetic, equal to rounding (the compiler may contract a product and a sum differently in the two instantiations). */
 int vnp_edge_fused_r1(hipStream_t st, int mode, const float* xu, const float* xv, const float* wu, const float* wv, const int* nbr,
                       long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                       float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,

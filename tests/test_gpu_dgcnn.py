@@ -384,8 +384,8 @@ def test_edge_conv_on_the_cloud_itself_equals_the_general_form(lib_built, B, N, 
     names = ("out", "running_mean", "running_var", "gW", "ggamma", "gbeta", "gx")
     for nm, a, b in zip(names, run(True), run(False)):
         if nm in ("gW", "gx"):
-            # the two weight / input gradients are products over the same guv in both forms, but the general form reaches them through
-            # VNLinearFn's own launches: same kernels and shapes, so the same bits as well
-            assert torch.equal(a, b), nm
+            # products over the source points' gradient gu: the two instantiations of the gather kernel are free to contract a * b + c
+            # differently (one rounding more or less per edge term), so these agree to rounding, not to the bit
+            assert relerr(a, b) < 2e-6, (nm, relerr(a, b))
         else:
             assert torch.equal(a, b), nm

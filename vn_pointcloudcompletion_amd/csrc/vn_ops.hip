@@ -1182,10 +1182,14 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
     // and sqrtf, so statistics and outputs stay bit-identical to the materialising path
 #define EDIV(x, y) ((MODE >= 2 && VNP_GRAD_HW) ? (x) * __builtin_amdgcn_rcpf(y) : (x) / (y))
 #define ESQRT(x) ((MODE >= 2 && VNP_GRAD_HW) ? __builtin_amdgcn_sqrtf(x) : sqrtf(x))
-    __shared__ float2 red[4][64];
-    __shared__ int cnt[4];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx, C = a.C, k = a.k;
+    // 256 threads = CW channel lanes x NQ query lanes: 64 x 4, or 32 x 8 for a layer of at most 32 channels (conv1 of the encoders), whose
+    // second half of the channel lanes would otherwise idle through every edge
+    __shared__ float2 red[256];
+    __shared__ int cnt[8];
+    const int C = a.C, k = a.k;
+    const int CW = C <= 32 ? 32 : 64, NQ = 256 / CW;
+    const int cx = threadIdx.x & (CW - 1), py = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
     const long long q0 = (long long)blockIdx.y * VNP_EDGE_QB;
@@ -1198,7 +1202,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
     int wn = 0;
     float wup = 0.f, wud = 0.f, wvp = 0.f, wvd = 0.f;
     if (R1) { wup = a.wu[cc]; wud = a.wu[C + cc]; wvp = a.wv[cc]; wvd = a.wv[C + cc]; }
-    for (long long q = q0 + py; q < q1; q += 4) {
+    for (long long q = q0 + py; q < q1; q += NQ) {
         float vp0, vp1, vp2, vd0, vd1, vd2;
         if (R1) {
             const float* xq = a.v + (size_t)q * 3;
@@ -1286,25 +1290,29 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
         }
     }
     if (MODE == 0) {
-        red[py][cx] = make_float2(wmean, wm2);
+        red[py * CW + cx] = make_float2(wmean, wm2);
         if (cx == 0) cnt[py] = wn;
         __syncthreads();
         if (py == 0 && live) {
-            double na = cnt[0], ma = red[0][cx].x, Ma = red[0][cx].y;
-#pragma unroll
-            for (int j = 1; j < 4; ++j) {
-                if (na == 0.0) { na = cnt[j]; ma = red[j][cx].x; Ma = red[j][cx].y; }
-                else vnp_chan_merge(na, ma, Ma, (double)cnt[j], (double)red[j][cx].x, (double)red[j][cx].y);
+            double na = cnt[0], ma = red[cx].x, Ma = red[cx].y;
+            for (int j = 1; j < NQ; ++j) {
+                const float2 rj = red[j * CW + cx];
+                if (na == 0.0) { na = cnt[j]; ma = rj.x; Ma = rj.y; }
+                else vnp_chan_merge(na, ma, Ma, (double)cnt[j], (double)rj.x, (double)rj.y);
             }
             a.partial[(size_t)blockIdx.y * C + c] = make_float2((float)ma, (float)Ma);
         }
     }
     if (MODE == 2) {
-        red[py][cx] = make_float2(s1, s2);
+        red[py * CW + cx] = make_float2(s1, s2);
         __syncthreads();
         if (py == 0 && live) {
-            const float2 r0 = red[0][cx], r1 = red[1][cx], r2 = red[2][cx], r3 = red[3][cx];
-            a.partial[(size_t)blockIdx.y * C + c] = make_float2((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y));
+            float2 t[2];
+            for (int h = 0; h < NQ / 4; ++h) {                       // quads in lane order, then the two quads of the 32 x 8 form
+                const float2 r0 = red[(4 * h) * CW + cx], r1 = red[(4 * h + 1) * CW + cx], r2 = red[(4 * h + 2) * CW + cx], r3 = red[(4 * h + 3) * CW + cx];
+                t[h] = make_float2((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y));
+            }
+            a.partial[(size_t)blockIdx.y * C + c] = NQ == 4 ? t[0] : make_float2(t[0].x + t[1].x, t[0].y + t[1].y);
         }
     }
 }
@@ -1318,9 +1326,11 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
                                                                long long Pu)
 {
     constexpr int MODE = 3;
-    __shared__ double red[3][6][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx, C = a.C;
+    __shared__ double red[7 * 6 * 32];               // [NQ - 1][6][CW]: 64 channel lanes x 4 edge lanes, or 32 x 8 for C <= 32
+    const int C = a.C;
+    const int CW = C <= 32 ? 32 : 64, NQ = 256 / CW;
+    const int cx = threadIdx.x & (CW - 1), py = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
     const long long s0 = (long long)blockIdx.y * VNP_EDGE_SB;
@@ -1346,7 +1356,7 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
         double F0 = 0.0, F1 = 0.0, F2 = 0.0, E0 = 0.0, E1 = 0.0, E2 = 0.0;
         const int e1 = rstart[sp + 1];
 #pragma unroll 2
-        for (int e = rstart[sp] + py; e < e1; e += 4) {
+        for (int e = rstart[sp] + py; e < e1; e += NQ) {
             const size_t q = (size_t)rev[e];
             const float* rv = R1 ? a.v + q * 3 : a.v + q * 3 * a.ldv + cc;
             const float* rg = a.go + q * 3 * a.ldgo + cc;
@@ -1387,15 +1397,15 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
             E0 += (double)ee0; E1 += (double)ee1; E2 += (double)ee2;
         }
         if (py > 0) {
-            red[py - 1][0][cx] = F0; red[py - 1][1][cx] = F1; red[py - 1][2][cx] = F2;
-            red[py - 1][3][cx] = E0; red[py - 1][4][cx] = E1; red[py - 1][5][cx] = E2;
+            double* r = red + (size_t)(py - 1) * 6 * CW + cx;
+            r[0] = F0; r[CW] = F1; r[2 * CW] = F2; r[3 * CW] = E0; r[4 * CW] = E1; r[5 * CW] = E2;
         }
         __syncthreads();
         if (py == 0 && live) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                F0 += red[j][0][cx]; F1 += red[j][1][cx]; F2 += red[j][2][cx];
-                E0 += red[j][3][cx]; E1 += red[j][4][cx]; E2 += red[j][5][cx];
+            for (int j = 0; j < NQ - 1; ++j) {
+                const double* r = red + (size_t)j * 6 * CW + cx;
+                F0 += r[0]; F1 += r[CW]; F2 += r[2 * CW];
+                E0 += r[3 * CW]; E1 += r[4 * CW]; E2 += r[5 * CW];
             }
             float* w = a.gu + (size_t)sp * 3 * a.ldgu + c;
             w[0] = (float)F0; w[a.ldgu] = (float)F1; w[2 * a.ldgu] = (float)F2;
@@ -1893,7 +1903,7 @@ static int vnp_edge_fused_impl(hipStream_t st, int mode, const float* u, int ldu
         if (out) s.out = out + (size_t)qoff * 3 * ldo;
         if (go) s.go = go + (size_t)qoff * 3 * ldgo;
         if (gv) s.gv = gv + (size_t)qoff * 3 * ldgv;
-        const dim3 grid(vnp_cdiv(C, 64), nb), block(256);
+        const dim3 grid(vnp_cdiv(C, C <= 32 ? 32 : 64), nb), block(256);
         if (r1) switch (mode) {
         case 0: hipLaunchKernelGGL((vnp_edge_fused_kernel<0, true>), grid, block, 0, st, s); break;
         case 1: hipLaunchKernelGGL((vnp_edge_fused_kernel<1, true>), grid, block, 0, st, s); break;
@@ -1922,7 +1932,7 @@ extern "C" int vnp_edge_fused(hipStream_t st, int mode, const float* u, int ldu,
 // The same passes for a layer whose input is ONE VN channel, the points themselves (conv1 of the encoders: models/dgcnn.py:291,
 // dgcnn_group.py:225): xu [Pu*3], xv [Pq*3] coordinates, wu, wv [2C] the columns of [Wu; Wv] (vnp_edge_weights with one input channel).
 // The per-point matrices u = x wu^T, v = x wv^T are never formed: an edge reads its neighbour's 12 bytes instead of 24 C.
-// Same bits as vnp_edge_fused on the formed matrices.
+// Forward: the same bits as vnp_edge_fused on the formed matrices; backward: equal to rounding.
 extern "C" int vnp_edge_fused_r1(hipStream_t st, int mode, const float* xu, const float* xv, const float* wu, const float* wv, const int* nbr,
                                  long long Pq, int k, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                  float negative_slope, float* partial, float* out, int ldo, const float* go, int ldgo,
@@ -1974,8 +1984,9 @@ static int vnp_edge_fused_gather_impl(hipStream_t st, const float* u, int ldu, c
         const long long soff = b0 * VNP_EDGE_SB;
         s.u = u + (size_t)soff * 3 * ldu; s.gu = gu + (size_t)soff * 3 * ldgu;
         const long long np = (Pu - soff) < (long long)nb * VNP_EDGE_SB ? (Pu - soff) : (long long)nb * VNP_EDGE_SB;
-        if (wu) hipLaunchKernelGGL((vnp_edge_gather_u_kernel<true>), dim3(vnp_cdiv(C, 64), nb), dim3(256), 0, st, s, start + soff, rev, np);
-        else    hipLaunchKernelGGL((vnp_edge_gather_u_kernel<false>), dim3(vnp_cdiv(C, 64), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        const int cw = C <= 32 ? 32 : 64;
+        if (wu) hipLaunchKernelGGL((vnp_edge_gather_u_kernel<true>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        else    hipLaunchKernelGGL((vnp_edge_gather_u_kernel<false>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
     }
     return vnp_last_error();
 }

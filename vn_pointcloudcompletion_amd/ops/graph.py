@@ -308,7 +308,7 @@ class EdgeConvRank1Fn(Function):
     grouper, models/dgcnn.py:291, dgcnn_group.py:225): x [P*3, 1] coordinates in the rows layout, Wuv [4C', 1] = [Wu; Wv] (EdgeWeightsFn).
     The per-point matrices u | v = x Wuv^T ([P*3, 4C'], 100 MB at 65536 points) are never formed: every pass rebuilds an edge's
     pre-activations from the neighbour's and the centre's 12 bytes of coordinates (vnp_edge_fused_r1) instead of gathering 24 C' bytes per
-    edge and channel block — the gathers were what bounded the passes.  Same bits as the general form."""
+    edge and channel block — the gathers were what bounded the passes.  Forward: the same bits as the general form; gradients: to rounding."""
 
     @staticmethod
     def forward(ctx, x, Wuv, nbr, gamma, beta, running_mean, running_var, training, ns):
