@@ -39,6 +39,7 @@ class Attention_VN_FoldingNet(nn.Module):
         self.vn_folding2 = nn.Sequential(VNLinearLeakyReLU(in_channel + 1, hidden_dim, dim=4),
                                          VNLinearLeakyReLU(hidden_dim, hidden_dim // 2, dim=4), VNLinear(hidden_dim // 2, 1))
 
+    _ones = None             # [384, 1] of ones on the device (the unit weight of the token build), made once
     FUSED_TAIL = True        # stage[1] + stage[2] as one function (ops.VNLinearLeakyOutFn); False: layer by layer (tests)
 
     @classmethod
@@ -59,12 +60,17 @@ class Attention_VN_FoldingNet(nn.Module):
         bs, N, _ = coarse.shape
         S = self.grid_size ** 2
         coarse = coarse.float()
-        # pcn.py:466: expand + RESHAPE (memory-order re-chunking), then transpose -> [bs, N, 1152]
-        centers = coarse.unsqueeze(1).expand(-1, 384, -1, -1).reshape(bs, -1, N).transpose(2, 1)
         g = self.downsize_global.forward_rows(global_to_rows(feature_global.float()))                # [bs*3, 384]
-        # pcn.py:467: [bs,384,3,1].expand(N).reshape(bs,1152,N).transpose -> tokens with feature index c*3+t
-        tok = g.reshape(bs, 3, 384).permute(0, 2, 1).reshape(bs, 1, 1152).expand(-1, N, -1) + centers
-        rows = tokens_to_rows(tok, 384)                                                              # [bs*N*3, 384]
+        # pcn.py:466-469: the centres are added through expand(384) + RESHAPE (memory-order re-chunking) + transpose, which works out to
+        # token (b, n), feature (c, t) <- coarse[b].flatten()[t N + n], the same for every channel c; with the per-sample part g (the
+        # down-sized global feature, feature index c*3+t, pcn.py:467) the block input in the rows layout is
+        #   rows[(b, n, t), c] = s[b, n, t] + g[(b, t), c],   s[b, n, t] = coarse[b].flatten()[t N + n]
+        # i.e. a one-channel VNLinear with weight 1 and a per-sample bias: one K = 1 product (vnp_gemm_rank1) instead of two 75 MB copies and
+        # an addition forward, three full-size sums backward (tests/test_gpu_attention_emd.py::test_attention_decoder_matches_reference)
+        s = coarse.reshape(bs, 3, N).transpose(1, 2).reshape(bs * N * 3, 1)
+        if self._ones is None or self._ones.device != coarse.device:
+            self._ones = torch.ones((384, 1), device=coarse.device, dtype=torch.float32)
+        rows = ops.VNLinearFn.apply(s.contiguous(), self._ones, g, N * 3)                            # [bs*N*3, 384]
         carry = None
         for blk in self.transformer:                                     # a block's output stays the pair (skip stream, MLP branch) until
             rows, carry = blk.forward_rows_split(rows, bs, N, carry=carry)   # the next LayerNorm pass (or the add below) sums it
