@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""A/B in one process: step time of configs 2..5 with the coarse loss on a side stream beside the decoder (train.COARSE_LOSS_AHEAD) and
+after it on the main stream, alternating blocks of steps."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from types import SimpleNamespace
+import torch
+from vn_pointcloudcompletion_amd import train as T
+from vn_pointcloudcompletion_amd.model import PCNNet
+from vn_pointcloudcompletion_amd.optim import FusedAdam
+CONFIGS = {
+    2: dict(enc="vn_pointnet", dec="vn_foldingnet", B=32, latent=2048, loss="cd", mc=1024),
+    3: dict(enc="vn_dgcnn_fps", dec="vn_foldingnet", B=32, latent=512, loss="cd", mc=1024, knn_k=20),
+    4: dict(enc="vn_pointnet", dec="attention_vn_foldingnet", B=16, latent=2048, loss="emd", mc=1024),
+    5: dict(enc="vn_pointr", dec="vn_foldingnet", B=32, latent=1024, loss="cd", mc=1024),
+}
+for cid in [int(a) for a in sys.argv[1:]] or [2, 4, 5]:
+    c = CONFIGS[cid]
+    cfg = SimpleNamespace(num_coarse=c["mc"], latent_dim=c["latent"], only_coarse=False, enc_pretrained="none", device="cuda:0",
+                          coarse_loss=c["loss"], dcd_opts={"alpha": 200, "lambda": 0.5}, knn_k=c.get("knn_k", 16))
+    torch.manual_seed(0)
+    net = PCNNet(cfg, c["enc"], c["dec"]).train()
+    md = getattr(net.decoder, "num_dense", 16384)
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    g = torch.Generator().manual_seed(1)
+    p = (torch.rand(c["B"], 2048, 3, generator=g) - 0.5).cuda()
+    gt = (torch.rand(c["B"], md, 3, generator=g) - 0.5).cuda()
+    for _ in range(5):
+        T.train_step(cfg, net, opt, p, gt)
+    res = {True: [], False: []}
+    for rnd in range(6):
+        for flag in (True, False):
+            T.COARSE_LOSS_AHEAD = ("cd", "emd", "dcd") if flag else ()
+            T.train_step(cfg, net, opt, p, gt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                T.train_step(cfg, net, opt, p, gt)
+            torch.cuda.synchronize()
+            res[flag].append((time.perf_counter() - t0) / 10 * 1e3)
+    print(f"config {cid}: ahead {min(res[True]):.2f} (median {sorted(res[True])[3]:.2f}) ms, after {min(res[False]):.2f} (median {sorted(res[False])[3]:.2f}) ms", flush=True)
+    del net, opt
+    torch.cuda.empty_cache()

@@ -426,3 +426,42 @@ def test_add_layernorm_equals_the_adds_and_the_layernorm(lib_built, P, C, na):
         return [s.detach(), y.detach()] + [v.grad for v in xs] + [gam.grad, bet.grad]
     for a, b in zip(run(True), run(False)):
         assert torch.equal(a, b)
+
+
+def test_coarse_emd_loss_beside_the_decoder_is_the_same_step(lib_built):
+    """train.train_step starts an EMD coarse loss on a side HIP stream the moment the encoder's output exists (PCNNet's on_coarse hook) and
+    lets it run beside the decoder.  From the same state and batches: two runs taken that way agree bit for bit over three steps (a
+    missing stream dependency — a loss computed on stale coordinates, a gradient read before it was written — would differ from run to
+    run or be plainly wrong), and they agree with the run that computes the loss after the forward on the main stream: the three losses
+    bit for bit, the flat gradient to rounding (the loss's node is created earlier in the graph, so autograd adds the coarse cloud's three
+    gradient contributions in another order)."""
+    import copy
+    from vn_pointcloudcompletion_amd import train as T
+    from vn_pointcloudcompletion_amd.model import PCNNet
+    from vn_pointcloudcompletion_amd.optim import FusedAdam
+    cfg = SimpleNamespace(num_coarse=1024, latent_dim=2048, only_coarse=False, enc_pretrained="none", device="cuda",
+                          coarse_loss="emd", dcd_opts={"alpha": 200, "lambda": 0.5})
+    torch.manual_seed(0)
+    ref_net = PCNNet(cfg, "vn_pointnet", "attention_vn_foldingnet").train()
+    g = torch.Generator().manual_seed(3)
+    batches = [((torch.rand(2, 2048, 3, generator=g) - 0.5).cuda(), (torch.rand(2, 16384, 3, generator=g) - 0.5).cuda()) for _ in range(3)]
+    runs = []
+    old = T.COARSE_LOSS_AHEAD
+    try:
+        for ahead in (("emd",), ("emd",), ()):
+            T.COARSE_LOSS_AHEAD = ahead
+            net = copy.deepcopy(ref_net)
+            opt = FusedAdam(net.parameters(), lr=1e-3)
+            rec = []
+            for p, c in batches[:1 if ahead == () else 3]:       # later steps start from weights that already differ by rounding
+                losses = T.train_step(cfg, net, opt, p, c)
+                torch.cuda.synchronize()
+                rec.append((torch.stack(losses).clone(), opt.flat_buffers[0].flat_grad.clone()))
+            runs.append(rec)
+    finally:
+        T.COARSE_LOSS_AHEAD = old
+    for (la, ga), (lb, gb) in zip(runs[0], runs[1]):
+        assert torch.equal(la, lb) and torch.equal(ga.view(torch.int32), gb.view(torch.int32))
+    (la, ga), (lc, gc) = runs[0][0], runs[2][0]
+    assert torch.equal(la, lc)
+    assert relerr(ga, gc) < 1e-5, relerr(ga, gc)

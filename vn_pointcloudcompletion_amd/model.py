@@ -61,20 +61,27 @@ class PCNNet(nn.Module):
                 # construction): num_coarse = 1248, num_dense = 19968; config.latent_dim must be 1024.
                 self.decoder.num_coarse, self.decoder.num_dense = 1248, 1248 * 16
 
-    def forward(self, input, rot=None):
+    def forward(self, input, rot=None, on_coarse=None):
+        """``on_coarse(coarse_pred)``: called as soon as the encoder has produced the coarse cloud, before the decoder runs — the training
+        step starts the coarse loss there on a side stream (train.train_step), beside the decoder's launches.  Not part of the
+        reference's signature; without it the forward is the reference's."""
         prev = vn_layers.begin_deferred_ticks()          # all BatchNorm step counters of this forward in one launch at its end
         try:
-            return self._forward(input, rot)
+            return self._forward(input, rot, on_coarse)
         finally:
             vn_layers.end_deferred_ticks(prev)
 
-    def _forward(self, input, rot=None):
+    def _forward(self, input, rot=None, on_coarse=None):
         coarse, feature_global = self.encoder(input)
         if self.num_coarse == 448:
+            if on_coarse is not None:
+                on_coarse(coarse[1])
             if self.only_coarse:
                 return coarse[1], None
             fine = self.decoder(coarse[0], feature_global, rot)
             return coarse[1], fine
+        if on_coarse is not None:
+            on_coarse(coarse)
         if self.only_coarse:
             return coarse, None
         fine = self.decoder(coarse, feature_global, rot)

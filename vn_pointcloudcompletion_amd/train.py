@@ -47,20 +47,26 @@ def make_rotation(kind, batch, device):
     return None
 
 
-def compute_losses(config, coarse_pred, dense_pred, c):
-    """train.py:146-167: returns (loss, loss1, loss2)."""
+def coarse_loss(config, coarse_pred, c):
+    """train.py:146-155: the loss on the coarse cloud."""
     if config.coarse_loss == "cd":
-        loss1 = cd_loss_L1(coarse_pred, c)
-    elif config.coarse_loss == "emd":
-        loss1 = emd_loss(coarse_pred, c[:, :1024, :])
-    elif config.coarse_loss == "dcd":
+        return cd_loss_L1(coarse_pred, c)
+    if config.coarse_loss == "emd":
+        return emd_loss(coarse_pred, c[:, :1024, :])
+    if config.coarse_loss == "dcd":
         opts = config.dcd_opts
         t_alpha = opts["alpha"] if isinstance(opts, dict) else opts.alpha
         n_lambda = opts["lambda"] if isinstance(opts, dict) else getattr(opts, "lambda")
         loss1, _, _ = calc_dcd(coarse_pred, c, alpha=t_alpha, n_lambda=n_lambda)
-        loss1 = loss1.mean()
-    else:
-        raise ValueError("Not implemented loss {}".format(config.coarse_loss))
+        return loss1.mean()
+    raise ValueError("Not implemented loss {}".format(config.coarse_loss))
+
+
+def compute_losses(config, coarse_pred, dense_pred, c, loss1=None):
+    """train.py:146-167: returns (loss, loss1, loss2).  ``loss1``: the coarse loss when it has been computed already (train_step starts it
+    beside the decoder)."""
+    if loss1 is None:
+        loss1 = coarse_loss(config, coarse_pred, c)
     if config.only_coarse:
         return loss1, loss1, torch.zeros((), device=loss1.device)
     loss2 = cd_loss_L1(dense_pred, c)
@@ -90,13 +96,44 @@ def _one_like(loss):
     return t
 
 
+_LOSS_STREAMS = {}
+# which coarse losses are started on a side HIP stream beside the decoder's forward.  Measured on MI355X, alternating blocks of steps in one
+# process (scripts/experiments/ab_coarse_ahead.py): EMD — 41 dependent, latency-bound launches — 24.58 -> 23.93 ms per step of config 4;
+# the Chamfer losses — one VALU-bound search that fills the chip — LOSE when interleaved with the decoder (config 2 17.16 -> 17.60 ms,
+# config 3 17.42 -> 17.61): they stay on the main stream
+COARSE_LOSS_AHEAD = ("emd",)
+
+
 def train_step(config, model, optimizer, p, c, trot=None, loss_weight=1.0):
     """One iteration of the hot loop (train.py:140-173): zero_grad, forward, losses, backward, gradient all-reduce
     (world > 1), Adam.  Returns the three loss tensors (on device, no host sync).  ``loss_weight`` scales the gradient of an
-    uneven data-parallel shard (ShardedBatchSampler.weight); the returned losses are unscaled."""
+    uneven data-parallel shard (ShardedBatchSampler.weight); the returned losses are unscaled.
+    The coarse loss depends on the encoder's output alone: an EMD loss (41 dependent launches: latency) is started on a side stream the
+    moment that output exists (PCNNet's ``on_coarse`` hook) and runs beside the decoder; autograd runs its backward on the same side
+    stream (COARSE_LOSS_AHEAD)."""
     optimizer.zero_grad()
-    coarse_pred, dense_pred = model(p, trot)
-    loss, loss1, loss2 = compute_losses(config, coarse_pred, dense_pred, c)
+    ahead = config.coarse_loss in COARSE_LOSS_AHEAD and p.is_cuda and isinstance(model, PCNNet) and not model.only_coarse
+    if ahead:
+        main = torch.cuda.current_stream(p.device)
+        side = _LOSS_STREAMS.get(p.device.index)
+        if side is None:
+            side = _LOSS_STREAMS[p.device.index] = torch.cuda.Stream(device=p.device)
+        box = []
+
+        def on_coarse(coarse_pred):
+            side.wait_stream(main)                       # the encoder's launches produced coarse_pred on the main stream
+            coarse_pred.record_stream(side)
+            c.record_stream(side)
+            with torch.cuda.stream(side):
+                box.append(coarse_loss(config, coarse_pred, c))
+        coarse_pred, dense_pred = model(p, trot, on_coarse=on_coarse)
+        main.wait_stream(side)
+        if box:
+            box[0].record_stream(main)
+        loss, loss1, loss2 = compute_losses(config, coarse_pred, dense_pred, c, loss1=box[0] if box else None)
+    else:
+        coarse_pred, dense_pred = model(p, trot)
+        loss, loss1, loss2 = compute_losses(config, coarse_pred, dense_pred, c)
     (loss if loss_weight == 1.0 else loss * loss_weight).backward(gradient=_one_like(loss))
     D.allreduce_gradients(optimizer)
     optimizer.step()
