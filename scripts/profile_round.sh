@@ -9,7 +9,7 @@ set -e
 tag=${1:-r02}
 root=$(pwd)
 out=$root/gpurun_out/$tag
-rm -rf $out          # gpurun merges into gpurun_out/: an earlier pass of the same tag would be summarised along with this one
+rm -rf $out          # (on the box; the LOCAL gpurun_out/<tag> of an earlier pass must be removed by hand before the call: gpurun merges into it and the summaries would mix the two)
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 B="$root/bench.py --no-cpu-baseline --no-fp32-mode --no-extras"
