@@ -1172,6 +1172,18 @@ struct VnpEdgeArgs {
 };
 #define VNP_EDGE_QB 64                         // queries per block
 
+// Workgroup w of a launch runs on XCD w % 8, each with its own 4 MB L2.  The EdgeConv passes gather rows of u / v / go that belong to the
+// block's own cloud (a few hundred KB to a few MB per cloud and channel block), so the blocks of one cloud should share an L2: logical
+// block L = (blocks of XCD 0, then of XCD 1, ...) — XCD x takes a contiguous run of T/8 logical blocks, i.e. of whole clouds — instead of
+// the dispatch order that deals a cloud's blocks out to all eight.  Bijective for any T.
+__device__ __forceinline__ void vnp_xcd_block(int& bx, int& by)
+{
+    const unsigned gx = gridDim.x, T = gx * gridDim.y, w = blockIdx.y * gx + blockIdx.x;
+    const unsigned q8 = T >> 3, r8 = T & 7u, xcd = w & 7u, i = w >> 3;
+    const unsigned L = xcd * q8 + (xcd < r8 ? xcd : r8) + i;
+    bx = (int)(L % gx); by = (int)(L / gx);
+}
+
 // one rounding of the product and no contraction with the addition behind it: the bits of the stored u = x W^T (a K = 1 product)
 __device__ __forceinline__ float vnp_mul_alone(float a, float b) { float p = a * b; asm volatile("" : "+v"(p)); return p; }
 
@@ -1189,10 +1201,12 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
     const int C = a.C, k = a.k;
     const int CW = C <= 32 ? 32 : 64, NQ = 256 / CW;
     const int cx = threadIdx.x & (CW - 1), py = threadIdx.x / CW;
-    const int c = blockIdx.x * CW + cx;
+    int bx, by;
+    vnp_xcd_block(bx, by);
+    const int c = bx * CW + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
-    const long long q0 = (long long)blockIdx.y * VNP_EDGE_QB;
+    const long long q0 = (long long)by * VNP_EDGE_QB;
     const long long q1 = min(a.Pq, q0 + VNP_EDGE_QB);
     float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, m1 = 0.f, m2 = 0.f;
     if (MODE >= 1) { mu = a.mean[cc]; rs = a.rstd[cc]; ga = a.gamma[cc]; be = a.beta[cc]; }
@@ -1300,7 +1314,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
                 if (na == 0.0) { na = cnt[j]; ma = rj.x; Ma = rj.y; }
                 else vnp_chan_merge(na, ma, Ma, (double)cnt[j], (double)rj.x, (double)rj.y);
             }
-            a.partial[(size_t)blockIdx.y * C + c] = make_float2((float)ma, (float)Ma);
+            a.partial[(size_t)by * C + c] = make_float2((float)ma, (float)Ma);
         }
     }
     if (MODE == 2) {
@@ -1312,7 +1326,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
                 const float2 r0 = red[(4 * h) * CW + cx], r1 = red[(4 * h + 1) * CW + cx], r2 = red[(4 * h + 2) * CW + cx], r3 = red[(4 * h + 3) * CW + cx];
                 t[h] = make_float2((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y));
             }
-            a.partial[(size_t)blockIdx.y * C + c] = NQ == 4 ? t[0] : make_float2(t[0].x + t[1].x, t[0].y + t[1].y);
+            a.partial[(size_t)by * C + c] = NQ == 4 ? t[0] : make_float2(t[0].x + t[1].x, t[0].y + t[1].y);
         }
     }
 }
@@ -1330,10 +1344,12 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
     const int C = a.C;
     const int CW = C <= 32 ? 32 : 64, NQ = 256 / CW;
     const int cx = threadIdx.x & (CW - 1), py = threadIdx.x / CW;
-    const int c = blockIdx.x * CW + cx;
+    int bx, by;
+    vnp_xcd_block(bx, by);
+    const int c = bx * CW + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
-    const long long s0 = (long long)blockIdx.y * VNP_EDGE_SB;
+    const long long s0 = (long long)by * VNP_EDGE_SB;
     const long long s1 = min(Pu, s0 + VNP_EDGE_SB);
     const float mu = a.mean[cc], rs = a.rstd[cc], ga = a.gamma[cc], be = a.beta[cc];
     float m1 = 0.f, m2 = 0.f;
