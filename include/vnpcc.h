@@ -268,7 +268,7 @@ int vnp_vn_pool_bwd_acc(hipStream_t st, const float* gout, int ldgo, const int* 
                         float* gx, int ldgx);
 /* Backward of VNLinear followed by VNMaxPool (models/pcn.py:169-170,173-174) without the dense gradient of the linear output:
  * gW[Co][Ci] = sum_{g,t} gout[g*3+t][o] x[(g*gs+idx[g][o])*3+t][:]   (NULL: skip)
- * gx[G*gs*3][Ci] (zero-filled here) gets, for every selected point, sum_{o: idx[g][o]==n} gout[g*3+t][o] W[o][:]   (NULL: skip)
+ * gx[G*gs*3][Ci] (every row written, zeros for a point no channel selected: no fill beforehand) gets, for every selected point, sum_{o: idx[g][o]==n} gout[g*3+t][o] W[o][:]   (NULL: skip)
  * order/pts [G][Co]: channels of each group sorted by arg-max point, and those points (ascending). */
 int vnp_pool_lin_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx, const int* order, const int* pts,
                      const float* x, int ldx, const float* W, int ldw, int G, int gs, int Co, int Ci,
@@ -447,7 +447,7 @@ int vnp_unit_dirs_r(hipStream_t st, const float* xyz, long long P, float* u, flo
 /* VNLinear -> VNMaxPool on a map u (x) h (maxpool1 behind the single-channel first layer, models/pcn.py:168-169): y [P][ldy] holds
  * y = h W^T in columns [0, C) and y' = h (Wd W)^T in [C, 2C); the score of a point is y y'.  idx [G][C] = first arg-max inside each
  * group of gs consecutive points, out [G*3][ldo] = u[n*][t] y[n*][c].  _bwd: the gradient of y has one entry per (group, channel);
- * gW (nullable) [C][ldgw] = dL/dW, gh (nullable) [G*gs][ldgh] = dL/dh (zero-filled inside); order / pts [G][C]: the channels of a
+ * gW (nullable) [C][ldgw] = dL/dW, gh (nullable) [G*gs][ldgh] = dL/dh (every row written); order / pts [G][C]: the channels of a
  * group sorted by their picked point, and that point (stable sort of idx, as for vnp_pool_lin_bwd). */
 int vnp_dir_pool_fwd(hipStream_t st, const float* y, int ldy, const float* u, long long G, int gs, int C, int* idx, float* out, int ldo);
 int vnp_dir_pool_bwd(hipStream_t st, const float* gout, int ldgo, const float* u, const int* idx, const int* order, const int* pts,

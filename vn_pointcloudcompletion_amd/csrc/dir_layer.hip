@@ -350,34 +350,39 @@ __global__ void __launch_bounds__(256) vnp_dir_pool_bwd_w_kernel(const float* __
 }
 
 // gh[n][:] = sum over the channels that picked point n of gy W[c][:]; `order`[g][j] lists the channels of group g sorted by their
-// picked point, `pts`[g][j] that point: block (j, g) owns the run of equal points starting at j (blocks inside a run exit), so every
-// picked point's row is written exactly once, without atomics; all other rows of gh were zero-filled beforehand (as vnp_pool_lin_bwd)
+// picked point, `pts`[g][j] that point (ascending): block (n, g) owns point n, finds its run in `pts` by bisection and writes the point's
+// row — the sum over the run, or zeros for a point no channel picked: every row written exactly once, no atomics, no zero fill beforehand
+// (as vnp_pool_lin_bwd)
 __global__ void __launch_bounds__(128) vnp_dir_pool_bwd_x_kernel(const float* __restrict__ gout, int ldgo, const float* __restrict__ u,
                                                                 const int* __restrict__ order, const int* __restrict__ pts,
                                                                 const float* __restrict__ W, int ldw, int gs, int C, int Ci,
                                                                 float* __restrict__ gh, int ldgh)
 {
-    const int j0 = blockIdx.x, g = blockIdx.y;
+    const int n0 = blockIdx.x * 16, g = blockIdx.y;                    // 16 consecutive points per block: one bisection, then a walk
+    const int n1 = n0 + 16 < gs ? n0 + 16 : gs;
     const int* pg = pts + (size_t)g * C;
-    const int nloc = pg[j0];
-    if (j0 > 0 && pg[j0 - 1] == nloc) return;
-    int j1 = j0 + 1;
-    while (j1 < C && pg[j1] == nloc) ++j1;
+    int lo = 0, hi = C;                               // first j with pg[j] >= n0
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (pg[mid] < n0) lo = mid + 1; else hi = mid; }
     const int* og = order + (size_t)g * C;
-    const size_t n = (size_t)g * gs + nloc;
-    const float u0 = u[n * 3], u1 = u[n * 3 + 1], u2 = u[n * 3 + 2];
-    for (int k = threadIdx.x; k < Ci; k += 128) {
-        float acc = 0.f;
-        for (int j = j0; j < j1; ++j) {
-            const int c = og[j];
-            const float gy = u0 * gout[((size_t)g * 3) * ldgo + c] + u1 * gout[((size_t)g * 3 + 1) * ldgo + c] + u2 * gout[((size_t)g * 3 + 2) * ldgo + c];
-            acc += gy * W[(size_t)c * ldw + k];
+    int j1 = lo;
+    for (int nloc = n0; nloc < n1; ++nloc) {
+        const int j0 = j1;
+        while (j1 < C && pg[j1] == nloc) ++j1;        // an empty run stores zeros below
+        const size_t n = (size_t)g * gs + nloc;
+        const float u0 = u[n * 3], u1 = u[n * 3 + 1], u2 = u[n * 3 + 2];
+        for (int k = threadIdx.x; k < Ci; k += 128) {
+            float acc = 0.f;
+            for (int j = j0; j < j1; ++j) {
+                const int c = og[j];
+                const float gy = u0 * gout[((size_t)g * 3) * ldgo + c] + u1 * gout[((size_t)g * 3 + 1) * ldgo + c] + u2 * gout[((size_t)g * 3 + 2) * ldgo + c];
+                acc += gy * W[(size_t)c * ldw + k];
+            }
+            gh[n * ldgh + k] = acc;
         }
-        gh[n * ldgh + k] = acc;
     }
 }
 
-// gW (nullable) [C][ldgw], gh (nullable) [G gs][ldgh] (zero-filled here); order / pts [G][C] int32 from a stable sort of idx per group
+// gW (nullable) [C][ldgw], gh (nullable) [G gs][ldgh] (every row written); order / pts [G][C] int32 from a stable sort of idx per group
 extern "C" int vnp_dir_pool_bwd(hipStream_t st, const float* gout, int ldgo, const float* u, const int* idx, const int* order, const int* pts,
                                 const float* h, int ldh, const float* W, int ldw, long long G, int gs, int C, int Ci,
                                 float* gW, int ldgw, float* gh, int ldgh)
@@ -389,10 +394,7 @@ extern "C" int vnp_dir_pool_bwd(hipStream_t st, const float* gout, int ldgo, con
     }
     if (gh) {
         if (!order || !pts || !W) return VNP_EINVAL;
-        hipError_t e = ldgh == Ci ? hipMemsetAsync(gh, 0, (size_t)G * gs * Ci * 4, st)
-                                  : hipMemset2DAsync(gh, (size_t)ldgh * 4, 0, (size_t)Ci * 4, (size_t)G * gs, st);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(vnp_dir_pool_bwd_x_kernel, dim3(C, (unsigned)G), dim3(128), 0, st, gout, ldgo, u, order, pts, W, ldw, gs, C, Ci, gh, ldgh);
+        hipLaunchKernelGGL(vnp_dir_pool_bwd_x_kernel, dim3(vnp_cdiv(gs, 16), (unsigned)G), dim3(128), 0, st, gout, ldgo, u, order, pts, W, ldw, gs, C, Ci, gh, ldgh);
     }
     return vnp_last_error();
 }
