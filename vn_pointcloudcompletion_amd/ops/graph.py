@@ -203,17 +203,32 @@ def edge_reverse(nbr, Pu):
     return start, rev
 
 
-def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
-    """The two forward passes of the fused EdgeConv on u [Pu*3, >= 2C], v [Pq*3, >= 2C] (row strides free): (out, mean, rstd, nblk)."""
+def _edge_pass(mode, u, v, r1, nbr, C, bn, ns, partial=None, out=None, go=None, sums=None, gv=None):
+    """One pass of the fused EdgeConv (vnp_edge_fused modes 0-3) on the per-point matrices u | v, or — ``r1 = (wu, wv)`` — on the
+    coordinates themselves (u = v = x [P*3, 1], vnp_edge_fused_r1).  ``bn`` = (mean, rstd, gamma, beta) or None (mode 0)."""
     Pq, k = nbr.shape
-    C = u.shape[1] // 2
+    mean, rstd, gamma, beta = bn if bn is not None else (None, None, None, None)
+    tail = (ptr(partial), ptr(out), out.shape[1] if out is not None else 0, ptr(go), _ld(go) if go is not None else 0, sums,
+            Pq * k if mode == 3 else 0)
+    if r1 is None:
+        call("vnp_edge_fused", mode, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
+             float(ns), *tail, None, 0, 0, ptr(gv), _ld(gv) if gv is not None else 0)
+    else:
+        call("vnp_edge_fused_r1", mode, ptr(u), ptr(v), ptr(r1[0]), ptr(r1[1]), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma),
+             ptr(beta), float(ns), *tail, ptr(gv), _ld(gv) if gv is not None else 0)
+
+
+def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns, r1=None, C=None):
+    """The two forward passes of the fused EdgeConv on u [Pu*3, >= 2C], v [Pq*3, >= 2C] (row strides free) — or, with ``r1`` = (wu, wv)
+    [2C] and ``C`` given, on the coordinates u = v = x [P*3, 1]: (out, mean, rstd, nblk)."""
+    Pq, k = nbr.shape
+    C = u.shape[1] // 2 if C is None else C
     dev = u.device
     qb = _lib.lib().vnp_edge_block_queries()
     nblk = (Pq + qb - 1) // qb
     if training:
         part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
-        call("vnp_edge_fused", 0, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
-             ptr(part), None, 0, None, 0, None, 0, None, 0, 0, None, 0)
+        _edge_pass(0, u, v, r1, nbr, C, None, ns, partial=part)
         mean = torch.empty(C, device=dev, dtype=torch.float32)
         rstd = torch.empty(C, device=dev, dtype=torch.float32)
         call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
@@ -223,29 +238,31 @@ def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, traini
         rstd = torch.empty(C, device=dev, dtype=torch.float32)
         call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
     out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
-    call("vnp_edge_fused", 1, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
-         float(ns), None, ptr(out), C, None, 0, None, 0, None, 0, 0, None, 0)
+    _edge_pass(1, u, v, r1, nbr, C, (mean, rstd, gamma, beta), ns, out=out)
     return out, mean, rstd, nblk
 
 
-def _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv):
+def _edge_conv_backward(go, u, v, nbr, gamma, beta, mean, rstd, training, ns, nblk, gu, gv, r1=None, C=None):
     """The backward passes: fills gu [Pu*3, >= 2C] and gv [Pq*3, >= 2C] (row strides free: column halves of one buffer in the packed
-    form) and returns the per-channel sums as planar [2, C] rows (dL/dbeta, dL/dgamma)."""
+    form) and returns the per-channel sums as planar [2, C] rows (dL/dbeta, dL/dgamma).  ``r1`` / ``C`` as in _edge_conv_forward."""
     Pq, k = nbr.shape
-    C = u.shape[1] // 2
+    C = u.shape[1] // 2 if C is None else C
     Pu = u.shape[0] // 3
+    bn = (mean, rstd, gamma, beta)
     part = torch.empty((nblk, C, 2), device=go.device, dtype=torch.float32)
-    call("vnp_edge_fused", 2, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-         ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0, 0, None, 0)
+    _edge_pass(2, u, v, r1, nbr, C, bn, ns, partial=part, go=go)
     S, planar = reduce_pairs(part, nblk, C)
     sums = ptr(S) if training else None
     # gv per query; gu per SOURCE point through the reverse adjacency (built once per graph: conv4 / conv5 share theirs) — a gather
     # with plain stores instead of float atomics
     start, rev = edge_reverse(nbr, Pu)
-    call("vnp_edge_fused", 3, ptr(u), _ld(u), ptr(v), _ld(v), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-         None, None, 0, ptr(go), _ld(go), sums, Pq * k, None, 0, 0, ptr(gv), _ld(gv))
-    call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
-         ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
+    _edge_pass(3, u, v, r1, nbr, C, bn, ns, go=go, sums=sums, gv=gv)
+    if r1 is None:
+        call("vnp_edge_fused_gather", ptr(u), _ld(u), ptr(v), _ld(v), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd), ptr(gamma),
+             ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
+    else:
+        call("vnp_edge_fused_gather_r1", ptr(u), ptr(v), ptr(r1[0]), ptr(r1[1]), ptr(start), ptr(rev), Pu, k, C, ptr(mean), ptr(rstd),
+             ptr(gamma), ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
     return planar
 
 
@@ -315,29 +332,11 @@ class EdgeConvRank1Fn(Function):
         x = _rows(x).contiguous()
         nbr = nbr.contiguous()
         Wuv = Wuv.contiguous()
-        Pq, k = nbr.shape
         C = Wuv.shape[0] // 4
-        if x.shape[1] != 1 or Wuv.shape[1] != 1 or x.shape[0] != Pq * 3:
+        if x.shape[1] != 1 or Wuv.shape[1] != 1 or x.shape[0] != nbr.shape[0] * 3:
             raise _lib.VnpError("EdgeConvRank1Fn: one input channel and a graph on the layer's own points expected")
-        dev = x.device
-        wu, wv = Wuv[:2 * C], Wuv[2 * C:]
-        qb = _lib.lib().vnp_edge_block_queries()
-        nblk = (Pq + qb - 1) // qb
-        if training:
-            part = torch.empty((nblk, C, 2), device=dev, dtype=torch.float32)
-            call("vnp_edge_fused_r1", 0, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, None, None, None, None, float(ns),
-                 ptr(part), None, 0, None, 0, None, 0, None, 0)
-            mean = torch.empty(C, device=dev, dtype=torch.float32)
-            rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_vn_bn_finalize_chunked", ptr(part), nblk, qb * k, C, Pq * k, ptr(mean), ptr(rstd), ptr(running_mean),
-                 ptr(running_var), BN_MOMENTUM, BN_EPS)
-        else:
-            mean = running_mean
-            rstd = torch.empty(C, device=dev, dtype=torch.float32)
-            call("vnp_rstd_from_var", ptr(running_var), ptr(rstd), C, BN_EPS)
-        out = torch.empty((Pq * 3, C), device=dev, dtype=torch.float32)
-        call("vnp_edge_fused_r1", 1, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta),
-             float(ns), None, ptr(out), C, None, 0, None, 0, None, 0)
+        out, mean, rstd, nblk = _edge_conv_forward(x, x, nbr, gamma, beta, running_mean, running_var, training, ns,
+                                                   r1=(Wuv[:2 * C], Wuv[2 * C:]), C=C)
         trace("edge_conv_rank1")
         ctx.save_for_backward(x, Wuv, nbr, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(ns), nblk)
@@ -349,24 +348,13 @@ class EdgeConvRank1Fn(Function):
         x, Wuv, nbr, gamma, beta, mean, rstd = ctx.saved_tensors
         training, ns, nblk = ctx.cfg
         go = _rows(go)
-        Pq, k = nbr.shape
         C = Wuv.shape[0] // 4
-        wu, wv = Wuv[:2 * C], Wuv[2 * C:]
-        part = torch.empty((nblk, C, 2), device=go.device, dtype=torch.float32)
-        call("vnp_edge_fused_r1", 2, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-             ptr(part), None, 0, ptr(go), _ld(go), None, 0, None, 0)
-        S, planar = reduce_pairs(part, nblk, C)
-        sums = ptr(S) if training else None
-        guv = torch.empty((Pq * 3, 4 * C), device=go.device, dtype=torch.float32)
-        gu, gv = guv[:, :2 * C], guv[:, 2 * C:]
-        start, rev = edge_reverse(nbr, Pq)
-        call("vnp_edge_fused_r1", 3, ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(nbr), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ns,
-             None, None, 0, ptr(go), _ld(go), sums, Pq * k, ptr(gv), _ld(gv))
-        call("vnp_edge_fused_gather_r1", ptr(x), ptr(x), ptr(wu), ptr(wv), ptr(start), ptr(rev), Pq, k, C, ptr(mean), ptr(rstd), ptr(gamma),
-             ptr(beta), ns, ptr(go), _ld(go), sums, Pq * k, ptr(gu), _ld(gu))
+        guv = torch.empty((x.shape[0], 4 * C), device=go.device, dtype=torch.float32)
+        S = _edge_conv_backward(go, x, x, nbr, gamma, beta, mean, rstd, training, ns, nblk, guv[:, :2 * C], guv[:, 2 * C:],
+                                r1=(Wuv[:2 * C], Wuv[2 * C:]), C=C)
         gW = _wgrad(guv, x) if ctx.needs_input_grad[1] else None                 # [4C', 1] = guv^T x
         gx = _dgrad(guv, Wuv) if ctx.needs_input_grad[0] else None               # [P*3, 1] (the input cloud rarely asks for it)
-        return gx, gW, None, planar[1], planar[0], None, None, None, None
+        return gx, gW, None, S[1], S[0], None, None, None, None
 
 
 class EdgeWeightsFn(Function):
