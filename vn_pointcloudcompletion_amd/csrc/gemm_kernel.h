@@ -18,7 +18,7 @@ struct VnpGemmArgs {
     // VN max-pool epilogue of vnp_gemm_split_kernel<.., EPI = 1> (C is not written): per 32-point wave block and channel,
     // the best <x, d>, its point index inside the group of pool_gs points, and the winning x vector
     float* pool_val; int* pool_idx; float* pool_x; int pool_gs;
-    // EPI = 3 (screening pass of the exact screened arg-max pool, gemm.hip): three of the six bf16 products only; per 32-point
+    // EPI = 3 (screening pass of the exact screened arg-max pool, pool_gemm.hip): three of the six bf16 products only; per 32-point
     // wave block and channel one float4 {max lower bound, largest upper bound, second-largest upper bound, its local index}
     // goes to pool_val (as float4*).  row_norm[M]: upper bounds of |A row|_2; col_norm[N]: of |B row|_2; screen_eps: the error
     // constant E with |exact - screened| <= E |A row| |B row| per output element.

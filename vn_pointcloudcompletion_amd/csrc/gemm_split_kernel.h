@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(256, 2) vnp_gemm_split_kernel(const VnpGemmArg
 
     if (EPI == 4) {
         // ---- the one-fp16-product screening pass has its own K loop.  Its operands ARE fp16 already (p.A / p.B point to [rows][K] halves,
-        // lda / ldb in halves: gemm.hip converts them once, in the pass that takes the row norms), so there is nothing to do between the
+        // lda / ldb in halves: pool_gemm.hip converts them once, in the pass that takes the row norms), so there is nothing to do between the
         // load and LDS — and with 24 MFMAs per 32-wide K-tile the pass is bound by the operand bytes a CU pulls from L2 (both panels are
         // re-read for every tile: ~45 GB/s per CU against the 66-73 the L2 serves), not by the matrix pipe.  So: half the bytes (fp16
         // images instead of fp32), K walked in steps of 64 — a thread loads 16 bytes and eight neighbouring lanes cover one whole

@@ -1,0 +1,25 @@
+// Definitions shared by the Vector-Neuron kernel files (vn_ops.hip: BatchNorm / leaky / pooling passes; fold_fused.hip: FoldingNet's first
+// layer end to end; edge_ops.hip: fused EdgeConv and the reverse adjacency).
+#pragma once
+#include "vnp_common.h"
+
+#define VNP_CHUNK 1024         // points (rows) per block in the chunked kernels (also exported via vnp_chunk_points)
+// gradient kernels use v_rcp_f32 / v_sqrt_f32 (1 ulp each) where the forward kernels keep IEEE division and sqrtf
+#define VNP_GRAD_HW 1
+
+__device__ __forceinline__ float vnp_sq3(float a, float b, float c) { return a * a + b * b + c * c; }
+
+// (count, mean, M2) of two sets of values merged (Chan): Welford per thread + pairwise merges — the batch variance of the norms can be
+// 1e4-1e5 times smaller than mean^2 (FoldingNet layer 0: every point of a sample shares the dominant global term), where sum /
+// sum-of-squares in fp32 loses the variance to cancellation.
+__device__ __forceinline__ void vnp_chan_merge(double& na, double& ma, double& Ma, double nb, double mb, double Mb)
+{
+    if (nb <= 0.0) return;
+    const double n = na + nb, delta = mb - ma;
+    ma += delta * nb / n;
+    Ma += Mb + delta * delta * na * nb / n;
+    na = n;
+}
+
+static inline dim3 vnp_grid_pc(long long P, int C, int chunk) { return dim3(vnp_cdiv(C, 64), vnp_cdiv(P, chunk)); }
+static inline bool vnp_chunk_ok(int chunk) { return chunk >= 4 && chunk <= VNP_CHUNK; }
