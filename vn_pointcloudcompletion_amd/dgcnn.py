@@ -76,7 +76,9 @@ def fps_downsample_rows(coords, f_rows, m, picked=None):
             gid = (idx + batch_base(B, N, coords.device).view(B, 1)).reshape(-1)
         new_coords = torch.gather(coords, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
     else:
-        _, new_coords, gid = picked
+        idx, new_coords, gid = picked
+        if coords.requires_grad:                                           # a caller that differentiates through the sampled coordinates
+            new_coords = torch.gather(coords, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
     return new_coords, ops.GatherPointsFn.apply(f_rows, gid)
 
 
