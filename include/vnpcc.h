@@ -266,6 +266,10 @@ int vnp_vn_pool_bwd(hipStream_t st, const float* gout, int ldgo, const int* idx,
  * there (encoder first_conv[1] feeds maxpool1 and second_conv[0], models/pcn.py:169-172) */
 int vnp_vn_pool_bwd_acc(hipStream_t st, const float* gout, int ldgo, const int* idx, long long G, int gs, int C,
                         float* gx, int ldgx);
+/* Stable sort of every group's arg-max indices (what vnp_pool_lin_bwd / vnp_dir_pool_bwd take as `pts` / `order`; replaces
+ * torch.sort(idx, dim=1, stable=True) and its dtype conversions): idx [G][C] int32 with values in [0, gs) -> pts [G][C] ascending,
+ * order [G][C] the positions they came from, ties in position order.  C <= 4096. */
+int vnp_sort_groups(hipStream_t st, const int* idx, long long G, int C, int gs, int* pts, int* order);
 /* Backward of VNLinear followed by VNMaxPool (models/pcn.py:169-170,173-174) without the dense gradient of the linear output:
  * gW[Co][Ci] = sum_{g,t} gout[g*3+t][o] x[(g*gs+idx[g][o])*3+t][:]   (NULL: skip)
  * gx[G*gs*3][Ci] (every row written, zeros for a point no channel selected: no fill beforehand) gets, for every selected point, sum_{o: idx[g][o]==n} gout[g*3+t][o] W[o][:]   (NULL: skip)

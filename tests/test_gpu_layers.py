@@ -861,3 +861,16 @@ def test_pack_pd_cols_and_leaky_dir_equal_their_unfused_forms(lib_built):
         y2.backward(go)
         assert torch.equal(y, y2) and torch.equal(W.grad, W2.grad)
         assert torch.equal(x.grad, x2.grad)
+
+
+@pytest.mark.parametrize("G,C,gs", [(32, 2048, 2048), (5, 1000, 77), (3, 4096, 16384), (2, 1, 9), (4, 70, 3)])
+def test_sort_groups_is_the_stable_sort(lib_built, G, C, gs):
+    """vnp_sort_groups (every group's arg-max indices ascending, with the channels they came from, ties in channel order: what the sparse
+    pool backward walks) against torch.sort(stable=True) per row, many ties included."""
+    from vn_pointcloudcompletion_amd.ops.pool import sort_groups
+    g = torch.Generator().manual_seed(G + C)
+    idx = torch.randint(0, gs, (G, C), generator=g, dtype=torch.int32).cuda()
+    pts, order = sort_groups(idx, gs)
+    rp, ro = torch.sort(idx, dim=1, stable=True)
+    assert pts.dtype == torch.int32 and order.dtype == torch.int32
+    assert torch.equal(pts, rp.int()) and torch.equal(order, ro.int())

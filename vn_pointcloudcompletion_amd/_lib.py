@@ -117,6 +117,7 @@ _SIGNATURES = {
     "vnp_vn_pool_fwd": [_vp, _i, _vp, _i, _ll, _i, _i, _vp, _vp, _i, _vp, _vp],
     "vnp_vn_pool_bwd": [_vp, _i, _vp, _ll, _i, _i, _vp, _i],
     "vnp_vn_pool_bwd_acc": [_vp, _i, _vp, _ll, _i, _i, _vp, _i],
+    "vnp_sort_groups": [_vp, _ll, _i, _i, _vp, _vp],
     "vnp_pool_lin_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i],
     "vnp_vn_mean_pool_fwd": [_vp, _i, _ll, _i, _i, _vp, _i],
     "vnp_vn_mean_pool_bwd": [_vp, _i, _ll, _i, _i, _vp, _i],

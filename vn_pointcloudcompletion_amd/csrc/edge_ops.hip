@@ -345,28 +345,6 @@ __global__ void vnp_edge_rev_fill_kernel(const int* __restrict__ nbr, long long 
     }
 }
 
-// Ascending sort of data[0 .. L) by one workgroup: the bitonic network in its all-ascending form (first stage of every merge mirrors the
-// block, i ^ (2 j - 1); the others i ^ j; the smaller value always goes to the smaller index), so positions >= L behave as +infinity
-// without being stored.  `data` is LDS or global memory (a workgroup's own global accesses are ordered by __syncthreads).
-__device__ void vnp_block_sort_asc(int* data, int L)
-{
-    int n2 = 1;
-    while (n2 < L) n2 <<= 1;
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool first = j == (k >> 1);
-            for (int i = threadIdx.x; i < n2; i += blockDim.x) {
-                const int p = first ? (i ^ (k - 1)) : (i ^ j);
-                if (p > i && p < L) {                             // (i < p < L: both real; p >= L is +infinity and stays where it is)
-                    const int a = data[i], c = data[p];
-                    if (c < a) { data[i] = c; data[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // Every source point's list `in[start[s] .. start[s + 1])` (query ids, in arrival order) -> ascending in `out`.  A workgroup takes four
 // sources.  Lists of up to 64 entries (a kNN graph's in-degree is ~k) are sorted by one wave each, by counting: an entry's position is the
 // number of entries that are smaller, or equal and earlier (equal ids — a query that lists the same neighbour twice — are

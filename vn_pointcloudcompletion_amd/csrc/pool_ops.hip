@@ -213,6 +213,25 @@ extern "C" int vnp_pool_lin_bwd(hipStream_t st, const float* gout, int ldgo, con
 }
 
 
+// ---- stable sort of every group's arg-max indices: what the sparse pool backward walks --------------------------------------------------
+// idx [G][C] (values in [0, gs)) -> pts [G][C] = the values ascending, order [G][C] = the positions they came from, ties in position order
+// (torch.sort(stable=True) per row, which this replaces together with its two dtype conversions).  One workgroup per group sorts the
+// combined keys value * C2 + position (C2 = C rounded up to a power of two) in LDS.
+#define VNP_SORT_MAXC 4096
+__global__ void __launch_bounds__(1024) vnp_sort_groups_kernel(const int* __restrict__ idx, int C, int shift, int* __restrict__ pts, int* __restrict__ order)
+{
+    __shared__ int keys[VNP_SORT_MAXC];
+    const size_t g = blockIdx.x;
+    for (int j = threadIdx.x; j < C; j += 1024) keys[j] = (idx[g * C + j] << shift) | j;
+    __syncthreads();
+    vnp_block_sort_asc(keys, C);
+    for (int j = threadIdx.x; j < C; j += 1024) {
+        const int v = keys[j];
+        pts[g * C + j] = v >> shift;
+        order[g * C + j] = v & ((1 << shift) - 1);
+    }
+}
+
 // ================================================================================================ C-ABI
 // ws_val / ws_idx: G * ceil(gs / vnp_chunk_points()) * C elements each
 extern "C" int vnp_vn_pool_fwd(hipStream_t st, const float* x, int ldx, const float* d, int ldd, long long G, int gs, int C,
@@ -288,5 +307,16 @@ extern "C" int vnp_vn_mean_pool_bwd(hipStream_t st, const float* gout, int ldgo,
         hipLaunchKernelGGL(vnp_mean_pool_bwd_kernel, dim3(vnp_cdiv(C, 256), ng * 3), dim3(256), 0, st,
                            gout + (size_t)g0 * 3 * ldgo, ldgo, gs, C, gx + (size_t)g0 * gs * 3 * ldgx, ldgx);
     }
+    return vnp_last_error();
+}
+
+// idx [G][C] int32 with values in [0, gs): pts / order as described at vnp_sort_groups_kernel.  C <= 4096, gs * C2 < 2^31.
+extern "C" int vnp_sort_groups(hipStream_t st, const int* idx, long long G, int C, int gs, int* pts, int* order)
+{
+    if (!idx || !pts || !order || G <= 0 || G > 2147483647LL || C <= 0 || C > VNP_SORT_MAXC || gs <= 0) return VNP_EINVAL;
+    int shift = 0;
+    while ((1 << shift) < C) ++shift;
+    if (((long long)gs << shift) > 2147483647LL) return VNP_EINVAL;
+    hipLaunchKernelGGL(vnp_sort_groups_kernel, dim3((unsigned)G), dim3(1024), 0, st, idx, C, shift, pts, order);
     return vnp_last_error();
 }

@@ -11,7 +11,7 @@ from .._lib import call, ptr
 from ._state import HK, SW, POOL_PATH_COUNTS, prof_arm, trace
 from .core import (BN_EPS, BN_MOMENTUM, _bn_leaky_backward, _bn_leaky_forward, _bn_statistics, _chunk_pc, _dgrad, _ld, _nchunk,
                    _per_sample_colsum, _rows, _wgrad, cat_rows, gemm, gemm_pd_stats, reduce_pairs, reduce_rows)
-from .pool import _forced_pool
+from .pool import _forced_pool, sort_groups
 
 
 def unit_dirs(xyz, return_norm=False):
@@ -111,8 +111,7 @@ class DirLinearMaxPoolFn(Function):
         gh = order = pts = None
         if ctx.needs_input_grad[0]:
             gh = torch.empty((G * gs, K), device=dev, dtype=torch.float32)
-            pts64, order64 = torch.sort(idx, dim=1, stable=True)        # index bookkeeping only
-            pts, order = pts64.int().contiguous(), order64.int().contiguous()
+            pts, order = sort_groups(idx, gs)                           # the channels of a group by the point they picked (stable)
         Wc = _rows(W)
         call("vnp_dir_pool_bwd", ptr(gout), _ld(gout), ptr(u), ptr(idx), ptr(order), ptr(pts), ptr(h), _ld(h), ptr(Wc), _ld(Wc),
              G, gs, C, K, ptr(gW), K, ptr(gh), K)

@@ -86,6 +86,19 @@ class VNMaxPoolFn(Function):
 # differently and move everything downstream.  Never set on the product path.
 
 
+def sort_groups(idx, gs):
+    """(pts, order) [G, C] int32: every group's arg-max indices ascending and the channels they came from, ties in channel order —
+    vnp_sort_groups; groups of more than 4096 channels: torch.sort(stable=True)."""
+    G, C = idx.shape
+    if C > 4096 or gs * (1 << max(C - 1, 1).bit_length()) >= 2 ** 31:
+        pts64, order64 = torch.sort(idx, dim=1, stable=True)
+        return pts64.int().contiguous(), order64.int().contiguous()
+    idx = idx.contiguous()
+    pts, order = torch.empty_like(idx), torch.empty_like(idx)
+    call("vnp_sort_groups", ptr(idx), G, C, gs, ptr(pts), ptr(order))
+    return pts, order
+
+
 def _forced_pool(idx, out, rows_of_y, G, gs):
     f = HK.pool_idx_force
     if f is None:
@@ -293,8 +306,7 @@ class VNLinearMaxPoolFn(Function):
         gx = order = pts = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((G * gs * 3, Ci), device=dev, dtype=torch.float32)
-            pts64, order64 = torch.sort(idx, dim=1, stable=True)        # index bookkeeping only
-            pts, order = pts64.int().contiguous(), order64.int().contiguous()
+            pts, order = sort_groups(idx, gs)                           # the channels of a group by the point they picked (stable)
         Wc = _rows(W)
         call("vnp_pool_lin_bwd", ptr(gout), _ld(gout), ptr(idx), ptr(order), ptr(pts), ptr(x), _ld(x), ptr(Wc), _ld(Wc),
              G, gs, C, Ci, ptr(gW), Ci, ptr(gx), Ci)
