@@ -394,12 +394,19 @@ def test_gemm_with_a_residual_in_the_epilogue(lib_built, M, N, K, nsplit):
     Bm = (torch.randn(K, N, generator=g) if op_a else torch.randn(N, K, generator=g)).cuda()
     Rw = torch.randn(M, N + 4, generator=g).cuda()
     R = Rw[:, :N]
-    want = ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit) + R
-    got = ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit, resid=R)
-    assert torch.equal(got, want)
-    inplace = R.contiguous()
-    ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit, resid=inplace, out=inplace)
-    assert torch.equal(inplace, want)
+    from vn_pointcloudcompletion_amd import _lib
+    mode0 = _lib.get_gemm_mode()
+    try:
+        for mode in ("split", "fp32"):                   # both product kernels carry the residual epilogue
+            _lib.set_gemm_mode(mode)
+            want = ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit) + R
+            got = ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit, resid=R)
+            assert torch.equal(got, want), mode
+            inplace = R.contiguous()
+            ops.gemm(A, Bm, op_a=op_a, op_b=op_a, nsplit=nsplit, resid=inplace, out=inplace)
+            assert torch.equal(inplace, want), mode
+    finally:
+        _lib.set_gemm_mode(mode0)
 
 
 @pytest.mark.parametrize("P,C,na", [(4096, 128, 2), (37, 384, 1), (5, 12, 0), (300, 128, 2)])
