@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-input-MFMA comparison steps (clean profiles)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_other / chamfer_op / configs (clean profiles)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 3, 4, 5 leg (`configs`)")
+    ap.add_argument("--sustain", type=float, default=6.0, help="seconds of back-to-back steps after the timed region (`sustained`; 0: skip)")
     ap.add_argument("--shapes", action="store_true", help="print the kernel time of every matrix product of the timed steps, by shape (stderr)")
     ap.add_argument("--deadline", type=float, default=900.0,
                     help="self-launched ranks (--gpus N without a launcher): wall-clock limit in seconds after which the launcher "
@@ -409,6 +410,27 @@ def main():
                                        "waves_with_0_16_32_64_128_to_256_chunks": [int(((w_ >= lo) & (w_ < hi)).sum()) for lo, hi in ((0, 16), (16, 32), (32, 64), (64, 128), (128, 257))]}
                                 for name, w_ in (("queries = prediction", wc[:half]), ("queries = ground truth", wc[half:]))}}
 
+    # the same step for ~6 s without a break, outside the timed region: what the chip holds once its clock / temperature have settled (the
+    # timed region is 20 steps = 0.4 s), and a window long enough for a GPU-activity sampler with a period of seconds to see this run
+    sustained = None
+    if not args.no_extras and args.sustain > 0:
+        torch.cuda.synchronize()
+        D.barrier()
+        n_sus, t1 = 0, time.perf_counter()
+        while True:
+            for _ in range(25):
+                train_step(cfg, model, opt, p, c)
+            n_sus += 25
+            torch.cuda.synchronize()
+            stop = (time.perf_counter() - t1) >= args.sustain
+            if D.allreduce_scalar_max(1.0 if stop else 0.0) > 0.0:          # every rank leaves after the same number of steps
+                break
+        D.barrier()
+        dt_sus = D.allreduce_scalar_max(time.perf_counter() - t1)
+        sustained = {"seconds": round(dt_sus, 2), "steps": n_sus, "ms_per_step": dt_sus / n_sus * 1e3,
+                     "points_per_s": world * B * Md * n_sus / dt_sus,
+                     "note": "the timed step repeated back to back after the timed region (not `value`): sustained clocks"}
+
     # the same step on the fp32-input MFMA kernels, outside the timed region (single GPU only; a comparison, not `value`)
     fp32_mode = None
     gemm_mode = _lib.get_gemm_mode()
@@ -566,7 +588,7 @@ def main():
                           "parallelism": f"dp{world}", "allreduce": allreduce["mode"]},
                "points_per_s_per_gpu": value / world, "ranks_joined": ranks_joined, "allreduce": allreduce,
                "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
-               "roofline": roofline, "pool_path": pool_path, "chamfer_dense_loss_in_step": chamfer_step}
+               "roofline": roofline, "pool_path": pool_path, "chamfer_dense_loss_in_step": chamfer_step, "sustained": sustained}
         if fp32_mode is not None:
             out["fp32_mfma_mode"] = fp32_mode
         if world == 1 and not args.no_extras:
