@@ -176,7 +176,7 @@ int vnp_softmax_bwd(hipStream_t st, const float* P, float* dP, long long R, int 
 /* ---- VN BatchNorm / leaky projection ------------------------------------------------------------------------
  * VNBatchNorm (models/vn_layers.py:107-127), VNLeakyReLU (:25-43), VNLinearLeakyReLU tail (:66-73).
  * Chunked reductions use chunks of vnp_chunk_points() points: nchunk = ceil(P / vnp_chunk_points()).  For the per-channel
- * passes over a [P, C] map vnp_chunk_points_pc(P, C) gives the chunk that fills the chip (1024 halved down to 64 until the grid has
+ * passes over a [P, C] map vnp_chunk_points_pc(P, C) gives the chunk that fills the chip (1024 halved down to 16 until the grid has
  * >= 1024 workgroups); vnp_vn_norm_stats / vnp_vn_bn_leaky_bwd1 take it as `chunk_points` (0 = vnp_chunk_points()) and write one
  * partial row per chunk of that size; vnp_vn_bn_finalize_chunked merges statistics partials of any chunk size. */
 int vnp_chunk_points(void);

@@ -18,16 +18,17 @@
 
 extern "C" int vnp_chunk_points() { return VNP_CHUNK; }
 
-// Points per workgroup of the BatchNorm / leaky passes for a [P points, C channels] map: VNP_CHUNK, halved (down to 64) until the
-// grid has at least 1024 workgroups — a 128-channel layer over 65536 points is only 128 chunks of 1024 and left half the chip idle
-// (measured: 1.0-1.5 TB/s on first_conv[0] against 5+ TB/s on the wide layers).  Statistics / gradient partials are per chunk of
+// Points per workgroup of the BatchNorm / leaky passes for a [P points, C channels] map: VNP_CHUNK, halved (down to 16: four points per
+// point lane) until the grid has at least 1024 workgroups — a 128-channel layer over 65536 points is only 128 chunks of 1024 and left half
+// the chip idle (measured: 1.0-1.5 TB/s on first_conv[0] against 5+ TB/s on the wide layers); the 4096-point layers of the transformer
+// blocks stopped at 64 points (256 workgroups, 16 dependent iterations per lane: 20-29 us for 12 MB) until round 4 lowered the floor.  Statistics / gradient partials are per chunk of
 // this size: callers size them with this function and pass the value on (vnp_vn_norm_stats, vnp_vn_bn_leaky_bwd1,
 // vnp_vn_bn_finalize_chunked).
 extern "C" int vnp_chunk_points_pc(long long P, int C)
 {
     int chunk = VNP_CHUNK;
     const long long cols = (C + 63) / 64;
-    while (chunk > 64 && ((P + chunk - 1) / chunk) * cols < 1024) chunk >>= 1;
+    while (chunk > 16 && ((P + chunk - 1) / chunk) * cols < 1024) chunk >>= 1;
     return chunk;
 }
 
