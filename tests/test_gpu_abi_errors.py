@@ -41,6 +41,21 @@ def test_einval_instead_of_launching(lib_built):
     assert _lib.lib().vnp_gemm_set_mode(7) == -1 and _lib.get_gemm_mode() in ("split", "fp32")
     # fused linear + pool: shapes outside its tiling are refused (callers fall back to vnp_gemm + vnp_vn_pool_fwd)
     assert _rc("vnp_linear_pool_fwd", ptr(A), 4, ptr(B), 4, 1, 30, 64, 32, ptr(idx), ptr(C), 64, ptr(ws)) == -1
+    # round-4 entry points: a residual without a matrix or narrower than the output, a group that does not fit the sort's LDS or whose
+    # combined keys would overflow, grouped permutes beyond one token's LDS budget, a sampling gather without a destination, a loss without
+    # scratch, EdgeConv weights in an unknown direction, the rank-1 EdgeConv without its weight columns
+    assert _rc("vnp_gemm_add", 0, 0, 8, 5, 4, ptr(A), 4, ptr(B), 4, ptr(C), 5, None, 5, 1, None) == -1
+    assert _rc("vnp_gemm_add", 0, 0, 8, 5, 4, ptr(A), 4, ptr(B), 4, ptr(C), 5, ptr(C), 3, 1, None) == -1
+    assert _rc("vnp_sort_groups", ptr(idx), 2, 5000, 8, ptr(idx), ptr(idx)) == -1
+    assert _rc("vnp_sort_groups", ptr(idx), 2, 4096, 1 << 20, ptr(idx), ptr(idx)) == -1
+    assert _rc("vnp_rows_to_heads_grouped", ptr(A), 6000, 1, 1, 2000, 4, 3, ptr(C)) == -1
+    assert _rc("vnp_gather_coords", 2, 8, ptr(a), ptr(idx), 4, None, None) == -1
+    assert _rc("vnp_cd_l1_loss", ptr(d1), 16, ptr(d2), 18, None, ptr(C)) == -1
+    assert _rc("vnp_cd_l1_grad", None, ptr(d1), 16, ptr(d2), 18, ptr(d1), ptr(d2)) == -1
+    assert _rc("vnp_edge_weights", 2, ptr(A), ptr(A), ptr(C), 2, 2) == -1
+    assert _rc("vnp_edge_fused_r1", 1, ptr(a), ptr(a), None, None, ptr(idx), 8, 4, 4, ptr(d1), ptr(d1), ptr(d1), ptr(d1), 0.2, None, ptr(C), 4,
+               None, 0, None, 0, None, 0) == -1
+    assert _rc("vnp_vn_add_layernorm_fwd", ptr(A), 4, None, 4, None, 0, 2, 4, ptr(d1), ptr(d1), ptr(C), 4, ptr(C), 4, ptr(d2)) == -1
     # and the Python layer turns the status into an exception
     with pytest.raises(_lib.VnpError):
         _lib.call("vnp_fps", 2, 8, ptr(a), 9, ptr(idx))
