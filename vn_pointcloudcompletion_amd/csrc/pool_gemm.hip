@@ -361,19 +361,19 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_final_kernel(const VnpScr
                                                                     int* __restrict__ idx, float* __restrict__ out, int ldo)
 {
     if (head->flag) return;
-    const int sub = threadIdx.x & 7;
-    const int c = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int sub = threadIdx.x & 63;                    // a wave per (group, channel) segment: a segment of a near-tied channel can hold
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);   // hundreds of candidates, and eight lanes walking it set the kernel's time
     const long long g = blockIdx.y;
     const bool live = c < C;
     const int2 sg = live ? seg[(size_t)g * C + c] : make_int2(0, 0);
     float best = 0.f; int bp = 0x7fffffff; float bx = 0.f, by = 0.f, bz = 0.f;
-    for (int i = sg.x + sub; i < sg.x + sg.y; i += 8) {
+    for (int i = sg.x + sub; i < sg.x + sg.y; i += 64) {
         const float4 r = res[i];
         const int pt = list[i].x;
         if (bp == 0x7fffffff || r.w > best || (r.w == best && pt < bp)) { best = r.w; bp = pt; bx = r.x; by = r.y; bz = r.z; }
     }
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
+    for (int o = 1; o < 64; o <<= 1) {
         const float ob = __shfl_xor(best, o), ox = __shfl_xor(bx, o), oy = __shfl_xor(by, o), oz = __shfl_xor(bz, o);
         const int op = __shfl_xor(bp, o);
         if (op != 0x7fffffff && (bp == 0x7fffffff || ob > best || (ob == best && op < bp))) { best = ob; bp = op; bx = ox; by = oy; bz = oz; }
@@ -500,7 +500,7 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
     // at most cap / 16 + nbins tiles (every bin's last tile may be partial); waves past the real tile count exit at once
     hipLaunchKernelGGL(vnp_pool_screen_exact_kernel, dim3((unsigned)vnp_cdiv(cap / 16 + nbins, 4)), dim3(256), 0, st, x, ldx, Wcat, ldw, K,
                        G * gs, (const VnpScreenHead*)head, (const int2*)list, (const int*)order, (const int*)start, (const int*)tstart, nbins, res);
-    hipLaunchKernelGGL(vnp_pool_screen_final_kernel, dim3(vnp_cdiv(C, 32), (unsigned)G), dim3(256), 0, st,
+    hipLaunchKernelGGL(vnp_pool_screen_final_kernel, dim3(vnp_cdiv(C, 4), (unsigned)G), dim3(256), 0, st,
                        (const VnpScreenHead*)head, (const int2*)seg, (const int2*)list, (const float4*)res, C, gs, idx, out, ldo);
     // predicated fallback: the full 6-product pool, runs only if the flag was raised
     VnpGemmArgs q{};
