@@ -94,14 +94,18 @@ __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __rest
 // (momentum, unbiased variance for running_var).
 // A workgroup = 64 channels x 16 chunk lanes: the chain of dependent double-precision merges per thread is nchunk / 16 long (C / 64
 // workgroups is all the parallelism the channels offer: with 4 chunk lanes the 512-chunk decoder layer took 42 us).
-#define VNP_FIN_LANES 16
-__global__ void __launch_bounds__(64 * VNP_FIN_LANES) vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int chunk_points, int C,
+// 1024 threads = VNP_FIN_CH channels x VNP_FIN_LANES partial lanes: lane l merges the partials l, l + 64, ... of its channel (Chan, in
+// double), then the 64 lanes of a channel merge pairwise in LDS (a fixed tree: deterministic).  (Rounds 1-3: 64 channels x 16 lanes and a
+// serial merge of the 16 — four workgroups for a 256-channel layer, 25 us for 512 partials; 16 channels x 64 lanes: 16 workgroups.)
+#define VNP_FIN_CH 16
+#define VNP_FIN_LANES 64
+__global__ void __launch_bounds__(VNP_FIN_CH * VNP_FIN_LANES) vnp_bn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int chunk_points, int C,
                                                              long long count, float* __restrict__ mean, float* __restrict__ rstd,
                                                              float* running_mean, float* running_var, float momentum, float eps)
 {
-    __shared__ double rn[VNP_FIN_LANES][64], rm[VNP_FIN_LANES][64], rM[VNP_FIN_LANES][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ double rn[VNP_FIN_LANES][VNP_FIN_CH], rm[VNP_FIN_LANES][VNP_FIN_CH], rM[VNP_FIN_LANES][VNP_FIN_CH];
+    const int cx = threadIdx.x & (VNP_FIN_CH - 1), py = threadIdx.x / VNP_FIN_CH;
+    const int c = blockIdx.x * VNP_FIN_CH + cx;
     double na = 0.0, ma = 0.0, Ma = 0.0;
     if (c < C) {
         for (int k = py; k < nchunk; k += VNP_FIN_LANES) {
@@ -114,12 +118,18 @@ __global__ void __launch_bounds__(64 * VNP_FIN_LANES) vnp_bn_finalize_kernel(con
     }
     rn[py][cx] = na; rm[py][cx] = ma; rM[py][cx] = Ma;
     __syncthreads();
-    if (py != 0 || c >= C) return;
-    for (int j = 1; j < VNP_FIN_LANES; ++j) {
-        if (rn[j][cx] == 0.0) continue;
-        if (na == 0.0) { na = rn[j][cx]; ma = rm[j][cx]; Ma = rM[j][cx]; }
-        else vnp_chan_merge(na, ma, Ma, rn[j][cx], rm[j][cx], rM[j][cx]);
+    for (int o = VNP_FIN_LANES / 2; o > 0; o >>= 1) {          // lane py absorbs lane py + o
+        if (py < o) {
+            const double nb = rn[py + o][cx];
+            if (nb > 0.0) {
+                if (na == 0.0) { na = nb; ma = rm[py + o][cx]; Ma = rM[py + o][cx]; }
+                else vnp_chan_merge(na, ma, Ma, nb, rm[py + o][cx], rM[py + o][cx]);
+                rn[py][cx] = na; rm[py][cx] = ma; rM[py][cx] = Ma;
+            }
+        }
+        __syncthreads();
     }
+    if (py != 0 || c >= C) return;
     const double m = ma;
     double var = Ma / (double)count;
     if (var < 0.0) var = 0.0;
@@ -432,7 +442,7 @@ extern "C" int vnp_vn_bn_finalize(hipStream_t st, const float* partial, int nchu
                                   float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps)
 {
     if (!partial || !mean || !rstd || C <= 0 || count <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(64 * VNP_FIN_LANES), 0, st, (const float2*)partial, nchunk, VNP_CHUNK, C, count,
+    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, VNP_FIN_CH)), dim3(VNP_FIN_CH * VNP_FIN_LANES), 0, st, (const float2*)partial, nchunk, VNP_CHUNK, C, count,
                        mean, rstd, running_mean, running_var, momentum, eps);
     return vnp_last_error();
 }
@@ -552,7 +562,7 @@ extern "C" int vnp_vn_bn_finalize_chunked(hipStream_t st, const float* partial, 
                                           float* mean, float* rstd, float* running_mean, float* running_var, float momentum, float eps)
 {
     if (!partial || !mean || !rstd || C <= 0 || count <= 0 || chunk_points <= 0) return VNP_EINVAL;
-    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, 64)), dim3(64 * VNP_FIN_LANES), 0, st, (const float2*)partial, nchunk, chunk_points, C, count,
+    hipLaunchKernelGGL(vnp_bn_finalize_kernel, dim3(vnp_cdiv(C, VNP_FIN_CH)), dim3(VNP_FIN_CH * VNP_FIN_LANES), 0, st, (const float2*)partial, nchunk, chunk_points, C, count,
                        mean, rstd, running_mean, running_var, momentum, eps);
     return vnp_last_error();
 }
