@@ -339,6 +339,7 @@ __global__ void __launch_bounds__(256) vnp_dir_pool_bwd_w_kernel(const float* __
     const int c = blockIdx.x;
     for (int k = threadIdx.x; k < Ci; k += 256) {
         float acc = 0.f;
+#pragma unroll 8                                     // eight groups' index -> row gathers in flight
         for (int g = 0; g < G; ++g) {
             const size_t n = (size_t)g * gs + idx[(size_t)g * C + c];
             const float gy = u[n * 3] * gout[((size_t)g * 3) * ldgo + c] + u[n * 3 + 1] * gout[((size_t)g * 3 + 1) * ldgo + c] +
@@ -358,8 +359,8 @@ __global__ void __launch_bounds__(128) vnp_dir_pool_bwd_x_kernel(const float* __
                                                                 const float* __restrict__ W, int ldw, int gs, int C, int Ci,
                                                                 float* __restrict__ gh, int ldgh)
 {
-    const int n0 = blockIdx.x * 16, g = blockIdx.y;                    // 16 consecutive points per block: one bisection, then a walk
-    const int n1 = n0 + 16 < gs ? n0 + 16 : gs;
+    const int n0 = blockIdx.x * 4, g = blockIdx.y;                     // 4 consecutive points per block: one bisection, then a walk
+    const int n1 = n0 + 4 < gs ? n0 + 4 : gs;
     const int* pg = pts + (size_t)g * C;
     int lo = 0, hi = C;                               // first j with pg[j] >= n0
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (pg[mid] < n0) lo = mid + 1; else hi = mid; }
@@ -394,7 +395,7 @@ extern "C" int vnp_dir_pool_bwd(hipStream_t st, const float* gout, int ldgo, con
     }
     if (gh) {
         if (!order || !pts || !W) return VNP_EINVAL;
-        hipLaunchKernelGGL(vnp_dir_pool_bwd_x_kernel, dim3(vnp_cdiv(gs, 16), (unsigned)G), dim3(128), 0, st, gout, ldgo, u, order, pts, W, ldw, gs, C, Ci, gh, ldgh);
+        hipLaunchKernelGGL(vnp_dir_pool_bwd_x_kernel, dim3(vnp_cdiv(gs, 4), (unsigned)G), dim3(128), 0, st, gout, ldgo, u, order, pts, W, ldw, gs, C, Ci, gh, ldgh);
     }
     return vnp_last_error();
 }
