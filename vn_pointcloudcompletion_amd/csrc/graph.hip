@@ -502,13 +502,12 @@ __global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const 
         float best = -1.f; int bi = 0x7fffffff;
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
+            // no bounds test: a slot past N holds md = -1 and coordinates 0, so it stays at -1 (d >= 0) and never beats `best`
             const int i = tid + u * FPS_SMALL_THREADS;
-            if (i < N) {
-                const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
-                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                md[u] = fminf(md[u], d);                          // a skipped point stays at -1 (d >= 0)
-                if (md[u] > best) { best = md[u]; bi = i; }       // ascending i within a thread: first max kept
-            }
+            const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
+            const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            md[u] = fminf(md[u], d);                              // a skipped point stays at -1 (d >= 0)
+            if (md[u] > best) { best = md[u]; bi = i; }           // ascending i within a thread: first max kept
         }
         // wave arg-max on DPP: the largest running distance, then the smallest index among the lanes that hold it
         const float wbest = vnp_wave_max_f32(best);
