@@ -478,18 +478,18 @@ __global__ void __launch_bounds__(FPS_THREADS) vnp_fps_kernel(const float* __res
 // Same arithmetic, same tie rule (largest running distance, then smallest index), same picks as the kernel above.
 #define FPS_SMALL_THREADS 256
 #define FPS_SMALL_MAXN 4096
-template <int PPT, bool SKIP>
-__global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const float* __restrict__ xyz, int N, int M, int* __restrict__ out)
+template <int PPT, bool SKIP, int THREADS = FPS_SMALL_THREADS>
+__global__ void __launch_bounds__(THREADS) vnp_fps_small_kernel(const float* __restrict__ xyz, int N, int M, int* __restrict__ out)
 {
     __shared__ float sx[FPS_SMALL_MAXN], sy[FPS_SMALL_MAXN], sz[FPS_SMALL_MAXN];
-    __shared__ float sv[2][FPS_SMALL_THREADS / 64];
-    __shared__ int si[2][FPS_SMALL_THREADS / 64];
+    __shared__ float sv[2][THREADS / 64];
+    __shared__ int si[2][THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
     float px[PPT], py[PPT], pz[PPT], md[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
-        const int i = tid + u * FPS_SMALL_THREADS;
+        const int i = tid + u * THREADS;
         if (i < N) { px[u] = p[i * 3]; py[u] = p[i * 3 + 1]; pz[u] = p[i * 3 + 2]; md[u] = 1e10f; sx[i] = px[u]; sy[i] = py[u]; sz[i] = pz[u]; }
         else { px[u] = py[u] = pz[u] = 0.f; md[u] = -1.f; }
         if (SKIP && i < N && px[u] * px[u] + py[u] * py[u] + pz[u] * pz[u] <= 1e-3f) md[u] = -1.f;     // never a candidate
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const 
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
             // no bounds test: a slot past N holds md = -1 and coordinates 0, so it stays at -1 (d >= 0) and never beats `best`
-            const int i = tid + u * FPS_SMALL_THREADS;
+            const int i = tid + u * THREADS;
             const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
             const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             md[u] = fminf(md[u], d);                              // a skipped point stays at -1 (d >= 0)
@@ -512,14 +512,17 @@ __global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const 
         // wave arg-max on DPP: the largest running distance, then the smallest index among the lanes that hold it
         const float wbest = vnp_wave_max_f32(best);
         const int wbi = vnp_wave_min_i32(best == wbest ? bi : 0x7fffffff);
-        const int par = r & 1;
-        if ((tid & 63) == 0) { sv[par][tid >> 6] = wbest; si[par][tid >> 6] = wbi; }
-        __syncthreads();
-        float v = sv[par][0]; int i = si[par][0];
+        float v = wbest; int i = wbi;
+        if (THREADS > 64) {                                       // several waves: their winners meet in LDS (one barrier per round)
+            const int par = r & 1;
+            if ((tid & 63) == 0) { sv[par][tid >> 6] = wbest; si[par][tid >> 6] = wbi; }
+            __syncthreads();
+            v = sv[par][0]; i = si[par][0];
 #pragma unroll
-        for (int w = 1; w < FPS_SMALL_THREADS / 64; ++w) {
-            const float ov = sv[par][w]; const int oi = si[par][w];
-            if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            for (int w = 1; w < THREADS / 64; ++w) {
+                const float ov = sv[par][w]; const int oi = si[par][w];
+                if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
         }
         if (i == 0x7fffffff) i = 0;
         if (tid == 0) out[(size_t)b * M + r] = i;
@@ -530,6 +533,13 @@ __global__ void __launch_bounds__(FPS_SMALL_THREADS) vnp_fps_small_kernel(const 
 template <bool SKIP>
 static int vnp_fps_launch(hipStream_t st, int B, int N, const float* xyz, int M, int* idx)
 {
+    if (N <= 512) {
+        // one wave per cloud, up to 8 points per lane: no barrier and no LDS exchange per round (measured inside config 3's step: 512 -> 128
+        // picks 77 -> 50 us; at 2048 points the 32 points per lane cost more than the exchange saves: 550 against 459 us, so from there on four waves)
+        if (N <= 128) hipLaunchKernelGGL((vnp_fps_small_kernel<2, SKIP, 64>), dim3(B), dim3(64), 0, st, xyz, N, M, idx);
+        else          hipLaunchKernelGGL((vnp_fps_small_kernel<8, SKIP, 64>), dim3(B), dim3(64), 0, st, xyz, N, M, idx);
+        return vnp_last_error();
+    }
     if (N <= FPS_SMALL_MAXN) {
         if (N <= 2 * FPS_SMALL_THREADS)      hipLaunchKernelGGL((vnp_fps_small_kernel<2, SKIP>), dim3(B), dim3(FPS_SMALL_THREADS), 0, st, xyz, N, M, idx);
         else if (N <= 4 * FPS_SMALL_THREADS) hipLaunchKernelGGL((vnp_fps_small_kernel<4, SKIP>), dim3(B), dim3(FPS_SMALL_THREADS), 0, st, xyz, N, M, idx);
