@@ -438,6 +438,37 @@ def test_add_layernorm_equals_the_adds_and_the_layernorm(lib_built, P, C, na):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("use", ["s", "y"])
+@pytest.mark.parametrize("na", [0, 2])
+def test_add_layernorm_with_one_output_unused(lib_built, use, na):
+    """Only the skip connection s, or only the normalised y, reaches the loss: the Function sees None for the other cotangent (no
+    zero-filled stand-in), absent addends get no gradient, and every gradient equals the unfused form bit for bit."""
+    from vn_pointcloudcompletion_amd import ops
+    P, C = 130, 128
+    g = torch.Generator().manual_seed(5)
+    leaves = [torch.randn(P * 3, C, generator=g).cuda() for _ in range(1 + na)]
+    gam0, bet0 = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.1).cuda()
+    cot = torch.randn(P * 3, C, generator=g).cuda()
+
+    def run(fused):
+        xs = [v.clone().requires_grad_(True) for v in leaves]
+        gam, bet = gam0.clone().requires_grad_(True), bet0.clone().requires_grad_(True)
+        if fused:
+            s, y = ops.AddLayerNormFn.apply(xs[0], xs[1] if na > 0 else None, xs[2] if na > 1 else None, gam, bet)
+        else:
+            s = xs[0] * 1.0
+            for v in xs[1:]:
+                s = s + v
+            y = ops.VNLayerNormFn.apply(s, gam, bet)
+        ((s if use == "s" else y) * cot).sum().backward()
+        return [v.grad for v in xs] + [gam.grad, bet.grad]
+    for a, b in zip(run(True), run(False)):
+        if use == "s" and (a is None or b is None):              # gamma / beta: no gradient (None) or an exact zero
+            assert (a is None or not a.any()) and (b is None or not b.any())
+        else:
+            assert torch.equal(a, b)
+
+
 def test_coarse_emd_loss_beside_the_decoder_is_the_same_step(lib_built):
     """train.train_step starts an EMD coarse loss on a side HIP stream the moment the encoder's output exists (PCNNet's on_coarse hook) and
     lets it run beside the decoder.  From the same state and batches: two runs taken that way agree bit for bit over three steps (a

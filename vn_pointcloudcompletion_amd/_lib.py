@@ -26,25 +26,66 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _source_hash():
+    """SHA-256 over the names and contents of every kernel source and header: what decides whether the library is stale (file times do
+    not survive a copy to another machine)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+_HASH_PATH = os.path.join(CSRC, "build", "libvnpcc.srchash")
+
+
+def _up_to_date():
+    if not os.path.exists(LIB_PATH):
+        return False
+    try:
+        with open(_HASH_PATH) as fh:
+            return fh.read().strip() == _source_hash()
+    except OSError:                               # a library built before the hash existed: fall back to file times
+        deps = sources() + glob.glob(os.path.join(CSRC, "*.h"))
+        return all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into csrc/libvnpcc.so (cross-compiles without a GPU).  Serialised across processes by a
-    file lock: the ranks of a multi-GPU launch that find the library stale build it once, not N times into the same files."""
+    """Compile every HIP source for gfx950 into csrc/libvnpcc.so (cross-compiles without a GPU).  An up-to-date library (source hash
+    recorded beside it) is returned without touching the file system, so a read-only install works.  A stale one is rebuilt under a
+    file lock: the ranks of a multi-GPU launch build it once, not N times into the same files.  When the rebuild is impossible (no
+    compiler, read-only tree) and a library exists, that library is used with a warning: a usable kernel library must not abort a
+    launch because its sources were touched."""
     import fcntl
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
-    with open(os.path.join(CSRC, "build", ".lock"), "w") as lock:
+    import warnings
+    if not force and _up_to_date():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    try:
+        if not os.path.exists(hipcc):
+            raise OSError(f"compiler {hipcc} not found")
+        os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+        lock = open(os.path.join(CSRC, "build", ".lock"), "w")
+    except OSError as e:
+        if os.path.exists(LIB_PATH) and not force:
+            warnings.warn(f"libvnpcc.so is older than its sources and cannot be rebuilt here ({e}); using the existing library")
+            return LIB_PATH
+        raise
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return _build_locked(force, verbose)
+            if not force and _up_to_date():       # another rank built it while this one waited for the lock
+                return LIB_PATH
+            return _build_locked(hipcc, force, verbose)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(force, verbose):
+def _build_locked(hipcc, force, verbose):
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in deps):
-        return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src_hash = _source_hash()
     objs = []
     procs = []
     for s in srcs:
@@ -64,6 +105,9 @@ def _build_locked(force, verbose):
     tmp = LIB_PATH + ".tmp"
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
     os.replace(tmp, LIB_PATH)                     # a process that has the old file mapped keeps it; nobody sees a half-written one
+    with open(_HASH_PATH + ".tmp", "w") as fh:
+        fh.write(src_hash + "\n")
+    os.replace(_HASH_PATH + ".tmp", _HASH_PATH)
     return LIB_PATH
 
 

@@ -82,6 +82,15 @@ def fps_downsample_rows(coords, f_rows, m, picked=None):
     return new_coords, ops.GatherPointsFn.apply(f_rows, gid)
 
 
+def sampled_coords(coords, picked):
+    """The coordinates of an ops.FpsPlan level (the 224 extra coarse points, dgcnn.py:322, vn_pointr.py:720).  The plan's own gather
+    (vnp_gather_coords) has no autograd: a cloud that asks for a gradient gets the differentiable torch.gather of the reference."""
+    idx, xyz_m, _ = picked
+    if coords.requires_grad:
+        return torch.gather(coords, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    return xyz_m
+
+
 class VN_DGCNN_fps(nn.Module):
     K = 16       # hard-coded in the reference (dgcnn.py:11,230,251); exposed as an attribute for the k=20 benchmark config
 
@@ -117,7 +126,7 @@ class VN_DGCNN_fps(nn.Module):
         coarse = h.reshape(B, 3, self.num_coarse).permute(0, 2, 1).contiguous()
         global_feature = rows_to_global(g, B)
         if self.num_coarse == 224:
-            inp_sparse = plan.level(2)[1]
+            inp_sparse = sampled_coords(coords, plan.level(2))
             coarse_cat = torch.cat([coarse, inp_sparse], dim=1).contiguous()
             return (coarse, coarse_cat), global_feature
         plan.close()

@@ -268,6 +268,7 @@ class AddLayerNormFn(Function):
             call("vnp_vn_add_layernorm_fwd", ptr(x), _ld(x), ptr(a1), _ld(a1), ptr(a2), _ld(a2) if a2 is not None else 0, P, C,
                  ptr(gamma), ptr(beta), ptr(s), C, ptr(out), C, ptr(stats))
         ctx.save_for_backward(s, gamma, beta, stats)
+        ctx.set_materialize_grads(False)                 # an unused output arrives as None, not as a zero-filled [R, C] tensor
         return s, out
 
     @staticmethod
@@ -276,8 +277,9 @@ class AddLayerNormFn(Function):
         s, gamma, beta, stats = ctx.saved_tensors
         R, C = s.shape
         P = R // 3
+        need = ctx.needs_input_grad
         if go is None:                                   # the normalised output was not used: only the skip connection carries a gradient
-            return gs, gs, gs, None, None
+            return tuple(gs if n else None for n in need[:3]) + (None, None)
         go = _rows(go)
         nblk = (P + 3) // 4
         nblk_pad = (nblk + 255) // 256 * 256 if nblk > 1024 else nblk
@@ -290,5 +292,4 @@ class AddLayerNormFn(Function):
             call("vnp_vn_layernorm_bwd_add", ptr(go), _ld(go), ptr(s), _ld(s), P, C, ptr(gamma), ptr(beta), ptr(stats), ptr(gs), _ld(gs),
                  ptr(gx), C, ptr(part))
         gb = reduce_rows(part, 1, nblk_pad, 2 * C)[0]
-        need = ctx.needs_input_grad
         return (gx if need[0] else None), (gx if need[1] else None), (gx if need[2] else None), gb[:C], gb[C:]

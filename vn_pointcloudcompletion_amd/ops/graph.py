@@ -78,9 +78,10 @@ class FpsPlan:
     head sample the input.  A sampling is M dependent rounds of one workgroup per cloud — latency, 32 of 256 CUs busy — so the whole
     chain is launched on a side HIP stream as soon as the coordinates exist and runs beside the kNN searches and EdgeConv layers of the
     main stream; a consumer waits for the event of the level it needs (``level``).  All buffers are allocated on the main stream before
-    the side stream starts and are held by the plan until ``close`` has made the main stream wait for the last event, so the caching
-    allocator cannot hand one of them out while a sampling still reads or writes it.  ``SW.FPS_AHEAD = False``: the same launches in the
-    same order on the main stream.  Each level also yields its coordinates and the global row ids of its picks (vnp_gather_coords)."""
+    the side stream starts and every one of them (the input coordinates included) is marked ``record_stream(side)``: the caching
+    allocator does not hand a block out again before the side stream's work queued up to its release has finished, also when a forward
+    raises between the plan's construction and ``close``.  ``SW.FPS_AHEAD = False``: the same launches in the same order on the main
+    stream.  Each level also yields its coordinates and the global row ids of its picks (vnp_gather_coords)."""
 
     def __init__(self, coords, chain, extra=()):
         _lib.require_gpu(coords)
@@ -93,11 +94,14 @@ class FpsPlan:
         for _, m in specs:
             self._items.append((torch.empty((B, m), device=dev, dtype=torch.int32), torch.empty((B, m, 3), device=dev, dtype=torch.float32),
                                 torch.empty(B * m, device=dev, dtype=torch.int32)))
+        self._dev = dev
         self._main = torch.cuda.current_stream(dev)
         ahead = SW.FPS_AHEAD and HK.trace is None          # a traced pass reads its picks on the host while it runs: keep it on one stream
         self._side = _side_stream(dev) if ahead else None
         if self._side is not None:
             self._side.wait_stream(self._main)
+            for t in (coords, *(t for item in self._items for t in item)):
+                t.record_stream(self._side)
         cur, n = coords, N
         with torch.cuda.stream(self._side if self._side is not None else self._main):
             for (chained, m), (idx, xyz_m, gid) in zip(specs, self._items):
@@ -115,7 +119,7 @@ class FpsPlan:
     def level(self, i):
         """(idx [B, m] int32 local picks, coordinates [B, m, 3], global row ids [B*m] int32) of item i, ready on the current stream."""
         if self._side is not None and i > self._waited:
-            torch.cuda.current_stream().wait_event(self._events[i])
+            torch.cuda.current_stream(self._dev).wait_event(self._events[i])
             self._waited = i
         idx, xyz_m, gid = self._items[i]
         trace("fps", idx, key="fps_idx")
@@ -123,7 +127,7 @@ class FpsPlan:
 
     def close(self):
         if self._side is not None and self._events and self._waited < len(self._events) - 1:
-            torch.cuda.current_stream().wait_event(self._events[-1])
+            torch.cuda.current_stream(self._dev).wait_event(self._events[-1])
             self._waited = len(self._events) - 1
 
 

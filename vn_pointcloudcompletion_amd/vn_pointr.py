@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .dgcnn import batch_base, edge_conv_rows, fps_downsample_rows, knn_graph
+from .dgcnn import batch_base, edge_conv_rows, fps_downsample_rows, knn_graph, sampled_coords
 from .pcn import rows_to_global
 from .vn_layers import (VNLayerNorm, VNLeakyReLU, VNLinear, VNLinearAndLeakyReLU, VNLinearLeakyReLU, VNMaxPool, mean_pool)
 
@@ -257,6 +257,6 @@ class VN_PCTransformer(nn.Module):
         if carry is not None:
             x = x + carry
         coarse, global_feature = self.head_rows(x, B, nc)
-        inp_sparse = plan.level(2)[1]
+        inp_sparse = sampled_coords(inpc, plan.level(2))
         coarse = torch.cat([coarse, inp_sparse], dim=1).contiguous()
         return coarse, global_feature
