@@ -11,6 +11,7 @@
 // exactly the reference's strict '<' scan.  A second tiny kernel unpacks (dist, idx).
 // This is VALU-bound (~9.5 lane-op-equivalents per pair), not HBM-bound: ~12 B per point are read once per block.
 #include "vnp_common.h"
+#include <type_traits>
 
 #define CH_THREADS 256
 #define CH_QPT 4                 // queries per thread
@@ -379,10 +380,24 @@ __global__ void __launch_bounds__(1024) vnp_chamfer_bin_kernel(const float* __re
     }
 }
 
-// NG: chunk groups of 64 (one ballot word each) the target cloud may have: 4 (up to 16384 points: 8 KB of boxes in LDS, 17 workgroups per
-// CU) or 8 (up to 32768: 16 KB, 9 per CU)
-template <int QPT, int NG>
-__global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __restrict__ qs, int n, const float4* __restrict__ rs,
+// LDS hand-off between the lanes of ONE wave: a wave's DS instructions execute in order, so a read issued after a write sees it; the wait
+// retires the outstanding ones and the asm statement keeps the compiler from moving LDS accesses across it.  No workgroup barrier.
+__device__ __forceinline__ void vnp_wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// NG: chunk groups of 64 (one ballot word each) the target cloud may have: 4 (up to 16384 points: 8 KB of boxes in LDS) or 8 (up to
+// 32768: 16 KB).  WPB: query waves per workgroup.  The waves of a workgroup scan the same target cloud and share ONE LDS copy of its chunk
+// boxes (loaded together, one barrier); from there on every wave is on its own — its 64 queries, its KB tiles of 1 KB, its own sequence
+// of chunks, no barrier (a wave's LDS operations execute in order).
+// Round 5, what bounds the scan (profiles/r05_chamfer_pmc.txt, scripts/experiments/chamfer_pmc.py / chamfer_hist.py; B = 32, 16384 x 16384):
+// 118 M VALU wave-instructions per launch, VALU busy 0.62 at ~2 resident waves per SIMD; a wave scans 25 chunks on average (uniform
+// clouds: p99 46, max 54), i.e. 9 VALU instructions per (query, target) pair x 1590 pairs per query = the time.  Measured in one process
+// against the round-4 kernel (one wave per workgroup, one chunk per visit), same outputs bit for bit: (WPB, KB) = (4, 4) -1.5 / -4 /
+// -2.5 % per call on uniform / near-copy / blob-vs-spread clouds, (4, 1) 0 / -0.5 / -6 %, (4, 2) and (2, 4) slower.  Dropped: the
+// minimum as a 32-bit (distance, index) pair with a tie flag and an exact second scan (VALU instructions -16 %, time +8...+27 %: the
+// flag's compare-to-SGPR + s_or per target stalls the in-order issue); chunk boxes through scalar loads (every skip test waits for a
+// memory round trip: +17 %).
+template <int QPT, int NG, int WPB, int KB>
+__global__ void __launch_bounds__(64 * WPB) vnp_chamfer_pruned_kernel(const float4* __restrict__ qs, int n, const float4* __restrict__ rs,
                                                                 int m, const float4* __restrict__ rbox, const int* __restrict__ flag,
                                                                 float* __restrict__ dist, int* __restrict__ idx,
                                                                 unsigned long long* __restrict__ visited, unsigned* __restrict__ wave_chunks)
@@ -392,9 +407,13 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
     // the chunk being scanned, two points interleaved per 32 bytes {x0 x1 y0 y1 | z0 z1 i0 i1}: a lane evaluates TWO targets per step
     // with packed fp32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma: 6 instructions for the two distances instead of 12), each distance
     // by the same fmaf chain as before
-    __shared__ __attribute__((aligned(16))) float tile[CHP_CHUNK * 4];
-    const int b = blockIdx.y, lane = threadIdx.x;
-    const int base = blockIdx.x * (64 * QPT);
+    __shared__ __attribute__((aligned(16))) float tiles[WPB][KB * CHP_CHUNK * 4];
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = tiles[wave];
+    const int qgroup = blockIdx.x * WPB + wave;                    // this wave's group of 64 QPT queries; groups past the cloud's end idle
+    const bool active = qgroup * (64 * QPT) < n;
+    const int base = active ? qgroup * (64 * QPT) : 0;
     const float4* qb = qs + (size_t)b * n;
     const float4* rb = rs + (size_t)b * m;
     const int nchunk = (m + CHP_CHUNK - 1) / CHP_CHUNK;
@@ -421,7 +440,10 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
             ql[t] = fminf(ql[t], __shfl_xor(ql[t], o));
             qh[t] = fmaxf(qh[t], __shfl_xor(qh[t], o));
         }
-    // chunk boxes -> LDS; the group-box bound of chunk lane + 64 g classifies it: overlapping (0) / apart (> 0)
+    // chunk boxes -> LDS (all waves together), then the group-box bound of chunk lane + 64 g classifies it: overlapping (0) / apart (> 0)
+    for (int c = threadIdx.x; c < nchunk; c += 64 * WPB) { box[2 * c] = bx[2 * c]; box[2 * c + 1] = bx[2 * c + 1]; }
+    __syncthreads();
+    if (!active) return;
     unsigned long long near_mask[NG], far_mask[NG];
     float vfar[NG];                                               // this lane's chunk of group g: squared distance between the two boxes
     float lmin = INFINITY;
@@ -431,8 +453,7 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
         const int c = lane + 64 * g;
         float v = INFINITY;
         if (c < nchunk) {
-            const float4 l = bx[2 * c], h = bx[2 * c + 1];
-            box[2 * c] = l; box[2 * c + 1] = h;
+            const float4 l = box[2 * c], h = box[2 * c + 1];
             const float gx = fmaxf(0.f, fmaxf(l.x - qh[0], ql[0] - h.x));
             const float gy = fmaxf(0.f, fmaxf(l.y - qh[1], ql[1] - h.y));
             const float gz = fmaxf(0.f, fmaxf(l.z - qh[2], ql[2] - h.z));
@@ -451,34 +472,47 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
         if (ov < lmin || (ov == lmin && oc < cmin)) { lmin = ov; cmin = oc; }
     }
     const int c0 = __builtin_amdgcn_readfirstlane(cmin);
-    __syncthreads();
 
     int npairs = 0, nvisit = 0;                                   // (query, target) pairs / chunks this wave evaluates: the kernel's executed work
-    auto visit = [&](int c) {
-        const int r0 = c * CHP_CHUNK;
-        const int cnt = min(CHP_CHUNK, m - r0);
-        npairs += cnt;
-        ++nvisit;
-        __syncthreads();                                          // one wave per workgroup: orders the LDS reuse only
-        {
-            float4 v = make_float4(NAN, NAN, NAN, 0.f);           // slots past the chunk's end: NaN distances never win
-            if (lane < cnt) v = rb[r0 + lane];
-            float* dst = tile + (lane >> 1) * 8 + (lane & 1);
-            dst[0] = v.x; dst[2] = v.y; dst[4] = v.z; dst[6] = v.w;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < cnt; i += 2) {
-            const vnp_f4 ta = *(const vnp_f4*)(tile + i * 4);        // same address in every lane: LDS broadcast
-            const vnp_f4 tb = *(const vnp_f4*)(tile + i * 4 + 4);
+    // Up to KB needed chunks are fetched TOGETHER (their loads in flight at once, KB KB of LDS per wave) and then scanned one after the
+    // other: a wave pays the global-load latency of its chunks once per batch instead of once per chunk (round 5: per-segment stamps put
+    // two thirds of a visit into waiting for its 1 KB).  Chunks of a batch are chosen with the minima as they were BEFORE the batch, so a
+    // batch may scan a chunk that its own earlier chunks would have ruled out — more pairs, never a different result.
+    auto visit_batch = [&](const int (&cs)[KB], int nb) {
+        float4 v[KB];
+        int cnt[KB];
 #pragma unroll
-            for (int u = 0; u < QPT; ++u) {
-                const vnp_f2 dx = vnp_f2{ta[0], ta[1]} - qx[u], dy = vnp_f2{ta[2], ta[3]} - qy[u], dz = vnp_f2{tb[0], tb[1]} - qz[u];
-                const vnp_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                const unsigned long long k0 = ((unsigned long long)__float_as_uint(d[0]) << 32) | __float_as_uint(tb[2]);
-                const unsigned long long k1 = ((unsigned long long)__float_as_uint(d[1]) << 32) | __float_as_uint(tb[3]);
-                if (k0 < best[u]) best[u] = k0;                   // NaN distances (bits above +inf) never win
-                if (k1 < best[u]) best[u] = k1;
+        for (int j = 0; j < KB; ++j) {
+            const int r0 = cs[j] * CHP_CHUNK;
+            cnt[j] = j < nb ? min(CHP_CHUNK, m - r0) : 0;
+            v[j] = make_float4(NAN, NAN, NAN, 0.f);               // slots past the chunk's end: NaN distances never win
+            if (lane < cnt[j]) v[j] = rb[r0 + lane];
+            npairs += cnt[j];
+        }
+        nvisit += nb;
+        vnp_wave_lds_sync();                                      // the tiles are this wave's own: order their reuse, no workgroup barrier
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            float* dst = tile + j * (CHP_CHUNK * 4) + (lane >> 1) * 8 + (lane & 1);
+            if (j < nb) { dst[0] = v[j].x; dst[2] = v[j].y; dst[4] = v[j].z; dst[6] = v[j].w; }
+        }
+        vnp_wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float* tj = tile + j * (CHP_CHUNK * 4);
+#pragma unroll 4
+            for (int i = 0; i < cnt[j]; i += 2) {
+                const vnp_f4 ta = *(const vnp_f4*)(tj + i * 4);        // same address in every lane: LDS broadcast
+                const vnp_f4 tb = *(const vnp_f4*)(tj + i * 4 + 4);
+#pragma unroll
+                for (int u = 0; u < QPT; ++u) {
+                    const vnp_f2 dx = vnp_f2{ta[0], ta[1]} - qx[u], dy = vnp_f2{ta[2], ta[3]} - qy[u], dz = vnp_f2{tb[0], tb[1]} - qz[u];
+                    const vnp_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    const unsigned long long k0 = ((unsigned long long)__float_as_uint(d[0]) << 32) | __float_as_uint(tb[2]);
+                    const unsigned long long k1 = ((unsigned long long)__float_as_uint(d[1]) << 32) | __float_as_uint(tb[3]);
+                    if (k0 < best[u]) best[u] = k0;                   // NaN distances (bits above +inf) never win
+                    if (k1 < best[u]) best[u] = k1;
+                }
             }
         }
     };
@@ -509,7 +543,11 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
         for (int o = 32; o > 0; o >>= 1) mb = fmaxf(mb, __shfl_xor(mb, o));
         return mb;                                                // (+inf while any query has seen nothing; NaN distances never enter best)
     };
-    visit(c0);
+    int cs[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) cs[j] = c0;
+    visit_batch(cs, 1);                                           // the closest chunk alone: it sets the minima every later test prunes with
+    int nb = 0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         float maxbest = (pass == 1 && prune) ? wave_max_best() : INFINITY;
@@ -523,11 +561,20 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
                 const int c = 64 * g + bit;
                 if (c == c0) continue;
                 if (prune && !needed(c)) continue;
-                visit(c);
+#pragma unroll
+                for (int j = 0; j < KB; ++j) if (j == nb) cs[j] = c;          // (nb is wave-uniform: scalar selects, no indexed registers)
+                if (++nb < KB) continue;
+                visit_batch(cs, KB);
+                nb = 0;
                 if (pass == 1 && prune) {
                     maxbest = wave_max_best();
                     mask &= __ballot(!(vfar[g] > maxbest));
                 }
+            }
+            if (nb > 0) {                                         // a group ends: its last chunks, before the next group's far test reads the minima
+                visit_batch(cs, nb);
+                nb = 0;
+                if (pass == 1 && prune) maxbest = wave_max_best();
             }
         }
     }
@@ -540,7 +587,7 @@ __global__ void __launch_bounds__(64) vnp_chamfer_pruned_kernel(const float4* __
     }
     if (lane == 0) {
         atomicAdd(visited, (unsigned long long)npairs * (unsigned long long)min(64 * QPT, n - base));
-        if (wave_chunks) wave_chunks[(size_t)b * gridDim.x + blockIdx.x] = (unsigned)nvisit;
+        if (wave_chunks) wave_chunks[(size_t)b * ((n + 64 * QPT - 1) / (64 * QPT)) + qgroup] = (unsigned)nvisit;
     }
 }
 
@@ -590,18 +637,16 @@ extern "C" int vnp_chamfer_fwd_pruned(hipStream_t st, int B, int n, const float*
     e = vnp_allow_dynamic_lds(lds_ok, (const void*)vnp_chamfer_bin_kernel, CHP_BINS * 4);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(vnp_chamfer_bin_kernel, dim3(B, 2), dim3(1024), (size_t)CHP_BINS * 4, st, xyz1, n, s1, b1, xyz2, m, s2, b2, flag);
-    if (c2 <= 256)
-        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 4>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
-                           (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2), wc1);
-    else
-        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 8>), dim3(vnp_cdiv(n, 64 * CHP_QPT), B), dim3(64), 0, st,
-                           (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2), wc1);
-    if (c1 <= 256)
-        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 4>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
-                           (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2), wc2);
-    else
-        hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, 8>), dim3(vnp_cdiv(m, 64 * CHP_QPT), B), dim3(64), 0, st,
-                           (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2), wc2);
+    const int g1 = vnp_cdiv(n, 64 * CHP_QPT), g2 = vnp_cdiv(m, 64 * CHP_QPT);
+#define VNP_CHP_LAUNCH(NGV, WPBV, KBV, GROUPS, ...) hipLaunchKernelGGL((vnp_chamfer_pruned_kernel<CHP_QPT, NGV, WPBV, KBV>), dim3(vnp_cdiv(GROUPS, WPBV), B), dim3(64 * WPBV), 0, st, __VA_ARGS__)
+#define VNP_CHP_BOTH(WPBV, KBV) do { \
+        if (c2 <= 256) VNP_CHP_LAUNCH(4, WPBV, KBV, g1, (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2), wc1); \
+        else VNP_CHP_LAUNCH(8, WPBV, KBV, g1, (const float4*)s1, n, (const float4*)s2, m, (const float4*)b2, (const int*)flag, dist1, idx1, (unsigned long long*)(flag + 2), wc1); \
+        if (c1 <= 256) VNP_CHP_LAUNCH(4, WPBV, KBV, g2, (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2), wc2); \
+        else VNP_CHP_LAUNCH(8, WPBV, KBV, g2, (const float4*)s2, m, (const float4*)s1, n, (const float4*)b1, (const int*)flag, dist2, idx2, (unsigned long long*)(flag + 2), wc2); } while (0)
+    VNP_CHP_BOTH(4, 4);
+#undef VNP_CHP_BOTH
+#undef VNP_CHP_LAUNCH
     return vnp_last_error();
 }
 
