@@ -568,6 +568,21 @@ def main():
                                                      "step; DESIGN.md §4 removed two thirds of the as-written products, so this is "
                                                      "reference-equivalent work, not executed work"}
                                             if (Mc == 1024 and all_t > 0) else None)}}
+        # the whole step against the HBM roofline (north_star: throughput "as fraction of the HBM roofline"): fabric bytes of one step
+        # (every kernel's FETCH_SIZE x 2 + WRITE_SIZE, profiles/ — bench.py cannot run counters on itself) / this run's step time
+        hbm_roofline = None
+        try:
+            sb = json.load(open(summ)).get("step_fabric_bytes")
+            if sb and gemm_mode == "split":
+                hbm_roofline = {"bytes_per_step": sb, "source": os.path.relpath(summ, ROOT), "achieved": round(sb / (ms * 1e-3) / 1e9, 1),
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(sb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                "bytes_per_completed_point": round(sb / (B * Md), 1),
+                                "note": "PMC fabric bytes of ALL kernels of one step (recorded passes under profiles/) over this run's wall time per "
+                                        "step; the step is matrix-pipe bound (roofline), so this fraction is a description, not a target: the "
+                                        "HBM-bound kernels themselves run at 4.7-5.6 TB/s (roofline_other), 0.95-1.0 of the chip's measured "
+                                        "mixed read/write ceiling (profiles/r02_hbm_yardstick.txt)"}
+        except Exception:
+            pass
         steps_total = args.warmup + args.steps
         pool_path = {"calls_since_start": pool_paths, "steps_since_start": steps_total,
                      "note": "VNLinear -> VNMaxPool (maxpool2) calls by path over warm-up + timed steps: `screened` = exact screened search, "
@@ -588,7 +603,7 @@ def main():
                           "parallelism": f"dp{world}", "allreduce": allreduce["mode"]},
                "points_per_s_per_gpu": value / world, "ranks_joined": ranks_joined, "allreduce": allreduce,
                "loss": {"total": loss.item(), "coarse_cd_l1": loss1.item(), "dense_cd_l1": loss2.item()},
-               "roofline": roofline, "pool_path": pool_path, "chamfer_dense_loss_in_step": chamfer_step, "sustained": sustained}
+               "roofline": roofline, "hbm_roofline": hbm_roofline, "pool_path": pool_path, "chamfer_dense_loss_in_step": chamfer_step, "sustained": sustained}
         if fp32_mode is not None:
             out["fp32_mfma_mode"] = fp32_mode
         if world == 1 and not args.no_extras:

@@ -94,6 +94,12 @@ if fetch_dir:
             t["TBps_at_avg_duration"] = (rd + wt) / (summary["kernels"][k]["avg_us"] * 1e-6) / 1e12
         traffic[k] = t
     summary["traffic"] = traffic
+    # the whole step through the fabric: every kernel's bytes per launch x its launches per step (launch counts from the --stats pass)
+    if steps:
+        tot = sum(t["hbm_bytes_per_launch"] * summary["kernels"][k]["calls"] / steps for k, t in traffic.items() if k in summary["kernels"])
+        summary["step_fabric_bytes"] = tot
+        summary["step_fabric_note"] = ("sum over the step's kernels of (FETCH_SIZE*2 + WRITE_SIZE) per launch x launches per step; divided by the "
+                                       "step time it is the step's average HBM-side rate (bench.py: hbm_roofline)")
     summary["traffic_note"] = ("FETCH_SIZE*2*1024 + WRITE_SIZE*1024 bytes per launch, separate --pmc passes (gfx950 correction per "
                                "MI355X_MICROARCH.md; L2-miss traffic: Infinity-Cache hits are included); TBps uses the un-profiled average "
                                "duration of the --stats pass")
