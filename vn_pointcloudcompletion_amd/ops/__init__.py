@@ -17,7 +17,8 @@ from .core import (BN_EPS, BN_MOMENTUM, FromRowsFn, SplitColsFn, ToRowsFn, Weigh
                    gemm_pd_stats, reduce_pairs, reduce_rows, set_amax, split_cols)
 from .dirlayer import DirContractFn, DirExpandFn, DirLinearMaxPoolFn, VNDirLinearLeakyFn, unit_dirs
 from .fold import FoldBnLeakyFn, FoldFn, GroupFoldBnLeakyFn, LinOutFn, group_fold_ok
-from .graph import (EdgeConvFn, EdgeConvPackedFn, EdgeConvRank1Fn, EdgeGatherAddFn, EdgeWeightsFn, FpsPlan, GatherPointsFn, edge_reverse, fps_indices,
+from .graph import (EdgeConvFn, EdgeConvPackedFn, EdgeConvRank1Fn, EdgeGatherAddFn, EdgeWeightsFn, FpsPlan, GatherPointsFn, edge_reverse, edge_reverse_ahead,
+                    fps_indices,
                     knn_indices)
 from .linear import VNBnLeakyFn, VNLeakyDirFn, VNLeakyFn, VNLinearFn, VNLinearLeakyFn, VNLinearLeakyOutFn
 from .pool import _screen_state, VNLinearMaxPoolFn, VNLinearPoolTapFn, VNMaxPoolFn, VNMaxPoolTapFn, VNMeanPoolFn

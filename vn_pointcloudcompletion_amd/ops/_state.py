@@ -53,6 +53,7 @@ class _Switches:
     WGRAD_SLICE_TILES = 64          # K-tiles (of 32 rows) per split-K slice of a weight gradient that is multiplied on
     WGRAD_SLAB_BYTES = 128 << 20    # ... as long as the slabs stay under this
     FPS_AHEAD = True                # an encoder's furthest-point samplings on a side HIP stream beside its kNN / EdgeConv launches (FpsPlan)
+    REV_AHEAD = True                # a graph's reverse adjacency (needed by the backward pass only) built on the side stream during the forward
 
 
 SW = _Switches()

@@ -193,18 +193,46 @@ class EdgeGatherAddFn(Function):
 
 
 
-def edge_reverse(nbr, Pu):
-    """Reverse adjacency (start [Pu + 1], rev [Pq * k]) of a neighbour table, cached on the tensor: layers that share a graph share it."""
-    cached = getattr(nbr, "_vnp_rev", None)
-    if cached is not None and cached[0].shape[0] == Pu + 1:
-        return cached
+def _edge_reverse_launch(nbr, Pu):
     Pq, k = nbr.shape
     start = torch.empty(Pu + 1, device=nbr.device, dtype=torch.int32)
     rev = torch.empty(Pq * k, device=nbr.device, dtype=torch.int32)
     ws = torch.empty(Pu + 1 + Pq * k, device=nbr.device, dtype=torch.int32)
-    call("vnp_edge_reverse", ptr(nbr), Pq, k, Pu, ptr(start), ptr(rev), ptr(ws))
+    return start, rev, ws
+
+
+def edge_reverse(nbr, Pu):
+    """Reverse adjacency (start [Pu + 1], rev [Pq * k]) of a neighbour table, cached on the tensor: layers that share a graph share it.
+    A table whose lists were started ahead of time (edge_reverse_ahead) is waited for here, once."""
+    cached = getattr(nbr, "_vnp_rev", None)
+    if cached is not None and cached[0].shape[0] == Pu + 1:
+        if len(cached) == 3:                                       # built on the side stream: this stream waits for it, then forgets the event
+            torch.cuda.current_stream(nbr.device).wait_event(cached[2])
+            nbr._vnp_rev = cached[:2]
+        return cached[0], cached[1]
+    start, rev, ws = _edge_reverse_launch(nbr, Pu)
+    call("vnp_edge_reverse", ptr(nbr), nbr.shape[0], nbr.shape[1], Pu, ptr(start), ptr(rev), ptr(ws))
     nbr._vnp_rev = (start, rev)
     return start, rev
+
+
+def edge_reverse_ahead(nbr, Pu):
+    """Start the reverse adjacency of a graph whose backward pass will need it (five small launches, ~55 us, one of them a single
+    workgroup) on the side HIP stream while the forward pass goes on; edge_reverse waits for its event.  The buffers are allocated on the
+    calling stream and marked record_stream(side), like FpsPlan's."""
+    if not SW.REV_AHEAD or HK.trace is not None or getattr(nbr, "_vnp_rev", None) is not None:
+        return
+    dev = nbr.device
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    start, rev, ws = _edge_reverse_launch(nbr, Pu)
+    side.wait_stream(main)                                         # the table is written by work queued on the calling stream
+    for t in (nbr, start, rev, ws):
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        call("vnp_edge_reverse", ptr(nbr), nbr.shape[0], nbr.shape[1], Pu, ptr(start), ptr(rev), ptr(ws))
+        ev = torch.cuda.Event()
+        ev.record(side)
+    nbr._vnp_rev = (start, rev, ev)
 
 
 def _edge_pass(mode, u, v, r1, nbr, C, bn, ns, partial=None, out=None, go=None, sums=None, gv=None):
@@ -222,12 +250,14 @@ def _edge_pass(mode, u, v, r1, nbr, C, bn, ns, partial=None, out=None, go=None, 
              ptr(beta), float(ns), *tail, ptr(gv), _ld(gv) if gv is not None else 0)
 
 
-def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns, r1=None, C=None):
+def _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns, r1=None, C=None, ahead=False):
     """The two forward passes of the fused EdgeConv on u [Pu*3, >= 2C], v [Pq*3, >= 2C] (row strides free) — or, with ``r1`` = (wu, wv)
     [2C] and ``C`` given, on the coordinates u = v = x [P*3, 1]: (out, mean, rstd, nblk)."""
     Pq, k = nbr.shape
     C = u.shape[1] // 2 if C is None else C
     dev = u.device
+    if ahead:
+        edge_reverse_ahead(nbr, u.shape[0] // 3)
     qb = _lib.lib().vnp_edge_block_queries()
     nblk = (Pq + qb - 1) // qb
     if training:
@@ -279,7 +309,7 @@ class EdgeConvFn(Function):
     def forward(ctx, u, v, nbr, gamma, beta, running_mean, running_var, training, ns):
         u, v = _rows(u), _rows(v)
         nbr = nbr.contiguous()
-        out, mean, rstd, nblk = _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns)
+        out, mean, rstd, nblk = _edge_conv_forward(u, v, nbr, gamma, beta, running_mean, running_var, training, ns, ahead=any(ctx.needs_input_grad))
         ctx.save_for_backward(u, v, nbr, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(ns), nblk)
         return out
@@ -307,7 +337,8 @@ class EdgeConvPackedFn(Function):
         uv = _rows(uv)
         nbr = nbr.contiguous()
         C2 = uv.shape[1] // 2
-        out, mean, rstd, nblk = _edge_conv_forward(uv[:, :C2], uv[:, C2:], nbr, gamma, beta, running_mean, running_var, training, ns)
+        out, mean, rstd, nblk = _edge_conv_forward(uv[:, :C2], uv[:, C2:], nbr, gamma, beta, running_mean, running_var, training, ns,
+                                                   ahead=any(ctx.needs_input_grad))
         ctx.save_for_backward(uv, nbr, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(ns), nblk)
         return out
@@ -340,7 +371,7 @@ class EdgeConvRank1Fn(Function):
         if x.shape[1] != 1 or Wuv.shape[1] != 1 or x.shape[0] != nbr.shape[0] * 3:
             raise _lib.VnpError("EdgeConvRank1Fn: one input channel and a graph on the layer's own points expected")
         out, mean, rstd, nblk = _edge_conv_forward(x, x, nbr, gamma, beta, running_mean, running_var, training, ns,
-                                                   r1=(Wuv[:2 * C], Wuv[2 * C:]), C=C)
+                                                   r1=(Wuv[:2 * C], Wuv[2 * C:]), C=C, ahead=any(ctx.needs_input_grad))
         trace("edge_conv_rank1")
         ctx.save_for_backward(x, Wuv, nbr, gamma, beta, mean, rstd)
         ctx.cfg = (bool(training), float(ns), nblk)
