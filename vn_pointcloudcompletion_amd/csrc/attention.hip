@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) vnp_ln_fwd_kernel(const float* __restrict
                                                         const float* __restrict__ a1, int lda1, const float* __restrict__ a2, int lda2,
                                                         float* sum_out, int lds)
 {
-    const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long pt = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pt >= P) return;
     const float* r = x + (size_t)pt * 3 * ldx;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) vnp_ln_bwd_kernel(const float* __restrict
                                                         float* __restrict__ part, const float* __restrict__ gres, int ldgres)
 {
     extern __shared__ float sm[];                 // [4 waves][2][C]
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long long pt = (long long)blockIdx.x * 4 + w;
     float* my = sm + (size_t)w * 2 * C;
     for (int c = lane; c < C; c += 64) { my[c] = 0.f; my[C + c] = 0.f; }
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) vnp_head_permute_kernel(const float* __re
     const int ch = C / H, Dh = ch * 3, per = 3 * C;
     const long long tok0 = (long long)blockIdx.x * PN, ntok = (long long)B * N;
     const int cnt = (int)(ntok - tok0 < PN ? ntok - tok0 : PN);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // a wave walks whole rows / whole head slices, its lanes the contiguous floats inside: the only divisions by run-time values are
     // per slice, not per element (with one flat index per element the kernel was bound by integer division, not by memory)
     const float* rowsp = TO_HEADS ? src : dst;
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) vnp_head_permute_fm_kernel(const float* _
     const int ch = C / H, Dh = ch * 3;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int n0 = blockIdx.x * TT, cnt = N - n0 < TT ? N - n0 : TT;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // vec (ch % 4 == 0, 16-byte aligned rows; TS % 4 == 0 with TS / 4 odd): every LDS access is 16 bytes wide and conflict-free —
     //   rows side: a (token, component) segment is ch contiguous floats of one row; a wave moves 64 / (ch / 4) segments per instruction
     //     as float4 (ds_write_b128: 8 contiguous lanes = 128 contiguous bytes);
@@ -283,7 +283,7 @@ static inline int vnp_head_permute_pn(int C) { const int pn = 6144 / (3 * C); re
 template <int NV>
 __global__ void __launch_bounds__(256) vnp_softmax_fwd_reg_kernel(float* __restrict__ S, long long R, float scale)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= R) return;
     float* row = S + (size_t)r * (NV * 64);
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) vnp_softmax_fwd_reg_kernel(float* __restr
 template <int NV>
 __global__ void __launch_bounds__(256) vnp_softmax_bwd_reg_kernel(const float* __restrict__ Pm, float* __restrict__ dP, long long R, float scale)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= R) return;
     const float* p = Pm + (size_t)r * (NV * 64);
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) vnp_softmax_bwd_reg_kernel(const float* _
 // in-place row softmax of S[R][L] * scale; one wave per row
 __global__ void __launch_bounds__(256) vnp_softmax_fwd_kernel(float* __restrict__ S, long long R, int L, float scale)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= R) return;
     float* row = S + (size_t)r * L;
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) vnp_softmax_fwd_kernel(float* __restrict_
 // dS = P * (dP - sum_j dP*P) * scale, written over dP
 __global__ void __launch_bounds__(256) vnp_softmax_bwd_kernel(const float* __restrict__ Pm, float* __restrict__ dP, long long R, int L, float scale)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= R) return;
     const float* p = Pm + (size_t)r * L;

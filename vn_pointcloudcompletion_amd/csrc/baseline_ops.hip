@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) vnp_bn1d_stats_kernel(const float* __rest
 {
     __shared__ float rm[4][64], rM[4][64];
     __shared__ int rn[4];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long r0 = (long long)blockIdx.y * VNP_B1_CHUNK, r1 = min(P, r0 + VNP_B1_CHUNK);
     float mean = 0.f, m2 = 0.f; int n = 0;
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) vnp_bn1d_act_fwd_kernel(const float* __re
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, int act, float slope)
 {
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     if (c >= C) return;
     const float mu = mean[c], sc = rstd[c] * gamma[c], be = beta[c];
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) vnp_bn1d_act_bwd_kernel(const float* __re
                                                               float2* __restrict__ partial, const float* __restrict__ sums, float inv_count)
 {
     __shared__ double2 red[4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) vnp_edge_gn_kernel(const VnpEdgeGnArgs a)
 {
     __shared__ float red[4][4][64];
     __shared__ int cnt[4];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx, C = a.C, k = a.k;
     const bool live = c < C;
     const int cc = live ? c : 0;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) vnp_edge_gn_gather_kernel(const VnpEdgeGn
                                                                  long long s_base, long long Pk, float* __restrict__ gu, int ldgu)
 {
     const int cx = threadIdx.x & 63;
-    const long long s = s_base + (long long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    const long long s = s_base + (long long)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + cx, C = a.C, k = a.k;
     if (s >= Pk || c >= C) return;
     const int cg = C / a.G, g = c / cg;

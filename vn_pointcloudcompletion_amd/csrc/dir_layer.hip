@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) vnp_dir_layer_kernel(const VnpDirArgs a)
     __shared__ double2 redd[MODE == 2 ? 4 : 1][64];
     __shared__ float red6[MODE == 3 ? 4 : 1][6][64];
     __shared__ int cnt[4];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const int C = a.C;
     const bool live = c < C;
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) vnp_dir_contract_kernel(float* __restrict
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     if (c >= C) return;
-    for (long long n = (long long)blockIdx.y * 4 + (threadIdx.x >> 6); n < P; n += (long long)gridDim.y * 4) {
+    for (long long n = (long long)blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); n < P; n += (long long)gridDim.y * 4) {
         const float u0 = u[n * 3], u1 = u[n * 3 + 1], u2 = u[n * 3 + 2];
         float* r = rows + (size_t)n * 3 * ldr + c;
         if (expand) {
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(1024) vnp_dir_pool_fwd_kernel(const float* __r
 {
     __shared__ float rv[16][64];
     __shared__ int ri[16][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long g = blockIdx.y;
     float best = -INFINITY; int bi = 0x7fffffff;

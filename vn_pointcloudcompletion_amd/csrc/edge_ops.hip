@@ -48,7 +48,15 @@ __device__ __forceinline__ void vnp_xcd_block(int& bx, int& by)
 // one rounding of the product and no contraction with the addition behind it: the bits of the stored u = x W^T (a K = 1 product)
 __device__ __forceinline__ float vnp_mul_alone(float a, float b) { float p = a * b; asm volatile("" : "+v"(p)); return p; }
 
-template <int MODE, bool R1 = false>
+// CW (template): channel lanes.  With 64 a query lane IS a wave: its index, the query, the neighbour list and every row base are SCALARS
+// (v_readfirstlane of the wave index) — the neighbour ids arrive through scalar loads, a gather's address is one SGPR base + the lane's
+// column, and the 64-bit per-lane address arithmetic of every edge (round 5: a third of the pass's vector instructions) is gone.
+// base (a scalar where the caller's row is one) + the lane's BYTE offset as an unsigned 32-bit value: the form the saddr addressing of
+// global_load / global_store takes (SGPR pair + one VGPR), instead of a 64-bit per-lane pointer built for every access
+__device__ __forceinline__ float vnp_ldo(const float* base, unsigned boff) { return *(const float*)((const char*)base + boff); }
+__device__ __forceinline__ void vnp_sto(float* base, unsigned boff, float v) { *(float*)((char*)base + boff) = v; }
+
+template <int MODE, bool R1 = false, int CW = 64>
 __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a)
 {
     // the backward modes use v_rcp_f32 / v_sqrt_f32 (1 ulp each) as the other gradient kernels do; the forward modes keep IEEE division
@@ -60,13 +68,14 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
     __shared__ float2 red[256];
     __shared__ int cnt[8];
     const int C = a.C, k = a.k;
-    const int CW = C <= 32 ? 32 : 64, NQ = 256 / CW;
-    const int cx = threadIdx.x & (CW - 1), py = threadIdx.x / CW;
+    constexpr int NQ = 256 / CW;
+    const int cx = threadIdx.x & (CW - 1), py = CW == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)threadIdx.x / CW;
     int bx, by;
     vnp_xcd_block(bx, by);
     const int c = bx * CW + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
+    const unsigned cb = (unsigned)cc * 4u, cbs = (unsigned)c * 4u;          // the lane's column as a byte offset (loads: clamped; stores: live lanes only)
     const long long q0 = (long long)by * VNP_EDGE_QB;
     const long long q1 = min(a.Pq, q0 + VNP_EDGE_QB);
     float mu = 0.f, rs = 0.f, ga = 0.f, be = 0.f, m1 = 0.f, m2 = 0.f;
@@ -85,26 +94,27 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             vp0 = vnp_mul_alone(c0, wvp); vp1 = vnp_mul_alone(c1, wvp); vp2 = vnp_mul_alone(c2, wvp);
             vd0 = vnp_mul_alone(c0, wvd); vd1 = vnp_mul_alone(c1, wvd); vd2 = vnp_mul_alone(c2, wvd);
         } else {
-            const float* rv = a.v + (size_t)q * 3 * a.ldv + cc;
-            vp0 = rv[0]; vp1 = rv[a.ldv]; vp2 = rv[2 * a.ldv];
-            vd0 = rv[C]; vd1 = rv[a.ldv + C]; vd2 = rv[2 * a.ldv + C];
+            // (row bases first, the lane's column last: with a scalar query the bases stay in SGPRs and a load is base + one 32-bit lane offset)
+            const float* rv = a.v + (size_t)q * 3 * a.ldv;
+            vp0 = vnp_ldo(rv, cb); vp1 = vnp_ldo(rv + a.ldv, cb); vp2 = vnp_ldo(rv + 2 * a.ldv, cb);
+            vd0 = vnp_ldo(rv + C, cb); vd1 = vnp_ldo(rv + a.ldv + C, cb); vd2 = vnp_ldo(rv + 2 * a.ldv + C, cb);
         }
         float ge0 = 0.f, ge1 = 0.f, ge2 = 0.f;
         if (MODE >= 2) {
-            const float* rg = a.go + (size_t)q * 3 * a.ldgo + cc;
-            ge0 = rg[0] * kinv; ge1 = rg[a.ldgo] * kinv; ge2 = rg[2 * a.ldgo] * kinv;     // vnp_mean_pool_bwd: g / gs (gradients: 1 ulp, as EDIV)
+            const float* rg = a.go + (size_t)q * 3 * a.ldgo;
+            ge0 = vnp_ldo(rg, cb) * kinv; ge1 = vnp_ldo(rg + a.ldgo, cb) * kinv; ge2 = vnp_ldo(rg + 2 * a.ldgo, cb) * kinv;     // vnp_mean_pool_bwd: g / gs (gradients: 1 ulp, as EDIV)
         }
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f;                 // MODE 1: sum of outputs; MODE 3: gv (p | d)
         const int* nb = a.nbr + (size_t)q * k;
 #pragma unroll 4
         for (int j = 0; j < k; ++j) {
             const size_t urow = (size_t)nb[j] * 3;
-            const float* ru = R1 ? a.u + urow : a.u + urow * a.ldu + cc;
+            const float* ru = R1 ? a.u + urow : a.u + urow * a.ldu;                       // row base (a scalar when the query is one)
             float x0, x1, x2, t0 = 0.f, t1 = 0.f, t2 = 0.f;
             if (R1) {
                 t0 = ru[0]; t1 = ru[1]; t2 = ru[2];                                          // the neighbour's coordinates: 12 bytes, not 24 C
                 x0 = vnp_mul_alone(t0, wup) + vp0; x1 = vnp_mul_alone(t1, wup) + vp1; x2 = vnp_mul_alone(t2, wup) + vp2;
-            } else { x0 = ru[0] + vp0; x1 = ru[a.ldu] + vp1; x2 = ru[2 * a.ldu] + vp2; }
+            } else { x0 = vnp_ldo(ru, cb) + vp0; x1 = vnp_ldo(ru + a.ldu, cb) + vp1; x2 = vnp_ldo(ru + 2 * a.ldu, cb) + vp2; }
             if (MODE == 0) {
                 // statistics pass: hardware sqrt and reciprocal (1 ulp each) — the pass was bound by the IEEE sqrt / division sequences
                 // (~22 of its ~30 instructions per edge and channel); the running statistics move by ~1e-7 relative
@@ -119,7 +129,7 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             const float n = pn + VNP_EPS;
             float d0, d1, d2;
             if (R1) { d0 = vnp_mul_alone(t0, wud) + vd0; d1 = vnp_mul_alone(t1, wud) + vd1; d2 = vnp_mul_alone(t2, wud) + vd2; }
-            else { d0 = ru[C] + vd0; d1 = ru[a.ldu + C] + vd1; d2 = ru[2 * a.ldu + C] + vd2; }
+            else { d0 = vnp_ldo(ru + C, cb) + vd0; d1 = vnp_ldo(ru + a.ldu + C, cb) + vd1; d2 = vnp_ldo(ru + 2 * a.ldu + C, cb) + vd2; }
             const float xh = (n - mu) * rs;
             const float nh = xh * ga + be;
             const float s = EDIV(nh, n);
@@ -155,13 +165,13 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
             o0 += f0; o1 += f1; o2 += f2; h0 += e0; h1 += e1; h2 += e2;
         }
         if (MODE == 1 && live) {
-            float* w = a.out + (size_t)q * 3 * a.ldo + c;
-            w[0] = o0 / kf; w[a.ldo] = o1 / kf; w[2 * a.ldo] = o2 / kf;                    // vnp_mean_pool_fwd: s / gs
+            float* w = a.out + (size_t)q * 3 * a.ldo;
+            vnp_sto(w, cbs, o0 / kf); vnp_sto(w + a.ldo, cbs, o1 / kf); vnp_sto(w + 2 * a.ldo, cbs, o2 / kf);        // vnp_mean_pool_fwd: s / gs
         }
         if (MODE == 3 && live) {
-            float* w = a.gv + (size_t)q * 3 * a.ldgv + c;
-            w[0] = o0; w[a.ldgv] = o1; w[2 * a.ldgv] = o2;
-            w[C] = h0; w[a.ldgv + C] = h1; w[2 * a.ldgv + C] = h2;
+            float* w = a.gv + (size_t)q * 3 * a.ldgv;
+            vnp_sto(w, cbs, o0); vnp_sto(w + a.ldgv, cbs, o1); vnp_sto(w + 2 * a.ldgv, cbs, o2);
+            vnp_sto(w + C, cbs, h0); vnp_sto(w + a.ldgv + C, cbs, h1); vnp_sto(w + 2 * a.ldgv + C, cbs, h2);
         }
     }
     if (MODE == 0) {
@@ -196,20 +206,21 @@ __global__ void __launch_bounds__(256) vnp_edge_fused_kernel(const VnpEdgeArgs a
 // A workgroup = 64 channels x 4 edge lanes walks VNP_EDGE_SB consecutive sources; the four lanes share a source's list (edge e, e + 4, ...:
 // a hub of a feature-space graph with hundreds of incoming edges does not serialise on one thread) and meet in LDS in a fixed order.
 #define VNP_EDGE_SB 16
-template <bool R1 = false>
+template <bool R1 = false, int CW = 64>
 __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArgs a, const int* __restrict__ rstart, const int* __restrict__ rev,
                                                                long long Pu)
 {
     constexpr int MODE = 3;
     __shared__ double red[7 * 6 * 32];               // [NQ - 1][6][CW]: 64 channel lanes x 4 edge lanes, or 32 x 8 for C <= 32
     const int C = a.C;
-    const int CW = C <= 32 ? 32 : 64, NQ = 256 / CW;
-    const int cx = threadIdx.x & (CW - 1), py = threadIdx.x / CW;
+    constexpr int NQ = 256 / CW;
+    const int cx = threadIdx.x & (CW - 1), py = CW == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)threadIdx.x / CW;
     int bx, by;
     vnp_xcd_block(bx, by);
     const int c = bx * CW + cx;
     const bool live = c < C;
     const int cc = live ? c : 0;
+    const unsigned cb = (unsigned)cc * 4u, cbs = (unsigned)c * 4u;
     const long long s0 = (long long)by * VNP_EDGE_SB;
     const long long s1 = min(Pu, s0 + VNP_EDGE_SB);
     const float mu = a.mean[cc], rs = a.rstd[cc], ga = a.gamma[cc], be = a.beta[cc];
@@ -226,27 +237,27 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
             up0 = vnp_mul_alone(c0, wup); up1 = vnp_mul_alone(c1, wup); up2 = vnp_mul_alone(c2, wup);
             ud0 = vnp_mul_alone(c0, wud); ud1 = vnp_mul_alone(c1, wud); ud2 = vnp_mul_alone(c2, wud);
         } else {
-            const float* ru = a.u + (size_t)sp * 3 * a.ldu + cc;
-            up0 = ru[0]; up1 = ru[a.ldu]; up2 = ru[2 * a.ldu];
-            ud0 = ru[C]; ud1 = ru[a.ldu + C]; ud2 = ru[2 * a.ldu + C];
+            const float* ru = a.u + (size_t)sp * 3 * a.ldu;
+            up0 = vnp_ldo(ru, cb); up1 = vnp_ldo(ru + a.ldu, cb); up2 = vnp_ldo(ru + 2 * a.ldu, cb);
+            ud0 = vnp_ldo(ru + C, cb); ud1 = vnp_ldo(ru + a.ldu + C, cb); ud2 = vnp_ldo(ru + 2 * a.ldu + C, cb);
         }
         double F0 = 0.0, F1 = 0.0, F2 = 0.0, E0 = 0.0, E1 = 0.0, E2 = 0.0;
         const int e1 = rstart[sp + 1];
 #pragma unroll 2
         for (int e = rstart[sp] + py; e < e1; e += NQ) {
             const size_t q = (size_t)rev[e];
-            const float* rv = R1 ? a.v + q * 3 : a.v + q * 3 * a.ldv + cc;
-            const float* rg = a.go + q * 3 * a.ldgo + cc;
+            const float* rv = R1 ? a.v + q * 3 : a.v + q * 3 * a.ldv;
+            const float* rg = a.go + q * 3 * a.ldgo;
             float x0, x1, x2, d0, d1, d2;
             if (R1) {
                 const float c0 = rv[0], c1 = rv[1], c2 = rv[2];
                 x0 = up0 + vnp_mul_alone(c0, wvp); x1 = up1 + vnp_mul_alone(c1, wvp); x2 = up2 + vnp_mul_alone(c2, wvp);
                 d0 = ud0 + vnp_mul_alone(c0, wvd); d1 = ud1 + vnp_mul_alone(c1, wvd); d2 = ud2 + vnp_mul_alone(c2, wvd);
             } else {
-                x0 = up0 + rv[0]; x1 = up1 + rv[a.ldv]; x2 = up2 + rv[2 * a.ldv];
-                d0 = ud0 + rv[C]; d1 = ud1 + rv[a.ldv + C]; d2 = ud2 + rv[2 * a.ldv + C];
+                x0 = up0 + vnp_ldo(rv, cb); x1 = up1 + vnp_ldo(rv + a.ldv, cb); x2 = up2 + vnp_ldo(rv + 2 * a.ldv, cb);
+                d0 = ud0 + vnp_ldo(rv + C, cb); d1 = ud1 + vnp_ldo(rv + a.ldv + C, cb); d2 = ud2 + vnp_ldo(rv + 2 * a.ldv + C, cb);
             }
-            const float ge0 = rg[0] * kinv, ge1 = rg[a.ldgo] * kinv, ge2 = rg[2 * a.ldgo] * kinv;
+            const float ge0 = vnp_ldo(rg, cb) * kinv, ge1 = vnp_ldo(rg + a.ldgo, cb) * kinv, ge2 = vnp_ldo(rg + 2 * a.ldgo, cb) * kinv;
             const float pn = ESQRT(vnp_sq3(x0, x1, x2));
             const float n = pn + VNP_EPS;
             const float xh = (n - mu) * rs;
@@ -284,9 +295,9 @@ __global__ void __launch_bounds__(256) vnp_edge_gather_u_kernel(const VnpEdgeArg
                 F0 += r[0]; F1 += r[CW]; F2 += r[2 * CW];
                 E0 += r[3 * CW]; E1 += r[4 * CW]; E2 += r[5 * CW];
             }
-            float* w = a.gu + (size_t)sp * 3 * a.ldgu + c;
-            w[0] = (float)F0; w[a.ldgu] = (float)F1; w[2 * a.ldgu] = (float)F2;
-            w[C] = (float)E0; w[a.ldgu + C] = (float)E1; w[2 * a.ldgu + C] = (float)E2;
+            float* w = a.gu + (size_t)sp * 3 * a.ldgu;
+            vnp_sto(w, cbs, (float)F0); vnp_sto(w + a.ldgu, cbs, (float)F1); vnp_sto(w + 2 * a.ldgu, cbs, (float)F2);
+            vnp_sto(w + C, cbs, (float)E0); vnp_sto(w + a.ldgu + C, cbs, (float)E1); vnp_sto(w + 2 * a.ldgu + C, cbs, (float)E2);
         }
         __syncthreads();
     }
@@ -431,18 +442,14 @@ static int vnp_edge_fused_impl(hipStream_t st, int mode, const float* u, int ldu
         if (go) s.go = go + (size_t)qoff * 3 * ldgo;
         if (gv) s.gv = gv + (size_t)qoff * 3 * ldgv;
         const dim3 grid(vnp_cdiv(C, C <= 32 ? 32 : 64), nb), block(256);
-        if (r1) switch (mode) {
-        case 0: hipLaunchKernelGGL((vnp_edge_fused_kernel<0, true>), grid, block, 0, st, s); break;
-        case 1: hipLaunchKernelGGL((vnp_edge_fused_kernel<1, true>), grid, block, 0, st, s); break;
-        case 2: hipLaunchKernelGGL((vnp_edge_fused_kernel<2, true>), grid, block, 0, st, s); break;
-        default: hipLaunchKernelGGL((vnp_edge_fused_kernel<3, true>), grid, block, 0, st, s); break;
-        }
-        else switch (mode) {
-        case 0: hipLaunchKernelGGL((vnp_edge_fused_kernel<0, false>), grid, block, 0, st, s); break;
-        case 1: hipLaunchKernelGGL((vnp_edge_fused_kernel<1, false>), grid, block, 0, st, s); break;
-        case 2: hipLaunchKernelGGL((vnp_edge_fused_kernel<2, false>), grid, block, 0, st, s); break;
-        default: hipLaunchKernelGGL((vnp_edge_fused_kernel<3, false>), grid, block, 0, st, s); break;
-        }
+#define VNP_EDGE_GO(R1V, CWV) switch (mode) { \
+        case 0: hipLaunchKernelGGL((vnp_edge_fused_kernel<0, R1V, CWV>), grid, block, 0, st, s); break; \
+        case 1: hipLaunchKernelGGL((vnp_edge_fused_kernel<1, R1V, CWV>), grid, block, 0, st, s); break; \
+        case 2: hipLaunchKernelGGL((vnp_edge_fused_kernel<2, R1V, CWV>), grid, block, 0, st, s); break; \
+        default: hipLaunchKernelGGL((vnp_edge_fused_kernel<3, R1V, CWV>), grid, block, 0, st, s); break; }
+        if (C <= 32) { if (r1) VNP_EDGE_GO(true, 32) else VNP_EDGE_GO(false, 32) }
+        else { if (r1) VNP_EDGE_GO(true, 64) else VNP_EDGE_GO(false, 64) }
+#undef VNP_EDGE_GO
     }
     return vnp_last_error();
 }
@@ -512,8 +519,13 @@ static int vnp_edge_fused_gather_impl(hipStream_t st, const float* u, int ldu, c
         s.u = u + (size_t)soff * 3 * ldu; s.gu = gu + (size_t)soff * 3 * ldgu;
         const long long np = (Pu - soff) < (long long)nb * VNP_EDGE_SB ? (Pu - soff) : (long long)nb * VNP_EDGE_SB;
         const int cw = C <= 32 ? 32 : 64;
-        if (wu) hipLaunchKernelGGL((vnp_edge_gather_u_kernel<true>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
-        else    hipLaunchKernelGGL((vnp_edge_gather_u_kernel<false>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        if (cw == 32) {
+            if (wu) hipLaunchKernelGGL((vnp_edge_gather_u_kernel<true, 32>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
+            else    hipLaunchKernelGGL((vnp_edge_gather_u_kernel<false, 32>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        } else {
+            if (wu) hipLaunchKernelGGL((vnp_edge_gather_u_kernel<true, 64>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
+            else    hipLaunchKernelGGL((vnp_edge_gather_u_kernel<false, 64>), dim3(vnp_cdiv(C, cw), nb), dim3(256), 0, st, s, start + soff, rev, np);
+        }
     }
     return vnp_last_error();
 }

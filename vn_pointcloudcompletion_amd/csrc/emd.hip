@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(EMD_T) emd_grad1_kernel(int n, int m, const fl
 __global__ void __launch_bounds__(256) emd_grad2_kernel(int n, int m, const float* __restrict__ gc, const float* __restrict__ xyz1,
                                                        const float* __restrict__ xyz2, const float* __restrict__ match, float* __restrict__ grad2)
 {
-    const int b = blockIdx.y, l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y, l = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (l >= m) return;
     const float* p1 = xyz1 + (size_t)b * n * 3; const float* p2 = xyz2 + ((size_t)b * m + l) * 3;
     const float* mt = match + (size_t)b * n * m + (size_t)l * n;

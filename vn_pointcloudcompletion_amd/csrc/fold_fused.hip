@@ -39,7 +39,7 @@ __device__ __forceinline__ vnp_f2 vnp_sqrt2(vnp_f2 v) { return VNP_GRAD_HW ? vnp
 // formulas lane by lane; only the order in which the per-thread sums collect their terms changes (even and odd seed points separately)
 #define VNP_GRP_MAXS 16          // GRP, MODE 3 with gx_part: seed points per coarse point (LDS transpose of S * 3 values x 64 columns per wave)
 template <int MODE, bool PK = false, bool GRP = false>
-__global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a)
+__global__ void __launch_bounds__(256, (MODE == 3 && PK && !GRP) ? 3 : 1) vnp_fold_fused_kernel(const VnpFoldArgs a)
 {
     static_assert(!PK || MODE >= 2, "the packed body exists for the backward modes");
     static_assert(!GRP || MODE < 2 || PK, "the per-group form of the backward modes exists in the packed body only (even S)");
@@ -57,7 +57,10 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     // dominant term — as an error common to all rows; ten conversions and adds per coarse point cost nothing next to ~2400 VALU ops
     __shared__ double redd[MODE >= 2 ? 4 : 1][5][2][64];
     __shared__ int cnt[4];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    // the wave index as a SCALAR: the coarse point, the sample, the seed pointer and every row base derive from it, so their arithmetic
+    // and the loads of coordinates / seeds run on the scalar unit and a gradient load is one SGPR base + the lane's column (round 5:
+    // with a per-lane wave index all of it was 64-bit vector arithmetic held in registers across the seed loop)
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = blockIdx.x * 64 + cx;
     const bool live = j < a.C;
     const int C = a.C, S = a.S;
@@ -75,6 +78,15 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
     float wmean = 0.f, wm2 = 0.f; int wk = 0;                      // MODE 0
     double s1 = 0.0, s2 = 0.0;                                     // MODE 2
     double acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};         // MODE 3: [feat|dir][bias t0..2, seed, coarse]
+    // the packed MODE 3 body keeps these ten double sums in its own LDS slots (redd[py][r][h][cx], touched once per coarse point) instead
+    // of in 20 registers that would be live across the whole seed loop: 202 -> 178 VGPRs
+    constexpr bool ACC_LDS = MODE == 3 && PK;
+    if (ACC_LDS) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) redd[py][r][h][cx] = 0.0;
+    }
     for (long long cp = cp0 + py; cp < cp1; cp += 4) {
         const int b = (int)(cp / a.Mc);
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -152,7 +164,10 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 5; ++r) acc[h][r] += (double)vacc[h][r][0] + (double)vacc[h][r][1];
+                for (int r = 0; r < 5; ++r) {
+                    if (ACC_LDS) redd[py][r][h][cx] += (double)vacc[h][r][0] + (double)vacc[h][r][1];
+                    else acc[h][r] += (double)vacc[h][r][0] + (double)vacc[h][r][1];
+                }
             gc0 = vgc0[0] + vgc0[1]; gc1 = vgc1[0] + vgc1[1]; gc2 = vgc2[0] + vgc2[1];
             if (GRP && MODE == 3) {
                 if (live) {                                        // dL/dbias of THIS coarse point (the bias is per group here)
@@ -253,10 +268,12 @@ __global__ void __launch_bounds__(256) vnp_fold_fused_kernel(const VnpFoldArgs a
             a.partial[(size_t)blockIdx.y * C + j] = make_float2((float)((redd[0][0][0][cx] + redd[1][0][0][cx]) + (redd[2][0][0][cx] + redd[3][0][0][cx])),
                                                                 (float)((redd[0][1][0][cx] + redd[1][1][0][cx]) + (redd[2][1][0][cx] + redd[3][1][0][cx])));
     } else if (MODE == 3) {
+        if (!ACC_LDS) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) redd[py][r][h][cx] = acc[h][r];
+                for (int r = 0; r < 5; ++r) redd[py][r][h][cx] = acc[h][r];
+        }
         __syncthreads();
         if (py == 0 && live) {
 #pragma unroll

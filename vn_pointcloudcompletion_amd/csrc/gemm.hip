@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) vnp_reduce_slabs_kernel(const float* __re
 {
     __shared__ double part[4][64];
     const long long total = (long long)M * N;
-    const int ox = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ox = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
         const long long i = base + ox;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) vnp_gemm_rank1_kernel(const float* __rest
         const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
         if (c >= N) return;
         const vnp_f4 bv = *(const vnp_f4*)(B + c);
-        const int r0 = blockIdx.y * 64 + (threadIdx.x >> 6), r1 = min(M, (int)(blockIdx.y + 1) * 64);
+        const int r0 = blockIdx.y * 64 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r1 = min(M, (int)(blockIdx.y + 1) * 64);
         int grp = 0, rem = 0, t = 0;
         if (bias) { grp = r0 / rows_per_group; rem = r0 - grp * rows_per_group; t = r0 % 3; }
         for (int r = r0; r < r1; r += 4) {
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) vnp_gemm_rank1_kernel(const float* __rest
     const float bv = B[(size_t)c * bstride];
     // a thread's rows are r0, r0 + 4, ...: group index and component advance incrementally (one 32-bit division per thread instead of a
     // 64-bit division and a modulo per element: the kernel is a pure 0.8 GB store stream in config 4 and ran at half the store rate)
-    const int r0 = blockIdx.y * 64 + (threadIdx.x >> 6), r1 = min(M, (int)(blockIdx.y + 1) * 64);
+    const int r0 = blockIdx.y * 64 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r1 = min(M, (int)(blockIdx.y + 1) * 64);
     int grp = 0, rem = 0, t = 0;
     if (bias) { grp = r0 / rows_per_group; rem = r0 - grp * rows_per_group; t = r0 % 3; }
     for (int r = r0; r < r1; r += 4) {
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) vnp_gemm_rank1_kernel(const float* __rest
 __global__ void __launch_bounds__(256) vnp_gemm_matvec_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, long long bstride,
                                                              float* __restrict__ C, int ldc, int M, int K, int accumulate)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (r >= M) return;
     const int lane = threadIdx.x & 63;
     float s = 0.f;
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256) vnp_gemm_wcolsum_kernel(const float* __re
                                                               int K, int Ccols, int rows_per_split, float* __restrict__ slab)
 {
     __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long k0 = (long long)blockIdx.y * rows_per_split, k1 = min((long long)K, k0 + rows_per_split);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                  // four rows in flight per thread
@@ -383,7 +383,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
 __global__ void __launch_bounds__(256) vnp_stats_merge32_kernel(const float2* __restrict__ part32, int C, float2* __restrict__ out)
 {
     __shared__ double rm[4][64], rM[4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     double na = 0.0, ma = 0.0, Ma = 0.0;
     if (c < C) {

@@ -124,7 +124,7 @@ extern "C" int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx
 __global__ void __launch_bounds__(256) vnp_row_norm_kernel(const float* __restrict__ x, int ld, long long rows, int K, float* __restrict__ out,
                                                           unsigned short* __restrict__ h16)
 {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* src = x + (size_t)r * ld;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_select_kernel(const float
 {
     __shared__ float sL[4][64];
     __shared__ int sbad[4][64], scnt[4][64], sbase;
-    const int cx = threadIdx.x & 63, qy = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, qy = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long g = blockIdx.y;
     const int per = (nparts + 3) / 4, k0 = qy * per, k1 = min(nparts, k0 + per);
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_exact_kernel(const float*
 {
     if (head->flag) return;
     const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (tile >= tstart[nbins]) return;
     // the bin of this tile: largest b with tstart[b] <= tile (wave-uniform binary search)
     int lo = 0, hi = nbins;
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) vnp_pool_screen_final_kernel(const VnpScr
 {
     if (head->flag) return;
     const int sub = threadIdx.x & 63;                    // a wave per (group, channel) segment: a segment of a near-tied channel can hold
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);   // hundreds of candidates, and eight lanes walking it set the kernel's time
+    const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // hundreds of candidates, and eight lanes walking it set the kernel's time
     const long long g = blockIdx.y;
     const bool live = c < C;
     const int2 sg = live ? seg[(size_t)g * C + c] : make_int2(0, 0);

@@ -10,7 +10,7 @@ __global__ void __launch_bounds__(256) vnp_pool_partial_kernel(const float* __re
 {
     __shared__ float rv[4][64];
     __shared__ int ri[4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long g = blockIdx.z;
     const int n0 = blockIdx.y * VNP_CHUNK, n1 = min(gs, n0 + VNP_CHUNK);

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) vnp_rowdot_kernel(const float* __restrict
                                                         const float* __restrict__ add, int add_group, float* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long r = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (r >= R) return;
     const float* row = X + (size_t)r * ldx;
     float s = 0.f;
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) vnp_colsum_kernel(const float* __restrict
                                                         long long R, int C, const float* __restrict__ w, int nchunk, float* __restrict__ partial)
 {
     __shared__ float red[4][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long r0 = (long long)blockIdx.y * VNP_CHUNK, r1 = min(R, r0 + VNP_CHUNK);
     const float* base = X + (size_t)blockIdx.z * batch_stride;
@@ -220,7 +220,7 @@ extern "C" int vnp_group_sum3(hipStream_t st, const float* in, long long Pc, int
 __global__ void __launch_bounds__(256) vnp_colsum_small_kernel(const float* __restrict__ X, long long batch_stride, long long row_stride,
                                                               int nb, int R, int C, const float* __restrict__ w, float* __restrict__ partial)
 {
-    const int cx = threadIdx.x & 63, g = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int cx = threadIdx.x & 63, g = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + cx;
     if (g >= nb || c >= C) return;
     const float* base = X + (size_t)g * batch_stride + c;

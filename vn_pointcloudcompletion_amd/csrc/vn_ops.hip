@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) vnp_norm_stats_kernel(const float* __rest
 {
     __shared__ float2 red[4][64];
     __shared__ int cnt[4];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long p0 = (long long)blockIdx.y * chunk;
     const long long p1 = min(P, p0 + chunk);
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_fwd_kernel(const float* __re
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float ns, int chunk)
 {
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     if (c >= C) return;
     const long long p0 = (long long)blockIdx.y * chunk;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
     __shared__ float red3[4][64];
     __shared__ float red6[4][6][64];
     float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // MODE 2 + colsum: sums over the chunk's points of (dL/dp, dL/dd) per component
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     const long long p0 = (long long)blockIdx.y * chunk;
     const long long p1 = min(P, p0 + chunk);
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_rowdot_kernel(const float* _
                                                                  const float* __restrict__ w, const float* __restrict__ add, int add_group,
                                                                  float* __restrict__ out)
 {
-    const long long pt = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long pt = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (pt >= P) return;
     const float* rp = p + (size_t)pt * 3 * ldp;
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) vnp_bn_bwd2_kernel(float* __restrict__ g,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ S, float inv_count, int chunk)
 {
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int c = blockIdx.x * 64 + cx;
     if (c >= C) return;
     const long long p0 = (long long)blockIdx.y * chunk;
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(64 * VNP_RR_LANES) vnp_reduce_rows_kernel(cons
                                                              float* __restrict__ out, long long out_stride, float* __restrict__ planar = nullptr)
 {
     __shared__ double red[VNP_RR_LANES][64];
-    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
     const int j = blockIdx.x * 64 + cx;
     double s = 0.0, s2 = 0.0;
     if (j < W) {
