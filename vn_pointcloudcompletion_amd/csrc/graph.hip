@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64 * KNC_WAVES) vnp_knn_coords_kernel(const fl
     float* rs = knc_sm;                                        // [Nr][3]
     float* ld = knc_sm + (size_t)NPL * 64 * 3;                 // [KNC_WAVES][64] candidate distances
     int* li = (int*)(ld + KNC_WAVES * 64);                     // [KNC_WAVES][64] candidate indices
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* rb = ref + (size_t)b * Nr * 3;
     for (int i = threadIdx.x; i < Nr * 3; i += 64 * KNC_WAVES) rs[i] = rb[i];
     __syncthreads();
