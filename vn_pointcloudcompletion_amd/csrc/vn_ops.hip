@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(256) vnp_bn_leaky_bwd1_kernel(const float* __r
     __shared__ float red3[4][64];
     __shared__ float red6[4][6][64];
     float cs[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // MODE 2 + colsum: sums over the chunk's points of (dL/dp, dL/dd) per component
-    const int cx = threadIdx.x & 63, py = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // a wave = one point lane: scalar
+    // (MODE 2, the store-heavy final pass, measured 1.7 % slower with the scalar index — it sits at the HBM ceiling either way — and keeps the vector one)
+    const int cx = threadIdx.x & 63, py = MODE == 2 ? (int)(threadIdx.x >> 6) : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + cx;
     const long long p0 = (long long)blockIdx.y * chunk;
     const long long p1 = min(P, p0 + chunk);
