@@ -47,7 +47,7 @@ def other_configs(steps=5, warmup=3, which=(3, 4, 5)):
     from vn_pointcloudcompletion_amd import ops
     from vn_pointcloudcompletion_amd.model import PCNNet
     from vn_pointcloudcompletion_amd.optim import FusedAdam
-    from vn_pointcloudcompletion_amd.train import train_step
+    from vn_pointcloudcompletion_amd.train import settle_gc, train_step
     out = {}
     for cid in which:
         c = CONFIGS[cid]
@@ -60,22 +60,36 @@ def other_configs(steps=5, warmup=3, which=(3, 4, 5)):
         g = torch.Generator().manual_seed(1)
         p = (torch.rand(c["B"], 2048, 3, generator=g) - 0.5).cuda()
         gt = (torch.rand(c["B"], md, 3, generator=g) - 0.5).cuda()
-        for _ in range(warmup):
+        for i in range(warmup):
             train_step(cfg, net, opt, p, gt)
+            if i == 0:
+                settle_gc()                                        # as train.train() does after its first step
         torch.cuda.synchronize()
+        # the step time on un-instrumented steps; the GEMM roofline on `steps` more steps with the per-launch timers attached (they cost
+        # a step of config 5 — 150 matrix-product launches — about a millisecond, scripts/experiments/hook_overhead.py)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _, _ = train_step(cfg, net, opt, p, gt)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
         prof = []
         with ops.hooks(gemm_profile=prof):
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                loss, _, _ = train_step(cfg, net, opt, p, gt)
+            train_step(cfg, net, opt, p, gt)
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            ops.reserve_timers(len(prof) * steps + 8)
+            del prof[:]
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                train_step(cfg, net, opt, p, gt)
+            torch.cuda.synchronize()
+            dt_hooked = (time.perf_counter() - t1) / steps
         recs = [(f, t.seconds()) for _, f, _, _, t in prof if t.kind == 0 and t.seconds() is not None]
         fl, tm = sum(f for f, _ in recs), sum(t for _, t in recs)
         allm = sum(t.seconds() for *_, t in prof if t.seconds() is not None)
         out[f"cfg{cid}"] = {
             "workload": c["name"] + ", full train step (fwd + losses + bwd + Adam), fp32",
             "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "points_per_s": c["B"] * md / dt,
+            "ms_per_step_with_launch_timers": round(dt_hooked * 1e3, 3),
             "loss": float(loss.item()), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             "dominant_kernel": "vnp_gemm_split_kernel<*> + vnp_gemm_split_wide_kernel<*> + vnp_gemm_split_wide_tn_kernel<*> "
                                "(six bf16 MFMA products per fp32 product)",
@@ -83,7 +97,8 @@ def other_configs(steps=5, warmup=3, which=(3, 4, 5)):
                          "unit": "TFLOP/s", "frac": round(fl / tm / 1e12 / PEAK_SPLIT_TFLOPS, 4) if tm > 0 else None,
                          "ms_per_step": round(tm / steps * 1e3, 3), "launches_per_step": len(recs) // steps,
                          "all_matrix_kernels_ms_per_step": round(allm / steps * 1e3, 3),
-                         "note": "executed 2MNK of the split-GEMM launches / their kernel time (library HIP events)"}}
+                         "note": "executed 2MNK of the split-GEMM launches / their kernel time (library HIP events), taken on `steps` further steps "
+                                 "after the timed ones: ms_per_step carries no instrumentation"}}
         del net, opt, p, gt, prof
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()

@@ -8,7 +8,7 @@ from types import SimpleNamespace
 import torch
 from vn_pointcloudcompletion_amd.model import PCNNet
 from vn_pointcloudcompletion_amd.optim import FusedAdam
-from vn_pointcloudcompletion_amd.train import train_step
+from vn_pointcloudcompletion_amd.train import settle_gc, train_step
 
 CONFIGS = {
     2: dict(enc="vn_pointnet", dec="vn_foldingnet", B=32, latent=2048, loss="cd", mc=1024),
@@ -36,6 +36,7 @@ for cid in which:
     gt = (torch.rand(c["B"], md, 3, generator=g) - 0.5).cuda()
     for _ in range(5):                       # warm-up (a one-off ~0.1 s stall half a second into a process's GPU work would land in a shorter one's timed steps)
         train_step(cfg, net, opt, p, gt)
+    settle_gc()                              # as train.train() does after its first step
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = nsteps

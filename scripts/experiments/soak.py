@@ -5,12 +5,13 @@ import torch
 from vn_pointcloudcompletion_amd.model import PCNNet
 from vn_pointcloudcompletion_amd.optim import FusedAdam
 from vn_pointcloudcompletion_amd.train import train_step
-CONFIGS = {4: dict(enc="vn_pointnet", dec="attention_vn_foldingnet", B=16, latent=2048, loss="emd", mc=1024),
+CONFIGS = {3: dict(enc="vn_dgcnn_fps", dec="vn_foldingnet", B=32, latent=512, loss="cd", mc=1024, knn_k=20),
+           4: dict(enc="vn_pointnet", dec="attention_vn_foldingnet", B=16, latent=2048, loss="emd", mc=1024),
            5: dict(enc="vn_pointr", dec="vn_foldingnet", B=32, latent=1024, loss="cd", mc=1024)}
-for cid in (4, 5):
+for cid in ([int(a) for a in sys.argv[1:]] or (3, 4, 5)):          # configs whose steps use side streams (samplings, reverse adjacencies, EMD)
     c = CONFIGS[cid]
     cfg = SimpleNamespace(num_coarse=c["mc"], latent_dim=c["latent"], only_coarse=False, enc_pretrained="none", device="cuda:0",
-                          coarse_loss=c["loss"], dcd_opts={"alpha": 200, "lambda": 0.5}, knn_k=16)
+                          coarse_loss=c["loss"], dcd_opts={"alpha": 200, "lambda": 0.5}, knn_k=c.get("knn_k", 16))
     torch.manual_seed(0)
     net = PCNNet(cfg, c["enc"], c["dec"]).train()
     md = getattr(net.decoder, "num_dense", 16384)

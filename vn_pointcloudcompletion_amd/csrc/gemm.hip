@@ -253,9 +253,9 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             const bool v4 = bstr == 1 && N % 4 == 0 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && (uintptr_t)B % 16 == 0 &&
                             (!bias || (ldbias % 4 == 0 && (uintptr_t)bias % 16 == 0));
             vnp_prof_begin(stream);
-            if (v4) hipLaunchKernelGGL(vnp_gemm_rank1_kernel<true>, dim3(vnp_cdiv(N, 256), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B, bstr,
+            if (v4) VNP_KLAUNCH(vnp_gemm_rank1_kernel<true>, dim3(vnp_cdiv(N, 256), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B, bstr,
                                        C, ldc, M, N, bias, ldbias, rows_per_group > 0 ? rows_per_group : 1, accumulate);
-            else hipLaunchKernelGGL(vnp_gemm_rank1_kernel<false>, dim3(vnp_cdiv(N, 64), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B, bstr,
+            else VNP_KLAUNCH(vnp_gemm_rank1_kernel<false>, dim3(vnp_cdiv(N, 64), vnp_cdiv(M, 64)), dim3(256), 0, stream, A, lda, B, bstr,
                                     C, ldc, M, N, bias, ldbias, rows_per_group > 0 ? rows_per_group : 1, accumulate);
             vnp_prof_end(stream, 2);
             return vnp_last_error();
@@ -263,7 +263,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         // matrix-vector: A [M,K] K-contiguous, one output column
         if (N == 1 && op_a == 0 && !bias) {
             vnp_prof_begin(stream);
-            hipLaunchKernelGGL(vnp_gemm_matvec_kernel, dim3(vnp_cdiv(M, 4)), dim3(256), 0, stream, A, lda, B, (long long)(op_b == 0 ? 1 : ldb),
+            VNP_KLAUNCH(vnp_gemm_matvec_kernel, dim3(vnp_cdiv(M, 4)), dim3(256), 0, stream, A, lda, B, (long long)(op_b == 0 ? 1 : ldb),
                                C, ldc, M, K, accumulate);
             vnp_prof_end(stream, 2);
             return vnp_last_error();
@@ -279,7 +279,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
             float* slab = ws;
             if (ns > 1) {
             vnp_prof_begin(stream);
-            hipLaunchKernelGGL(vnp_gemm_wcolsum_kernel, dim3(vnp_cdiv(cols, 64), ns), dim3(256), 0, stream, X, ldx, wv, ws_, K, cols, rps, slab);
+            VNP_KLAUNCH(vnp_gemm_wcolsum_kernel, dim3(vnp_cdiv(cols, 64), ns), dim3(256), 0, stream, X, ldx, wv, ws_, K, cols, rps, slab);
             vnp_prof_end(stream, 2);
             int rc2 = vnp_last_error();
             if (rc2) return rc2;
@@ -329,13 +329,13 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
 #define VNP_LAUNCH(BM_, AKC_, BKC_)                                                                                    \
     do {                                                                                                                \
-        if (h2) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true, 0, 0, 1>), grid, block, 0, stream, p); \
+        if (h2) VNP_KLAUNCH((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true, 0, 0, 1>), grid, block, 0, stream, p); \
         else if (split) {                                                                                               \
-            if (fast) hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true>), grid, block, 0, stream, p);  \
-            else      hipLaunchKernelGGL((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, false>), grid, block, 0, stream, p); \
+            if (fast) VNP_KLAUNCH((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, true>), grid, block, 0, stream, p);  \
+            else      VNP_KLAUNCH((vnp_gemm_split_kernel<BM_, 128, AKC_, BKC_, false>), grid, block, 0, stream, p); \
         } else {                                                                                                        \
-            if (fast) hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, true>), grid, block, 0, stream, p);    \
-            else      hipLaunchKernelGGL((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p);   \
+            if (fast) VNP_KLAUNCH((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, true>), grid, block, 0, stream, p);    \
+            else      VNP_KLAUNCH((vnp_gemm_kernel<BM_, 128, BK, AKC_, BKC_, false>), grid, block, 0, stream, p);   \
         }                                                                                                               \
     } while (0)
     vnp_prof_begin(stream);
@@ -343,13 +343,13 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         // both operands K-contiguous, N % 256 == 0: the 512-thread kernel with the 192 x 256 tile — the same arithmetic bit for bit,
         // 0.7x the staging work per MFMA (scripts/experiments/gemm_wide_bench.hip)
         const long long items_w = (long long)(M / 192) * (N / 256) * nsplit * nbatch;
-        hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
+        VNP_KLAUNCH((vnp_gemm_split_wide_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
     } else if (tileable && fast && bm == 96) {
-        if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, true, true>), grid, block, 0, stream, p);
-        else           hipLaunchKernelGGL((vnp_gemm_split_kernel<96, 128, true, false, true>), grid, block, 0, stream, p);
+        if (op_b == 0) VNP_KLAUNCH((vnp_gemm_split_kernel<96, 128, true, true, true>), grid, block, 0, stream, p);
+        else           VNP_KLAUNCH((vnp_gemm_split_kernel<96, 128, true, false, true>), grid, block, 0, stream, p);
     } else if (tileable && fast && bm == 128) {
-        if (op_b == 0) hipLaunchKernelGGL((vnp_gemm_split_kernel<128, 128, true, true, true>), grid, block, 0, stream, p);
-        else           hipLaunchKernelGGL((vnp_gemm_split_kernel<128, 128, true, false, true>), grid, block, 0, stream, p);
+        if (op_b == 0) VNP_KLAUNCH((vnp_gemm_split_kernel<128, 128, true, true, true>), grid, block, 0, stream, p);
+        else           VNP_KLAUNCH((vnp_gemm_split_kernel<128, 128, true, false, true>), grid, block, 0, stream, p);
     }
     else if (op_a == 0 && op_b == 0) VNP_LAUNCH(192, true, true);
     else if (op_a == 0 && op_b == 1) VNP_LAUNCH(192, true, false);
@@ -360,7 +360,7 @@ static int vnp_gemm_impl(hipStream_t stream, int op_a, int op_b, int M, int N, i
         // weight gradients whose 256 x 128 tiles fill whole rounds of one 512-thread workgroup per CU: 0.75x the staging work per MFMA,
         // evenly divided (vnp_gemm_split_wide_tn_kernel); measured +2.5 .. 4 % on the step's shapes, same bits
         const long long items_w = (long long)(M / 256) * (N / 128) * nsplit * nbatch;
-        hipLaunchKernelGGL((vnp_gemm_split_wide_tn_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
+        VNP_KLAUNCH((vnp_gemm_split_wide_tn_kernel<0>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, stream, p);
     }
     else if (op_a == 1 && op_b == 1) VNP_LAUNCH(128, false, false);
     else                             VNP_LAUNCH(128, false, true);
@@ -434,12 +434,12 @@ extern "C" int vnp_gemm_vn_stats_ex(hipStream_t st, int M, int N, int K, const f
     p.amax_a = amax_a; p.amax_b = amax_b;
     const long long items_w = (long long)(M / 192) * (N / 256);
     vnp_prof_begin(st);
-    if (amax_a && K >= 64) hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2, 1>), grid, block, 0, st, p);
+    if (amax_a && K >= 64) VNP_KLAUNCH((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2, 1>), grid, block, 0, st, p);
     else if (N % 256 == 0 &&                                     // the wide tile where its rounds are cheaper (vnp_gemm_impl)
              (double)((items_w + vnp_num_cus() - 1) / vnp_num_cus()) * 1.38 <
              0.99 * ((double)(items / cap) * 1.45 + (items % cap == 0 ? 0.0 : 2 * (items % cap) <= cap ? 1.0 : 1.45)))
-        hipLaunchKernelGGL((vnp_gemm_split_wide_kernel<2>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
+        VNP_KLAUNCH((vnp_gemm_split_wide_kernel<2>), dim3((unsigned)(items_w < vnp_num_cus() ? items_w : vnp_num_cus())), dim3(512), 0, st, p);
+    else VNP_KLAUNCH((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 2>), grid, block, 0, st, p);
     vnp_prof_end(st, (amax_a && K >= 64) ? 5 : 0);
     hipLaunchKernelGGL(vnp_stats_merge32_kernel, dim3(vnp_cdiv(stats_cols, 64), M / 3072), dim3(256), 0, st,
                        (const float2*)ws, stats_cols, (float2*)part1024);

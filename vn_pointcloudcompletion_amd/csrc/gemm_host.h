@@ -3,6 +3,7 @@
 #pragma once
 #include "gemm_split_kernel.h"
 #include "gemm_split_wide_kernel.h"
+#include <hip/hip_ext.h>
 
 extern "C" int vnp_gemm_get_mode(void);
 
@@ -19,11 +20,19 @@ extern thread_local VnpProfReq g_vnp_prof;             // defined in gemm.hip
 // bracketed kernel) is dropped when the call returns instead of arming some later, unrelated launch with stale event handles.
 struct VnpProfScope { ~VnpProfScope() { g_vnp_prof = {nullptr, nullptr, nullptr}; } };
 
-static inline void vnp_prof_begin(hipStream_t st) { if (g_vnp_prof.e0) (void)hipEventRecord(g_vnp_prof.e0, st); }
-static inline void vnp_prof_end(hipStream_t st, int kind)
+// The bracketed kernel is launched through VNP_KLAUNCH: with a request pending it goes out by hipExtLaunchKernelGGL, which stamps e0 / e1
+// from the dispatch packet's OWN start / end — no marker packets in the queue.  (Rounds 3-4 recorded two events around the launch: each
+// is a barrier packet of its own, and the ~45 instrumented launches of a step cost the timed region 0.26-0.36 ms on config 2, 1.2-1.4 ms
+// on config 5's 150 products: scripts/experiments/hook_overhead.py.)
+#define VNP_KLAUNCH(kern, grid, block, lds, st, ...)                                                                              \
+    do {                                                                                                                         \
+        if (g_vnp_prof.e0) hipExtLaunchKernelGGL(kern, grid, block, lds, st, g_vnp_prof.e0, g_vnp_prof.e1, 0, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                          \
+    } while (0)
+static inline void vnp_prof_begin(hipStream_t) {}
+static inline void vnp_prof_end(hipStream_t, int kind)
 {
     if (!g_vnp_prof.e0) return;
-    (void)hipEventRecord(g_vnp_prof.e1, st);
     if (g_vnp_prof.kind) *g_vnp_prof.kind = kind;
     g_vnp_prof = {nullptr, nullptr, nullptr};
 }

@@ -62,7 +62,7 @@ extern "C" int vnp_linear_pool_fwd(hipStream_t st, const float* x, int ldx, cons
     const long long cap = (long long)vnp_num_cus() * 2;
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
     vnp_prof_begin(st);
-    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 1>), grid, block, 0, st, p);
+    VNP_KLAUNCH((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 1>), grid, block, 0, st, p);
     vnp_prof_end(st, 0);
     hipLaunchKernelGGL(vnp_pool_fused_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
                        (const float*)p.pool_val, (const int*)p.pool_idx, (const float*)p.pool_x, gs / 32, C, idx, out, ldo,
@@ -97,7 +97,7 @@ extern "C" int vnp_linear_pool_store_fwd(hipStream_t st, const float* x, int ldx
     const long long cap = (long long)vnp_num_cus() * 2;
     dim3 grid((unsigned)(items < cap ? items : cap)), block(256);
     vnp_prof_begin(st);
-    hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 5>), grid, block, 0, st, p);
+    VNP_KLAUNCH((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 5>), grid, block, 0, st, p);
     vnp_prof_end(st, 0);
     hipLaunchKernelGGL(vnp_pool_fused_final_kernel, dim3(vnp_cdiv(C, 256), (unsigned)G), dim3(256), 0, st,
                        (const float*)p.pool_val, (const int*)p.pool_idx, (const float*)p.pool_x, gs / 32, C, idx, out, ldo,
@@ -467,7 +467,7 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
             static std::atomic<unsigned long long> xwide_ok{0};
             hipError_t ex = vnp_allow_dynamic_lds(xwide_ok, (const void*)vnp_screen_f16_xwide_kernel<0>, xwide_lds);
             if (ex != hipSuccess) return (int)ex;
-            hipLaunchKernelGGL(vnp_screen_f16_xwide_kernel<0>, dim3((unsigned)(iw < cw ? iw : cw)), dim3(512), xwide_lds, st, p);
+            VNP_KLAUNCH(vnp_screen_f16_xwide_kernel<0>, dim3((unsigned)(iw < cw ? iw : cw)), dim3(512), xwide_lds, st, p);
         } else if ((2 * C) % 256 == 0 && !narrow) {
             // 192 x 256 tiles on eight waves, one workgroup per CU: 0.70x the operand bytes per MFMA (screen_wide_kernel.h); same slots
             const long long iw = (M / 192) * (2LL * C / 256);
@@ -479,15 +479,15 @@ extern "C" int vnp_linear_pool_screened_fwd(hipStream_t st, const float* x, int 
             static std::atomic<unsigned long long> wide_ok{0};
             hipError_t ew = vnp_allow_dynamic_lds(wide_ok, (const void*)vnp_screen_f16_wide_kernel, wide_lds);
             if (ew != hipSuccess) return (int)ew;
-            hipLaunchKernelGGL(vnp_screen_f16_wide_kernel, dim3((unsigned)(iw < cw ? iw : cw)), dim3(512), wide_lds, st, p);
+            VNP_KLAUNCH(vnp_screen_f16_wide_kernel, dim3((unsigned)(iw < cw ? iw : cw)), dim3(512), wide_lds, st, p);
         } else
-            hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, st, p);
+            VNP_KLAUNCH((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 4>), grid, block, 0, st, p);
     } else {
         // THREE bf16 products: dropped (h l)+(l h)+(m m)+... <= 3.05 * 2^-18 of |w||f| per term, plus the worst-case fp32 rounding of
         // BOTH accumulations in any summation order (3K and 6K terms, unit roundoff 2^-24, terms <= 1.01 |w||f|)
         p.screen_eps = 1.17e-5f + 9.2f * (float)K * 5.9605e-8f;
         p.screen_abs = 0.f;
-        hipLaunchKernelGGL((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 3>), grid, block, 0, st, p);
+        VNP_KLAUNCH((vnp_gemm_split_kernel<192, 128, true, true, true, 0, 3>), grid, block, 0, st, p);
     }
     vnp_prof_end(st, f16pass ? 3 : 4);
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)nbins * 4, st);

@@ -8,7 +8,7 @@ is done by the HIP kernels.  No function in this package has a CPU / PyTorch fal
 Modules: ``core`` (GEMM wrapper, reductions, BatchNorm / leaky passes, layout Functions), ``linear``, ``dirlayer``, ``pool``, ``fold``,
 ``chamfer``, ``graph``, ``attention``; ``_state`` holds the switches (``SW``) and the test / bench hooks (``hooks(...)``).
 """
-from ._state import HK, POOL_PATH_COUNTS, SW, hooks, switches, trace
+from ._state import HK, POOL_PATH_COUNTS, SW, hooks, reserve_timers, switches, trace
 from .attention import (AddLayerNormFn, VNAttentionFn, VNAttentionPackedFn, VNLayerNormFn, _attn_dims, _attn_token_major, _from_heads, _heads_fm,
                         _heads_tm, _rows_from_fm, _to_heads, gemm_batched)
 from .chamfer import ChamferFn, ChamferL1LossFn

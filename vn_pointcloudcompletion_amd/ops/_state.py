@@ -112,11 +112,21 @@ def trace(name, idx=None, key="pool_idx"):
             tr.setdefault(key, []).append(idx)
 
 
+_TIMER_POOL = []
+
+
+def reserve_timers(n):
+    """Create ``n`` KernelTimers (two HIP events each) ahead of an instrumented region, so that arming one inside it is a list pop and one
+    library call instead of two hipEventCreate round trips through ctypes per matrix-product launch (bench.py: before its timed steps)."""
+    while len(_TIMER_POOL) < n:
+        _TIMER_POOL.append(_lib.KernelTimer())
+
+
 def prof_arm():
     """A KernelTimer armed for the next matrix-product launch when a profile list is attached, else None."""
     if HK.gemm_profile is None:
         return None
-    t = _lib.KernelTimer()
+    t = _TIMER_POOL.pop() if _TIMER_POOL else _lib.KernelTimer()
     t.arm()
     return t
 

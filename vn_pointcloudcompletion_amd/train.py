@@ -140,6 +140,16 @@ def train_step(config, model, optimizer, p, c, trot=None, loss_weight=1.0):
     return loss.detach(), loss1.detach(), loss2.detach()
 
 
+def settle_gc():
+    """Python's cyclic collector walks every tracked object of the process on a full collection: ~270 k objects once torch, the model, the
+    optimizer and the first step's autograd graph exist — a 70-90 ms host stall during which no kernel is launched (measured on config 3:
+    one at step ~50 of every process, scripts/experiments/step_times_cfg3.py).  After set-up everything long-lived moves to the permanent
+    generation (gc.freeze), so later collections only look at what a step creates; called after the first training step."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def train(config, args):
     rank, world = D.get_rank(), D.world_size()
     is_main = rank == 0
@@ -211,6 +221,8 @@ def train(config, args):
                 p, c = trot.transform_points(p), trot.transform_points(c)
             wgt = train_sampler.weight(i)
             loss, loss1, loss2 = train_step(config, model, optimizer, p, c, trot, wgt)
+            if epoch == start_epoch and i == 0:
+                settle_gc()                                   # model, optimizer state and the step's long-lived objects exist now
             sums += torch.stack([loss, loss1, loss2]) * (1.0 if wgt is None else wgt)
             if is_main and (i + 1) % step == 0:
                 l, l1, l2 = loss.item(), loss1.item(), loss2.item()
