@@ -90,8 +90,8 @@ int vnp_gemm_get_mode(void);
  * rounds each height needs (measured costs per round, gemm.hip: vnp_choose_tile); the results are the same bits whichever runs. */
 int vnp_gemm_tile_rows(int op_b, int M, int N, int nsplit, int nbatch, int has_bias);
 /* Measurement hook (bench.py, no reference counterpart): the NEXT matrix-product launch of the calling host thread (vnp_gemm*,
- * vnp_gemm_vn_stats*, vnp_linear_pool*_fwd) records e0 / e1 around its ONE dominant kernel on the launch stream — not the slab
- * reduction or the pool's candidate passes — and stores in *kind (host memory, may be NULL) what that kernel was:
+ * vnp_gemm_vn_stats*, vnp_linear_pool*_fwd) stamps e0 / e1 with the start and the end of its ONE dominant kernel's dispatch on the
+ * launch stream (hipExtLaunchKernelGGL: no marker packets; not the slab reduction or the pool's candidate passes) and stores in *kind (host memory, may be NULL) what that kernel was:
  * 0 six-product bf16 split kernel, 1 fp32-input MFMA kernel, 2 streaming kernel of a degenerate shape (K = 1, N = 1, M = 1: no
  * MFMA), 3 screening pass with one fp16 product, 4 screening pass with three bf16 products, 5 two fp16 planes / three products. */
 int vnp_gemm_profile_next(hipEvent_t e0, hipEvent_t e1, int* kind);
