@@ -212,3 +212,48 @@ def test_flat_buffers_place_hinted_parameters_side_by_side():
     l2 = net[2]
     cat2 = ops.cat_rows(l2.map_to_feat.weight.detach(), l2.map_to_dir.weight.detach())                # not adjacent: a copy
     assert cat2.data_ptr() != l2.map_to_feat.weight.data_ptr() and torch.equal(cat2, torch.cat([l2.map_to_feat.weight, l2.map_to_dir.weight]).detach())
+
+
+def test_library_staleness_is_decided_by_a_source_hash(lib_built, tmp_path, monkeypatch):
+    """_lib.build(): an up-to-date library (the SHA-256 of csrc/*.hip, *.h recorded beside it) is returned without a lock file, a
+    directory or a compiler being touched — a read-only install works, and a copy to another machine (new file times) does not trigger a
+    rebuild at rendezvous time; an edited source makes it stale; a stale library that cannot be rebuilt is used with a warning."""
+    import shutil
+    import warnings
+    from vn_pointcloudcompletion_amd import _lib
+    assert _lib._up_to_date()
+    assert open(_lib._HASH_PATH).read().strip() == _lib._source_hash()
+    # a scratch copy of csrc with the library and its hash: stale after an edit, fresh again after the edit is undone
+    c2 = tmp_path / "csrc"
+    shutil.copytree(_lib.CSRC, c2, ignore=shutil.ignore_patterns("*.o", "*.bin"))
+    monkeypatch.setattr(_lib, "CSRC", str(c2))
+    monkeypatch.setattr(_lib, "LIB_PATH", str(c2 / "libvnpcc.so"))
+    monkeypatch.setattr(_lib, "_HASH_PATH", str(c2 / "build" / "libvnpcc.srchash"))
+    os.utime(c2 / "vnp_common.h", None)                       # newer file time, same content: still up to date
+    assert _lib._up_to_date()
+    lock = c2 / "build" / ".lock"
+    if lock.exists():
+        lock.unlink()
+    assert _lib.build() == str(c2 / "libvnpcc.so") and not lock.exists()          # no lock taken for an up-to-date library
+    src = c2 / "vnp_common.h"
+    text = src.read_text()
+    src.write_text(text + "\n// edited\n")
+    assert not _lib._up_to_date()
+    monkeypatch.setenv("HIPCC", str(tmp_path / "no-such-compiler"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert _lib.build() == str(c2 / "libvnpcc.so")                            # no compiler: the existing library, with a warning
+    assert any("cannot be rebuilt" in str(x.message) for x in w)
+    src.write_text(text)
+    assert _lib._up_to_date()
+
+
+def test_settle_gc_moves_the_heap_to_the_permanent_generation():
+    import gc
+    from vn_pointcloudcompletion_amd.train import settle_gc
+    before = gc.get_freeze_count()
+    try:
+        settle_gc()
+        assert gc.get_freeze_count() > before and gc.get_freeze_count() > 1000
+    finally:
+        gc.unfreeze()
