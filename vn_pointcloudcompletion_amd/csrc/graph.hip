@@ -253,14 +253,18 @@ __device__ __forceinline__ void vnp_knc_cswap(float& d, int& i, int j, bool keep
 template <int NPL>
 __device__ __forceinline__ void vnp_knc_select(const float (&v)[NPL], float m, int Nr, int k, int lane, float* wd, int* wi, int* io, float* dio)
 {
-    // ascending bitonic sort of the lane minima across the wave; T = the k-th smallest of them (k <= 64)
-    float sm_ = m; int si = lane;
+    // T = the k-th smallest of the 64 lane minima (k <= 64), by a bit-wise search instead of a sort (round 5): the minima are non-negative
+    // floats (or +inf), so their bit patterns order like the values, and T's bits are the largest pattern P with fewer than k minima
+    // strictly below it — 31 steps of one wave-wide compare + a scalar population count, no cross-lane permute (the 21-step bitonic
+    // network this replaces was a chain of 42 dependent LDS-crossbar permutes per query)
+    const unsigned mb = __float_as_uint(m);
+    unsigned tb = 0u;
 #pragma unroll
-    for (int kk = 2; kk <= 64; kk <<= 1)
-#pragma unroll
-        for (int j = kk >> 1; j > 0; j >>= 1)
-            vnp_knc_cswap(sm_, si, j, ((lane & j) == 0) == ((lane & kk) == 0));
-    const float T = __shfl(sm_, k - 1);
+    for (int bit = 30; bit >= 0; --bit) {
+        const unsigned cand = tb | (1u << bit);
+        if (__popcll(__ballot(mb < cand)) < k) tb = cand;
+    }
+    const float T = __uint_as_float(tb);
     int cnt = 0;
 #pragma unroll
     for (int u = 0; u < NPL; ++u) cnt += (v[u] <= T) ? 1 : 0;
