@@ -603,8 +603,8 @@ def main():
                                 "bytes_per_completed_point": round(sb / (B * Md), 1),
                                 "note": "PMC fabric bytes of ALL kernels of one step (recorded passes under profiles/) over this run's wall time per "
                                         "step; the step is matrix-pipe bound (roofline), so this fraction is a description, not a target: the "
-                                        "HBM-bound kernels themselves run at 4.7-5.6 TB/s (roofline_other), 0.95-1.0 of the chip's measured "
-                                        "mixed read/write ceiling (profiles/r02_hbm_yardstick.txt)"}
+                                        "HBM-bound kernels themselves run at 4.7-5.6 TB/s (roofline_other), 0.9-1.0 of the chip's measured "
+                                        "mixed read/write ceiling (5.0-5.7 TB/s by box: profiles/r02_hbm_yardstick.txt, r05_hbm_yardstick.txt)"}
         except Exception:
             pass
         steps_total = args.warmup + args.steps
